@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI in include/icikt.h (libicikt_hip.so, built in-tree by build()).
+
+There is no CPU implementation behind this module: if the shared library is missing, or no HIP
+device is usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libicikt_hip.so")
+SOURCES = [os.path.join(_PKG, "csrc", "icikt_kernels.hip"), os.path.join(_PKG, "csrc", "icikt_capi.cpp")]
+HEADERS = [os.path.join(_ROOT, "include", "icikt.h"), os.path.join(_PKG, "csrc", "icikt_device.h")]
+
+# include/icikt.h
+SUCCESS = 0
+E_NO_DEVICE = -6
+PERSPECTIVE = {"local": 0, "global": 1}
+ALTERNATIVE = {"two.sided": 0, "less": 1, "greater": 2}
+ALT_OTHER = 3
+FLAG_EXACT_INT64 = 1
+FLAG_TIMING = 2
+CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
+K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
+MAX_FEATURES = 65535
+
+REASON_OK, REASON_ALL_MISSING, REASON_SHORT, REASON_SINGLE_UNIQUE, REASON_TIES_EQ_TOTAL = range(5)
+REASON_WARNINGS = {
+    REASON_SHORT: "Warning: The vectors only have a single value, NA returned!",  # src/kendallc.cpp:225
+    REASON_SINGLE_UNIQUE: "Warning: Either 'X' or 'Y' have only a single unique value, NA returned!",  # :238
+    REASON_TIES_EQ_TOTAL: "Warning: Ties equal the total, NA returned!",  # :292
+}
+
+EXPORTS = (
+    "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
+    "icikt_ctx_set_stream", "icikt_sync", "icikt_prepare_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
+    "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
+    "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest",
+)
+
+
+class IciktError(RuntimeError):
+    pass
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels + C ABI for gfx950 into icikendalltau_amd/libicikt_hip.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_PKG, "csrc"),
+           "-o", LIB_PATH] + SOURCES
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise IciktError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        print(" ".join(cmd))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IciktError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+            "icikendalltau_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_u32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p
+    L.icikt_version.restype = c_int
+    L.icikt_device_count.argtypes = [ctypes.POINTER(c_int)]
+    L.icikt_ctx_create.argtypes = [c_int, ctypes.POINTER(c_vp)]
+    L.icikt_ctx_destroy.argtypes = [c_vp]
+    L.icikt_ctx_destroy.restype = None
+    L.icikt_last_error.argtypes = [c_vp]
+    L.icikt_last_error.restype = ctypes.c_char_p
+    L.icikt_ctx_set_stream.argtypes = [c_vp, c_vp]
+    L.icikt_sync.argtypes = [c_vp]
+    L.icikt_prepare_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_u32]
+    L.icikt_set_pairs.argtypes = [c_vp, c_vp, c_vp, c_i64]
+    L.icikt_set_pairs_combn.argtypes = [c_vp, c_i64, c_i64, c_i64]
+    L.icikt_num_pairs.argtypes = [c_vp]
+    L.icikt_num_pairs.restype = c_i64
+    L.icikt_run_dev.argtypes = [c_vp, c_int, c_int, c_int, c_u32, c_vp, c_vp, c_vp]
+    L.icikt_kernel_ms.argtypes = [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]
+    L.icikt_reset_timers.argtypes = [c_vp]
+    L.icikt_pairs_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u32,
+                                  c_vp, c_vp, c_vp]
+    L.icikt_pair_f64.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u32, c_vp, c_vp, c_vp]
+    L.icikt_missingness_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]
+    L.icikt_selftest.argtypes = [c_vp]
+    for name in EXPORTS:
+        if getattr(L, name).restype is not None and name not in ("icikt_last_error", "icikt_num_pairs"):
+            getattr(L, name).restype = c_int
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    lib().icikt_device_count(ctypes.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One HIP device + stream + workspaces (icikt_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = ctypes.c_void_p()
+        rc = lib().icikt_ctx_create(int(device), ctypes.byref(self._h))
+        if rc == E_NO_DEVICE:
+            raise IciktError("no usable HIP device: icikendalltau_amd computes on an MI355X only (no CPU fallback)")
+        if rc != SUCCESS:
+            raise IciktError(f"icikt_ctx_create(device={device}) failed with code {rc}")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().icikt_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc != SUCCESS:
+            msg = lib().icikt_last_error(self._h)
+            raise IciktError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+    # -- device-resident path --------------------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        self._chk(lib().icikt_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "icikt_ctx_set_stream")
+
+    def sync(self):
+        self._chk(lib().icikt_sync(self._h), "icikt_sync")
+
+    def prepare_dev(self, d_ptr: int, n_feat: int, n_samp: int, ld: int, flags: int = 0):
+        self._chk(lib().icikt_prepare_dev(self._h, ctypes.c_void_p(d_ptr), n_feat, n_samp, ld, flags),
+                  "icikt_prepare_dev")
+
+    def set_pairs(self, pi, pj):
+        pi = np.ascontiguousarray(pi, dtype=np.int32)
+        pj = np.ascontiguousarray(pj, dtype=np.int32)
+        if pi.shape != pj.shape or pi.ndim != 1:
+            raise ValueError("pi and pj must be 1-D arrays of the same length")
+        self._chk(lib().icikt_set_pairs(self._h, _ptr(pi), _ptr(pj), pi.shape[0]), "icikt_set_pairs")
+
+    def set_pairs_combn(self, n_samp: int, begin: int, end: int):
+        self._chk(lib().icikt_set_pairs_combn(self._h, n_samp, begin, end), "icikt_set_pairs_combn")
+
+    def num_pairs(self) -> int:
+        return int(lib().icikt_num_pairs(self._h))
+
+    def run_dev(self, perspective: int, alternative: int, continuity: bool, flags: int, d_out4: int,
+                d_counts: int | None = None, d_reasons: int | None = None):
+        self._chk(lib().icikt_run_dev(self._h, perspective, alternative, int(bool(continuity)), flags,
+                                      ctypes.c_void_p(d_out4), ctypes.c_void_p(d_counts or 0),
+                                      ctypes.c_void_p(d_reasons or 0)), "icikt_run_dev")
+
+    def kernel_ms(self, kernel: int):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self._chk(lib().icikt_kernel_ms(self._h, kernel, ctypes.byref(ms), ctypes.byref(n)), "icikt_kernel_ms")
+        return ms.value, n.value
+
+    def reset_timers(self):
+        self._chk(lib().icikt_reset_timers(self._h), "icikt_reset_timers")
+
+    def selftest(self):
+        self._chk(lib().icikt_selftest(self._h), "icikt_selftest")
+
+    # -- host-buffer path ------------------------------------------------------------------------
+    def pairs(self, X, pi=None, pj=None, perspective="global", alternative="two.sided", continuity=False,
+              flags: int = 0, want_counts: bool = True):
+        """ici_split() over a host matrix (n_feat x n_samp, NaN = missing); pairs 0-based or None = all."""
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        if Xf.ndim != 2:
+            raise ValueError("X must be 2-D (features x samples)")
+        n_feat, n_samp = Xf.shape
+        if pi is None:
+            P = n_samp * (n_samp - 1) // 2
+            pi_a = pj_a = None
+        else:
+            pi_a = np.ascontiguousarray(pi, dtype=np.int32)
+            pj_a = np.ascontiguousarray(pj, dtype=np.int32)
+            P = pi_a.shape[0]
+        out = np.empty((P, 4), dtype=np.float64)
+        cnt = np.zeros((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
+        rsn = np.zeros(P, dtype=np.int32)
+        alt = ALTERNATIVE.get(alternative, ALT_OTHER)
+        self._chk(lib().icikt_pairs_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a), P,
+                                        PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, _ptr(out),
+                                        _ptr(cnt), _ptr(rsn)), "icikt_pairs_f64")
+        return out, cnt, rsn
+
+    def pair(self, x, y, perspective="local", alternative="two.sided", continuity=False, flags: int = 0):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        out = np.empty(4, dtype=np.float64)
+        cnt = np.zeros(len(CNT_FIELDS), dtype=np.int64)
+        rsn = np.zeros(1, dtype=np.int32)
+        alt = ALTERNATIVE.get(alternative, ALT_OTHER)
+        self._chk(lib().icikt_pair_f64(self._h, _ptr(x), _ptr(y), x.shape[0], PERSPECTIVE[perspective], alt,
+                                       int(bool(continuity)), flags, _ptr(out), _ptr(cnt), _ptr(rsn)),
+                  "icikt_pair_f64")
+        return out, dict(zip(CNT_FIELDS, cnt.tolist())), int(rsn[0])
+
+    def missingness(self, X, pi, pj):
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        n_feat, n_samp = Xf.shape
+        pi_a = np.ascontiguousarray(pi, dtype=np.int32)
+        pj_a = np.ascontiguousarray(pj, dtype=np.int32)
+        out = np.zeros(pi_a.shape[0], dtype=np.int64)
+        self._chk(lib().icikt_missingness_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a),
+                                              _ptr(pj_a), pi_a.shape[0], _ptr(out)), "icikt_missingness_f64")
+        return out
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("ICIKT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

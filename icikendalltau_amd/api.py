@@ -1,0 +1,384 @@
+"""Host-side mirror of the reference's R interface for the all-pairs ICI-Kendall-tau path.
+
+R is not available in the build image, so the host logic the reference keeps in R
+(R/kendalltau.R:96-308,357-421,563-629; R/utils.R:1-66) is mirrored here in Python with the same
+function names, argument names, defaults, return shapes and error / warning texts, on top of the
+C ABI (include/icikt.h).  The R glue a maintainer would use instead lives in icikendalltau_amd/r/.
+
+Every number is computed by the HIP kernels through ``engine`` (default: the MI355X engine, which
+raises when no GPU is usable -- there is no CPU fallback).  ``engine`` exists so the sharding /
+gather / reshape logic can be exercised in CPU-only tests with a checker engine.
+"""
+from __future__ import annotations
+
+import math
+import time
+import warnings
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+
+try:  # pandas is the natural carrier of R's data.frame / dimnames; numpy-only callers still work
+    import pandas as pd
+except Exception:  # pragma: no cover
+    pd = None
+
+
+# --------------------------------------------------------------------------------------------------
+# engines
+# --------------------------------------------------------------------------------------------------
+class HipEngine:
+    """Runs pair lists on one MI355X through libicikt_hip.so."""
+
+    name = "hip"
+
+    def __init__(self, device: int | None = None, exact_int64: bool = False):
+        self.ctx = _lib.default_context(device)
+        self.flags = _lib.FLAG_EXACT_INT64 if exact_int64 else 0
+
+    def pairs(self, X, pi, pj, perspective, alternative, continuity):
+        out, _cnt, rsn = self.ctx.pairs(X, pi, pj, perspective, alternative, continuity, self.flags,
+                                        want_counts=False)
+        return out, rsn
+
+    def missingness(self, X, pi, pj):
+        return self.ctx.missingness(X, pi, pj)
+
+
+def _default_engine():
+    return HipEngine()
+
+
+# --------------------------------------------------------------------------------------------------
+# ici_kt: one pair (R/RcppExports.R:62-64 -> src/kendallc.cpp:166)
+# --------------------------------------------------------------------------------------------------
+class IciKtResult(tuple):
+    """Named numeric(4): c(tau, pvalue, tau_max, completeness) (src/kendallc.cpp:171-172)."""
+
+    names = ("tau", "pvalue", "tau_max", "completeness")
+
+    def __new__(cls, values):
+        return super().__new__(cls, (float(v) for v in values))
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return super().__getitem__(self.names.index(key))
+        return super().__getitem__(key)
+
+    tau = property(lambda self: self[0])
+    pvalue = property(lambda self: self[1])
+    tau_max = property(lambda self: self[2])
+    completeness = property(lambda self: self[3])
+
+    def __repr__(self):
+        return "IciKtResult(" + ", ".join(f"{n}={v!r}" for n, v in zip(self.names, self)) + ")"
+
+
+def _warn_reason(reason: int):
+    msg = _lib.REASON_WARNINGS.get(int(reason))
+    if msg:
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def ici_kt(x, y, perspective="local", alternative="two.sided", continuity=False, output="simple", engine=None):
+    """Information-content-informed Kendall tau-b of two vectors (NaN = missing).
+
+    Same defaults as the reference (src/kendallc.cpp:166).  ``output`` is accepted for signature
+    compatibility; the debug print of kendallc.cpp:342-363 is replaced by ``ici_kt_counts``.
+    """
+    x = np.asarray(x, dtype=np.float64).ravel()
+    y = np.asarray(y, dtype=np.float64).ravel()
+    if x.shape[0] != y.shape[0]:
+        raise ValueError("'X' and 'Y' are not the same length!")  # src/kendallc.cpp:168-170
+    if perspective not in ("local", "global"):
+        # the reference treats any string other than "local" as global (kendallc.cpp:180)
+        perspective = "global"
+    eng = engine or _default_engine()
+    X = np.empty((x.shape[0], 2), dtype=np.float64, order="F")
+    X[:, 0] = x
+    X[:, 1] = y
+    out, rsn = eng.pairs(X, np.array([0], np.int32), np.array([1], np.int32), perspective, alternative, continuity)
+    _warn_reason(rsn[0])
+    return IciKtResult(out[0])
+
+
+def ici_kt_counts(x, y, perspective="local", device=None, exact_int64=False):
+    """The integer counts ici_kt(..., output != "simple") prints (src/kendallc.cpp:342-363)."""
+    ctx = _lib.default_context(device)
+    out, cnt, rsn = ctx.pair(x, y, perspective, flags=_lib.FLAG_EXACT_INT64 if exact_int64 else 0)
+    return cnt, rsn
+
+
+# --------------------------------------------------------------------------------------------------
+# input checks (R/utils.R:1-66)
+# --------------------------------------------------------------------------------------------------
+def _as_matrix(data_matrix, colnames, arg):
+    """check_if_colnames_null / transform_to_matrix / check_if_numeric."""
+    if pd is not None and isinstance(data_matrix, pd.DataFrame):
+        print(f"i `{arg}` is a data.frame, converting to matrix ...")  # R/utils.R:53-57
+        if colnames is None:
+            colnames = [str(c) for c in data_matrix.columns]
+        data_matrix = data_matrix.to_numpy()
+    arr = np.asarray(data_matrix)
+    if colnames is None:
+        raise ValueError(f"Colnames of `{arg}` must be be specified.")  # R/utils.R:29-34 (sic)
+    if arr.dtype.kind not in "fiu":
+        raise TypeError(f"`{arg}` must be a numeric type.")  # R/utils.R:42-47
+    if arr.ndim != 2:
+        raise ValueError(f"`{arg}` must be a 2-D matrix (features x samples)")
+    colnames = [str(c) for c in colnames]
+    if len(colnames) != arr.shape[1]:
+        raise ValueError("length of colnames does not match the number of columns")
+    return np.asarray(arr, dtype=np.float64), colnames
+
+
+def setup_missing_matrix(data_matrix: np.ndarray, global_na) -> np.ndarray:
+    """Logical exclude_loc (R/utils.R:1-23)."""
+    exclude = np.zeros(data_matrix.shape, dtype=bool)
+    vals = [] if global_na is None else list(np.atleast_1d(np.asarray(global_na, dtype=np.float64)))
+    if len(vals) > 0:
+        if any(math.isnan(v) for v in vals):
+            exclude |= np.isnan(data_matrix)
+            vals = [v for v in vals if not math.isnan(v)]
+        if any(math.isinf(v) for v in vals):
+            exclude |= np.isinf(data_matrix)
+            vals = [v for v in vals if not math.isinf(v)]
+    for v in vals:
+        with np.errstate(invalid="ignore"):
+            exclude |= (data_matrix == v)
+    return exclude
+
+
+# --------------------------------------------------------------------------------------------------
+# setup_comparisons (R/kendalltau.R:181-278)
+# --------------------------------------------------------------------------------------------------
+def _is_vector_like(obj):
+    if isinstance(obj, (str, int, float, np.integer, np.floating)):
+        return True
+    if isinstance(obj, np.ndarray):
+        return obj.ndim <= 1
+    if isinstance(obj, (list, tuple)):
+        return all(isinstance(v, (str, int, float, np.integer, np.floating)) for v in obj)
+    return False
+
+
+def _r_str(v) -> str:
+    if isinstance(v, (float, np.floating)) and float(v).is_integer():
+        return str(int(v))  # as.character(1) == "1"
+    return str(v)
+
+
+def _recycle(a: Sequence, n: int):
+    return [a[i % len(a)] for i in range(n)]
+
+
+def setup_comparisons(samples, include_only=None, diag_good=True, ncore=1, include_arg="include_only"):
+    """Pair list in utils::combn order with include_only filtering; returns (i, j, core) 0-based arrays."""
+    n_sample = len(samples)
+    iu, ju = np.triu_indices(n_sample, k=1)  # row-major upper triangle == combn(n, 2) order
+    pi = iu.astype(np.int32)
+    pj = ju.astype(np.int32)
+    if not diag_good:  # self comparisons appended after all pairs (R/kendalltau.R:191-194)
+        d = np.arange(n_sample, dtype=np.int32)
+        pi = np.concatenate([pi, d])
+        pj = np.concatenate([pj, d])
+    names = np.asarray(samples, dtype=object)
+
+    if include_only is not None:
+        if pd is not None and isinstance(include_only, pd.DataFrame):
+            include_only = [include_only[c].tolist() for c in include_only.columns]
+        elif isinstance(include_only, dict):
+            include_only = list(include_only.values())
+        if _is_vector_like(include_only):
+            inc = {_r_str(v) for v in np.atleast_1d(np.asarray(include_only, dtype=object))}
+            s1_in = np.fromiter((names[i] in inc for i in pi), dtype=bool, count=len(pi))
+            s2_in = np.fromiter((names[j] in inc for j in pj), dtype=bool, count=len(pj))
+            keep = s1_in | s2_in  # R/kendalltau.R:210-212
+        elif isinstance(include_only, (list, tuple)):
+            if len(include_only) == 2:
+                l1 = [_r_str(v) for v in np.atleast_1d(np.asarray(include_only[0], dtype=object))]
+                l2 = [_r_str(v) for v in np.atleast_1d(np.asarray(include_only[1], dtype=object))]
+                m = max(len(l1), len(l2))
+                l1r, l2r = _recycle(l1, m), _recycle(l2, m)  # paste0 recycles
+                allowed = {f"{a}-{b}" for a, b in zip(l1r, l2r)} | {f"{b}-{a}" for a, b in zip(l1r, l2r)}
+                keep = np.fromiter((f"{names[i]}-{names[j]}" in allowed for i, j in zip(pi, pj)), dtype=bool,
+                                   count=len(pi))
+            else:
+                raise ValueError(
+                    f"`{include_arg}` must be a vector, a data.frame with two columns, or list of two vectors. "
+                    f"Currently, `length({include_arg})` returns {len(include_only)}")  # R/kendalltau.R:230-236
+        else:
+            raise ValueError(f"`{include_arg}` must be a vector, a data.frame with two columns, or list of two vectors.")
+        pi, pj = pi[keep], pj[keep]
+
+    n_todo = len(pi)
+    if n_todo == 0:
+        raise ValueError("No comparisons to do. Check the list of column names in "
+                         f"`{include_arg}` vs those in the samples.")  # R/kendalltau.R:240-247
+    n_each = int(math.ceil(n_todo / ncore))
+    core = (np.arange(n_todo) // n_each + 1).astype(np.int32)  # rep(seq(1, ncore), each = n_each)
+    return pi, pj, core
+
+
+# --------------------------------------------------------------------------------------------------
+# sharding over ranks: the reference's `core` chunks (R/kendalltau.R:250-255) become GPU ranks
+# --------------------------------------------------------------------------------------------------
+def _dist_info():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist, dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return None, 0, 1
+
+
+def _run_sharded(engine, X, pi, pj, core, perspective, alternative, continuity):
+    """Each rank computes the pairs whose `core` is rank+1, then all ranks gather everything."""
+    dist, rank, world = _dist_info()
+    if world == 1:
+        return engine.pairs(X, pi, pj, perspective, alternative, continuity)
+    import torch
+    mine = np.nonzero(core == rank + 1)[0]
+    if len(mine):
+        out_l, rsn_l = engine.pairs(X, pi[mine], pj[mine], perspective, alternative, continuity)
+    else:
+        out_l, rsn_l = np.empty((0, 4)), np.empty((0,), np.int32)
+    n_each = int(math.ceil(len(pi) / world))
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.full((n_each, 5), float("nan"), dtype=torch.float64)
+    buf[:len(mine), :4] = torch.from_numpy(np.ascontiguousarray(out_l))
+    buf[:len(mine), 4] = torch.from_numpy(rsn_l.astype(np.float64))
+    buf = buf.to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)  # RCCL over xGMI when backend == "nccl"
+    out = np.empty((len(pi), 4))
+    rsn = np.zeros(len(pi), np.int32)
+    for r in range(world):
+        idx = np.nonzero(core == r + 1)[0]
+        g = gathered[r].cpu().numpy()
+        out[idx] = g[:len(idx), :4]
+        rsn[idx] = g[:len(idx), 4].astype(np.int32)
+    return out, rsn
+
+
+# --------------------------------------------------------------------------------------------------
+# ici_kendalltau (R/kendalltau.R:96-179) + scale_and_reshape (:357-421)
+# --------------------------------------------------------------------------------------------------
+def _named_matrix(values: np.ndarray, names):
+    if pd is not None:
+        return pd.DataFrame(values, index=list(names), columns=list(names))
+    return values
+
+
+def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), perspective="global", scale_max=True,
+                   diag_good=True, include_only=None, alternative="two.sided", continuity=False,
+                   check_timing=False, return_matrix=True, colnames=None, engine=None):
+    """All-pairs ICI-Kendall-tau between the COLUMNS (samples) of a features x samples matrix.
+
+    Mirrors R/kendalltau.R:96-179: same argument names and defaults; returns a dict with ``cor, raw,
+    pvalue, taumax, completeness`` (samples x samples, un-computed cells 0), ``keep`` and ``run_time``,
+    or with ``return_matrix=False`` ``{"cor": data.frame(s1, s2, core, raw, pvalue, taumax,
+    completeness, cor), "run_time"}``.  Column names are required, as in the reference (``colnames=``
+    for a bare ndarray).
+    """
+    data_matrix, names = _as_matrix(data_matrix, colnames, "data_matrix")
+    exclude_loc = setup_missing_matrix(data_matrix, global_na)
+    exclude_data = np.asfortranarray(np.where(exclude_loc, np.nan, data_matrix))
+    n_sample = exclude_data.shape[1]
+
+    eng = engine or _default_engine()
+    _dist, _rank, world = _dist_info()
+    pi, pj, core = setup_comparisons(names, include_only, diag_good, ncore=world)
+    n_todo = len(pi)
+
+    if check_timing:  # R/kendalltau.R:141-148, 633-669
+        rng = np.random.default_rng()
+        first = np.nonzero(core == 1)[0]
+        pick = rng.choice(first, size=min(5, len(first)), replace=False)
+        t0 = time.perf_counter()
+        for p in pick:
+            eng.pairs(exclude_data, pi[p:p + 1], pj[p:p + 1], perspective, "two.sided", False)
+        t_total = time.perf_counter() - t0
+        n_comp = len(pick)
+        t_each = t_total / n_comp
+        t_theoretical = t_each * n_todo
+        t_cores = t_theoretical / world
+        which = ["n_tested", "n_todo", "time_tested", "time_single", "time_all", "time_across_cores",
+                 "time_minutes", "time_hours", "time_days"]
+        value = [n_comp, n_todo, t_total, t_each, t_theoretical, t_cores, t_cores / 60, t_cores / (60 * 60),
+                 t_cores / (60 * 60 * 60)]  # (sic) the reference divides by 60^3 for days
+        return pd.DataFrame({"which": which, "value": value}) if pd is not None else dict(zip(which, value))
+
+    t1 = time.perf_counter()
+    out, rsn = _run_sharded(eng, exclude_data, pi, pj, core, perspective, alternative, continuity)
+    t_diff = time.perf_counter() - t1
+    for r in rsn[rsn > 1]:
+        _warn_reason(r)
+
+    raw, pvalue, taumax, completeness = out[:, 0], out[:, 1], out[:, 2], out[:, 3]
+    n_good = (~exclude_loc).sum(axis=0).astype(np.float64)
+    frac_complete = n_good / exclude_loc.shape[0]
+
+    # scale_and_reshape
+    if scale_max:
+        max_cor = np.nanmax(taumax) if np.any(~np.isnan(taumax)) else np.nan  # max(taumax, na.rm = TRUE)
+        cor = raw / max_cor
+    else:
+        cor = raw.copy()
+    s1, s2 = pi.copy(), pj.copy()
+    core_col = core.astype(np.float64)
+    if diag_good:
+        d = np.arange(n_sample, dtype=np.int32)
+        s1 = np.concatenate([s1, d])
+        s2 = np.concatenate([s2, d])
+        core_col = np.concatenate([core_col, np.zeros(n_sample)])
+        diag = n_good / n_good.max()
+        raw = np.concatenate([raw, diag])
+        pvalue = np.concatenate([pvalue, np.zeros(n_sample)])
+        taumax = np.concatenate([taumax, np.ones(n_sample)])
+        completeness = np.concatenate([completeness, frac_complete])
+        cor = np.concatenate([cor, diag])
+
+    if return_matrix:
+        res = {}
+        for key, vals in (("cor", cor), ("raw", raw), ("pvalue", pvalue), ("taumax", taumax),
+                          ("completeness", completeness)):
+            m = np.zeros((n_sample, n_sample))
+            m[s1, s2] = vals
+            m[s2, s1] = vals
+            res[key] = _named_matrix(m, names)
+        res["keep"] = (~exclude_loc).T
+        res["run_time"] = t_diff
+        return res
+    names_arr = np.asarray(names, dtype=object)
+    cols = {"s1": names_arr[s1], "s2": names_arr[s2], "core": core_col, "raw": raw, "pvalue": pvalue,
+            "taumax": taumax, "completeness": completeness, "cor": cor}
+    return {"cor": pd.DataFrame(cols) if pd is not None else cols, "run_time": t_diff}
+
+
+# --------------------------------------------------------------------------------------------------
+# pairwise_completeness (R/kendalltau.R:563-629)
+# --------------------------------------------------------------------------------------------------
+def pairwise_completeness(data_matrix, global_na=(float("nan"), float("inf"), 0), include_only=None,
+                          return_matrix=True, colnames=None, engine=None):
+    data_matrix, names = _as_matrix(data_matrix, colnames, "data_matrix")
+    exclude_loc = setup_missing_matrix(data_matrix, global_na)
+    _dist, _rank, world = _dist_info()
+    pi, pj, core = setup_comparisons(names, include_only, diag_good=False, ncore=world)
+    eng = engine or _default_engine()
+    masked = np.asfortranarray(np.where(exclude_loc, np.nan, 0.0))
+    missingness = eng.missingness(masked, pi, pj).astype(np.float64)
+    completeness = 1 - (missingness / exclude_loc.shape[0])
+    if return_matrix:
+        m = np.zeros((len(names), len(names)))
+        m[pi, pj] = completeness
+        m[pj, pi] = completeness
+        return _named_matrix(m, names)
+    names_arr = np.asarray(names, dtype=object)
+    cols = {"s1": names_arr[pi], "s2": names_arr[pj], "core": core.astype(np.float64), "missingness": missingness,
+            "completeness": completeness}
+    return pd.DataFrame(cols) if pd is not None else cols

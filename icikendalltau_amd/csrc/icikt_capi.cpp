@@ -1,0 +1,562 @@
+// icikt_capi.cpp -- host side of the C ABI declared in include/icikt.h.
+//
+// Owns the HIP device/stream/workspaces of a context and sequences the three kernels of
+// icikt_kernels.hip.  There is deliberately NO CPU implementation of the arithmetic here: when no
+// HIP device is usable every entry point fails with ICIKT_E_NO_DEVICE / ICIKT_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "icikt.h"
+#include "icikt_device.h"
+
+using icikt::ColStats;
+using icikt::PairRaw;
+using icikt::PrepView;
+
+static_assert(ICIKT_CNT_FIELDS == icikt::ICIKT_CNT_FIELDS_, "counts record layout");
+static_assert(ICIKT_PERSPECTIVE_LOCAL == icikt::ICIKT_PERSPECTIVE_LOCAL_, "perspective code");
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct icikt_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop{};
+
+  // prepared matrix
+  bool prepared = false;
+  PrepView pv{};
+  DevBuf<uint16_t> order, hirow;
+  DevBuf<uint32_t> rec;
+  DevBuf<unsigned long long> mask, fillmask, gflag, sort_keys;
+  DevBuf<uint32_t> sort_idx;
+  DevBuf<ColStats> stats;
+  int sort_chunk = 0;
+
+  // pair list
+  int64_t n_pairs = -1;
+  int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
+  int n_units = 0;
+  int wpb = 0;  // waves per block the units were built for
+  DevBuf<int32_t> d_pi, d_pj, d_unit_start;
+  DevBuf<PairRaw> d_raw;
+  std::vector<int32_t> h_pi, h_pj, h_units;
+
+  // host-path staging
+  DevBuf<double> d_X, d_out4;
+  DevBuf<int64_t> d_counts;
+  DevBuf<int32_t> d_reasons;
+  DevBuf<uint32_t> d_self;
+
+  // timing
+  hipEvent_t ev[ICIKT_K_COUNT][2] = {};
+  bool ev_pending[ICIKT_K_COUNT] = {};
+  double ms[ICIKT_K_COUNT] = {};
+  int64_t launches[ICIKT_K_COUNT] = {};
+};
+
+namespace {
+
+int fail(icikt_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return fail((c), ICIKT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));     \
+  } while (0)
+
+int use_device(icikt_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  return ICIKT_SUCCESS;
+}
+
+// fold a pending event pair into the accumulated time (needs the events to have completed)
+int flush_timer(icikt_ctx* c, int k) {
+  if (!c->ev_pending[k]) return ICIKT_SUCCESS;
+  HIPCHK(c, hipEventSynchronize(c->ev[k][1]));
+  float t = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&t, c->ev[k][0], c->ev[k][1]));
+  c->ms[k] += (double)t;
+  c->launches[k] += 1;
+  c->ev_pending[k] = false;
+  return ICIKT_SUCCESS;
+}
+
+int timer_begin(icikt_ctx* c, int k, uint32_t flags) {
+  if (!(flags & ICIKT_FLAG_TIMING)) return ICIKT_SUCCESS;
+  int rc = flush_timer(c, k);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[k][0], c->stream));
+  return ICIKT_SUCCESS;
+}
+
+int timer_end(icikt_ctx* c, int k, uint32_t flags) {
+  if (!(flags & ICIKT_FLAG_TIMING)) return ICIKT_SUCCESS;
+  HIPCHK(c, hipEventRecord(c->ev[k][1], c->stream));
+  c->ev_pending[k] = true;
+  return ICIKT_SUCCESS;
+}
+
+// LDS plan of the pair kernel for a given n
+struct K1Plan {
+  int wpb;
+  bool stage;
+  size_t lds_bytes;
+  int perwave_bytes;
+};
+
+K1Plan plan_k1(const PrepView& pv) {
+  K1Plan pl{};
+  const int Wp4 = (pv.Wp + 3) & ~3;
+  pl.perwave_bytes = Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16); multiple of 16
+  const size_t lds_cap = 160 * 1024;
+  const size_t stage_bytes = (size_t)pv.n_pad * 4;
+  // stage the random-access column in LDS when it leaves room for >= 8 waves in a 2-block-per-CU
+  // layout; otherwise gather it from L2.
+  const char* env = getenv("ICIKT_K1_STAGE");
+  bool want_stage = stage_bytes + 8 * (size_t)pl.perwave_bytes <= lds_cap / 2;
+  if (env) want_stage = (env[0] == '1') && (stage_bytes + (size_t)pl.perwave_bytes <= lds_cap);
+  pl.stage = want_stage;
+  int wpb = 8;
+  const char* envw = getenv("ICIKT_K1_WPB");
+  if (envw) wpb = std::max(1, std::min(16, atoi(envw)));
+  size_t avail = lds_cap - (pl.stage ? stage_bytes : 0);
+  int fit = (int)(avail / (size_t)pl.perwave_bytes);
+  if (fit < 1) fit = 1;
+  pl.wpb = std::min(wpb, fit);
+  pl.lds_bytes = (pl.stage ? stage_bytes : 0) + (size_t)pl.wpb * pl.perwave_bytes;
+  return pl;
+}
+
+// units: maximal runs of <= wpb consecutive pairs sharing pi
+void build_units(icikt_ctx* c, int wpb) {
+  c->h_units.clear();
+  const int64_t P = c->n_pairs;
+  int64_t p = 0;
+  while (p < P) {
+    c->h_units.push_back((int32_t)p);
+    const int32_t b = c->h_pi[p];
+    int64_t e = p + 1;
+    while (e < P && e - p < wpb && c->h_pi[e] == b) ++e;
+    p = e;
+  }
+  c->h_units.push_back((int32_t)P);
+  c->n_units = (int)c->h_units.size() - 1;
+  c->wpb = wpb;
+}
+
+int upload_pairs(icikt_ctx* c) {
+  const int64_t P = c->n_pairs;
+  HIPCHK(c, c->d_pi.reserve((size_t)std::max<int64_t>(P, 1)));
+  HIPCHK(c, c->d_pj.reserve((size_t)std::max<int64_t>(P, 1)));
+  HIPCHK(c, c->d_raw.reserve((size_t)std::max<int64_t>(P, 1)));
+  if (P > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->d_pi.p, c->h_pi.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pj.p, c->h_pj.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  // the host vectors must outlive the async copies
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ICIKT_SUCCESS;
+}
+
+int upload_units(icikt_ctx* c) {
+  HIPCHK(c, c->d_unit_start.reserve(c->h_units.size()));
+  HIPCHK(c, hipMemcpyAsync(c->d_unit_start.p, c->h_units.data(), c->h_units.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ICIKT_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icikt_version(void) { return ICIKT_VERSION; }
+
+int icikt_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (count) *count = n;
+  return n > 0 ? ICIKT_SUCCESS : ICIKT_E_NO_DEVICE;
+}
+
+int icikt_ctx_create(int device, icikt_ctx** out) {
+  if (!out) return ICIKT_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ICIKT_E_NO_DEVICE;
+  if (device < 0 || device >= n) return ICIKT_E_INVALID;
+  icikt_ctx* c = new (std::nothrow) icikt_ctx();
+  if (!c) return ICIKT_E_NOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return ICIKT_E_HIP;
+  }
+  c->stream = c->own_stream;
+  for (int k = 0; k < ICIKT_K_COUNT; ++k)
+    for (int j = 0; j < 2; ++j)
+      if (hipEventCreate(&c->ev[k][j]) != hipSuccess) {
+        icikt_ctx_destroy(c);
+        return ICIKT_E_HIP;
+      }
+  *out = c;
+  return ICIKT_SUCCESS;
+}
+
+void icikt_ctx_destroy(icikt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->order.release(); c->hirow.release(); c->rec.release(); c->mask.release(); c->fillmask.release();
+  c->gflag.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
+  c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
+  c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
+  for (int k = 0; k < ICIKT_K_COUNT; ++k)
+    for (int j = 0; j < 2; ++j)
+      if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* icikt_last_error(const icikt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int icikt_ctx_set_stream(icikt_ctx* c, void* hip_stream) {
+  if (!c) return ICIKT_E_INVALID;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return ICIKT_SUCCESS;
+}
+
+int icikt_sync(icikt_ctx* c) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ICIKT_SUCCESS;
+}
+
+int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags) {
+  if (!c) return ICIKT_E_INVALID;
+  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, "prepare: bad matrix shape");
+  if (n_feat > ICIKT_MAX_FEATURES)
+    return fail(c, ICIKT_E_TOO_LONG, "prepare: n_feat exceeds ICIKT_MAX_FEATURES (65535)");
+  if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
+  int rc = use_device(c);
+  if (rc) return rc;
+  c->prepared = false;
+
+  PrepView pv{};
+  pv.n = (int)n_feat;
+  pv.n_pad = (int)((n_feat + 63) / 64 * 64);
+  if (pv.n_pad == 0) pv.n_pad = 64;
+  pv.W = (int)((n_feat + 63) / 64);
+  pv.Wp = pv.W + 1;
+  int np2 = 2;
+  while (np2 < pv.n) np2 <<= 1;
+  pv.npow2 = np2;
+  pv.n_samp = (int)n_samp;
+  const size_t S = (size_t)std::max<int64_t>(n_samp, 1);
+
+  HIPCHK(c, c->order.reserve(S * pv.n_pad));
+  HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
+  HIPCHK(c, c->rec.reserve(S * pv.n_pad));
+  HIPCHK(c, c->mask.reserve(S * pv.Wp));
+  HIPCHK(c, c->fillmask.reserve(S * pv.Wp));
+  HIPCHK(c, c->gflag.reserve(S * pv.Wp));
+  HIPCHK(c, c->stats.reserve(S));
+  // sort scratch: bounded to ~1 GiB
+  size_t chunk = std::min<size_t>(S, std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)np2 * 12)));
+  HIPCHK(c, c->sort_keys.reserve(chunk * np2));
+  HIPCHK(c, c->sort_idx.reserve(chunk * np2));
+  c->sort_chunk = (int)chunk;
+
+  pv.order = c->order.p; pv.hirow = c->hirow.p; pv.rec = c->rec.p;
+  pv.mask = c->mask.p; pv.fillmask = c->fillmask.p; pv.gflag = c->gflag.p;
+  pv.stats = c->stats.p; pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
+  c->pv = pv;
+
+  rc = timer_begin(c, ICIKT_K_PREPARE, flags);
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->stats.p, 0, S * sizeof(ColStats), c->stream));
+  if (n_feat > 0) {
+    for (int64_t c0 = 0; c0 < n_samp; c0 += (int64_t)chunk) {
+      const int nc = (int)std::min<int64_t>((int64_t)chunk, n_samp - c0);
+      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->stream));
+    }
+  }
+  rc = timer_end(c, ICIKT_K_PREPARE, flags);
+  if (rc) return rc;
+  c->prepared = true;
+  return ICIKT_SUCCESS;
+}
+
+int icikt_set_pairs(icikt_ctx* c, const int32_t* pi, const int32_t* pj, int64_t n_pairs) {
+  if (!c) return ICIKT_E_INVALID;
+  if (n_pairs < 0 || (n_pairs > 0 && (!pi || !pj))) return fail(c, ICIKT_E_INVALID, "set_pairs: bad pair list");
+  if (n_pairs >= ((int64_t)1 << 31) - 1) return fail(c, ICIKT_E_INVALID, "set_pairs: more than 2^31-2 pairs");
+  int rc = use_device(c);
+  if (rc) return rc;
+  int32_t mx = -1;
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    if (pi[p] < 0 || pj[p] < 0) return fail(c, ICIKT_E_INVALID, "set_pairs: negative column index");
+    mx = std::max(mx, std::max(pi[p], pj[p]));
+  }
+  try {
+    c->h_pi.assign(pi, pi + n_pairs);
+    c->h_pj.assign(pj, pj + n_pairs);
+  } catch (const std::bad_alloc&) {
+    return fail(c, ICIKT_E_NOMEM, "set_pairs: host allocation failed");
+  }
+  c->n_pairs = n_pairs;
+  c->pairs_nsamp = (int64_t)mx + 1;
+  c->wpb = 0;  // units are (re)built at run time for the plan of the prepared matrix
+  return upload_pairs(c);
+}
+
+int icikt_set_pairs_combn(icikt_ctx* c, int64_t n_samp, int64_t begin, int64_t end) {
+  if (!c) return ICIKT_E_INVALID;
+  const int64_t total = n_samp * (n_samp - 1) / 2;
+  if (n_samp < 0 || begin < 0 || end < begin || end > total)
+    return fail(c, ICIKT_E_INVALID, "set_pairs_combn: range outside C(n_samp, 2)");
+  if (end - begin >= ((int64_t)1 << 31) - 1) return fail(c, ICIKT_E_INVALID, "set_pairs_combn: too many pairs");
+  int rc = use_device(c);
+  if (rc) return rc;
+  try {
+    c->h_pi.resize((size_t)(end - begin));
+    c->h_pj.resize((size_t)(end - begin));
+  } catch (const std::bad_alloc&) {
+    return fail(c, ICIKT_E_NOMEM, "set_pairs_combn: host allocation failed");
+  }
+  // walk combn order: row i holds pairs (i, i+1..S-1), starting at offset i*S - i(i+1)/2
+  int64_t i = 0, row_start = 0;
+  while (i < n_samp - 1 && row_start + (n_samp - 1 - i) <= begin) {
+    row_start += n_samp - 1 - i;
+    ++i;
+  }
+  int64_t j = i + 1 + (begin - row_start);
+  for (int64_t p = begin; p < end; ++p) {
+    c->h_pi[(size_t)(p - begin)] = (int32_t)i;
+    c->h_pj[(size_t)(p - begin)] = (int32_t)j;
+    if (++j >= n_samp) {
+      ++i;
+      j = i + 1;
+    }
+  }
+  c->n_pairs = end - begin;
+  c->pairs_nsamp = n_samp;
+  c->wpb = 0;
+  return upload_pairs(c);
+}
+
+int64_t icikt_num_pairs(const icikt_ctx* c) { return c ? c->n_pairs : -1; }
+
+int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity, uint32_t flags,
+                  double* d_out4, int64_t* d_counts, int32_t* d_reasons) {
+  if (!c) return ICIKT_E_INVALID;
+  if (!c->prepared) return fail(c, ICIKT_E_STATE, "run: icikt_prepare_dev has not been called");
+  if (c->n_pairs < 0) return fail(c, ICIKT_E_STATE, "run: no pair list set");
+  if (perspective != ICIKT_PERSPECTIVE_LOCAL && perspective != ICIKT_PERSPECTIVE_GLOBAL)
+    return fail(c, ICIKT_E_INVALID, "run: perspective must be local (0) or global (1)");
+  if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return fail(c, ICIKT_E_INVALID, "run: bad alternative code");
+  if (c->pairs_nsamp > c->pv.n_samp) return fail(c, ICIKT_E_INVALID, "run: pair list refers to a column >= n_samp");
+  if (c->n_pairs > 0 && !d_out4) return fail(c, ICIKT_E_INVALID, "run: null output");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->n_pairs == 0) return ICIKT_SUCCESS;
+
+  const K1Plan pl = plan_k1(c->pv);
+  if (c->wpb != pl.wpb) {
+    build_units(c, pl.wpb);
+    rc = upload_units(c);
+    if (rc) return rc;
+  }
+  if (c->pv.n > 0) {
+    rc = timer_begin(c, ICIKT_K_PAIRS, flags);
+    if (rc) return rc;
+    HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.wpb,
+                               pl.stage, pl.lds_bytes, pl.perwave_bytes, c->stream));
+    rc = timer_end(c, ICIKT_K_PAIRS, flags);
+    if (rc) return rc;
+  }
+  rc = timer_begin(c, ICIKT_K_EPILOGUE, flags);
+  if (rc) return rc;
+  HIPCHK(c, icikt::launch_k2(c->pv, c->d_pi.p, c->d_pj.p, c->d_raw.p, c->n_pairs, perspective, alternative,
+                             continuity ? 1 : 0, (flags & ICIKT_FLAG_EXACT_INT64) ? 1 : 0, d_out4, d_counts,
+                             d_reasons, c->stream));
+  return timer_end(c, ICIKT_K_EPILOGUE, flags);
+}
+
+int icikt_kernel_ms(icikt_ctx* c, int kernel, double* ms, int64_t* launches) {
+  if (!c || kernel < 0 || kernel >= ICIKT_K_COUNT) return ICIKT_E_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = flush_timer(c, kernel);
+  if (rc) return rc;
+  if (ms) *ms = c->ms[kernel];
+  if (launches) *launches = c->launches[kernel];
+  return ICIKT_SUCCESS;
+}
+
+int icikt_reset_timers(icikt_ctx* c) {
+  if (!c) return ICIKT_E_INVALID;
+  for (int k = 0; k < ICIKT_K_COUNT; ++k) {
+    int rc = flush_timer(c, k);
+    if (rc) return rc;
+    c->ms[k] = 0.0;
+    c->launches[k] = 0;
+  }
+  return ICIKT_SUCCESS;
+}
+
+int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                    const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
+                    int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
+  if (!c) return ICIKT_E_INVALID;
+  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, "pairs: bad matrix shape");
+  if (n_feat > ICIKT_MAX_FEATURES)
+    return fail(c, ICIKT_E_TOO_LONG, "pairs: n_feat exceeds ICIKT_MAX_FEATURES (65535)");
+  int rc = use_device(c);
+  if (rc) return rc;
+  // H2D (column by column when ld != n_feat)
+  const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
+  HIPCHK(c, c->d_X.reserve(nel));
+  if (n_feat > 0 && n_samp > 0) {
+    if (!X) return fail(c, ICIKT_E_INVALID, "pairs: null matrix");
+    HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
+                               (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
+  }
+  rc = icikt_prepare_dev(c, c->d_X.p, n_feat, n_samp, std::max<int64_t>(n_feat, 0), flags);
+  if (rc) return rc;
+  if (pi == nullptr) {
+    rc = icikt_set_pairs_combn(c, n_samp, 0, n_samp * (n_samp - 1) / 2);
+  } else {
+    for (int64_t p = 0; p < n_pairs; ++p)
+      if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
+        return fail(c, ICIKT_E_INVALID, "pairs: column index out of range");
+    rc = icikt_set_pairs(c, pi, pj, n_pairs);
+  }
+  if (rc) return rc;
+  const int64_t P = c->n_pairs;
+  if (P == 0) return ICIKT_SUCCESS;
+  if (!out4) return fail(c, ICIKT_E_INVALID, "pairs: null output");
+  HIPCHK(c, c->d_out4.reserve((size_t)P * 4));
+  if (counts) HIPCHK(c, c->d_counts.reserve((size_t)P * ICIKT_CNT_FIELDS));
+  if (reasons) HIPCHK(c, c->d_reasons.reserve((size_t)P));
+  rc = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, counts ? c->d_counts.p : nullptr,
+                     reasons ? c->d_reasons.p : nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(out4, c->d_out4.p, (size_t)P * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (counts)
+    HIPCHK(c, hipMemcpyAsync(counts, c->d_counts.p, (size_t)P * ICIKT_CNT_FIELDS * sizeof(int64_t),
+                             hipMemcpyDeviceToHost, c->stream));
+  if (reasons)
+    HIPCHK(c, hipMemcpyAsync(reasons, c->d_reasons.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ICIKT_SUCCESS;
+}
+
+int icikt_pair_f64(icikt_ctx* c, const double* x, const double* y, int64_t n, int perspective, int alternative,
+                   int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reason) {
+  if (!c) return ICIKT_E_INVALID;
+  if (n < 0 || (n > 0 && (!x || !y))) return fail(c, ICIKT_E_INVALID, "pair: bad vectors");
+  if (n > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, "pair: length exceeds ICIKT_MAX_FEATURES (65535)");
+  std::vector<double> xy;
+  try {
+    xy.resize((size_t)std::max<int64_t>(2 * n, 1));
+  } catch (const std::bad_alloc&) {
+    return fail(c, ICIKT_E_NOMEM, "pair: host allocation failed");
+  }
+  if (n > 0) {
+    memcpy(xy.data(), x, (size_t)n * sizeof(double));
+    memcpy(xy.data() + n, y, (size_t)n * sizeof(double));
+  }
+  const int32_t pi = 0, pj = 1;
+  return icikt_pairs_f64(c, xy.data(), n, 2, n, &pi, &pj, 1, perspective, alternative, continuity, flags, out4,
+                         counts, reason);
+}
+
+int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                          const int32_t* pi, const int32_t* pj, int64_t n_pairs, int64_t* missingness) {
+  if (!c) return ICIKT_E_INVALID;
+  if (n_feat < 0 || n_samp < 0 || ld < n_feat || n_pairs < 0) return fail(c, ICIKT_E_INVALID, "missingness: bad shape");
+  if (n_feat > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, "missingness: n_feat exceeds 65535");
+  if (n_pairs == 0) return ICIKT_SUCCESS;
+  if (!pi || !pj || !missingness) return fail(c, ICIKT_E_INVALID, "missingness: null argument");
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
+      return fail(c, ICIKT_E_INVALID, "missingness: column index out of range");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
+  HIPCHK(c, c->d_X.reserve(nel));
+  if (n_feat > 0 && n_samp > 0)
+    HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
+                               (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
+  rc = icikt_prepare_dev(c, c->d_X.p, n_feat, n_samp, n_feat, 0);
+  if (rc) return rc;
+  rc = icikt_set_pairs(c, pi, pj, n_pairs);
+  if (rc) return rc;
+  HIPCHK(c, c->d_counts.reserve((size_t)n_pairs));
+  HIPCHK(c, icikt::launch_missingness(c->pv, c->d_pi.p, c->d_pj.p, n_pairs, c->d_counts.p, c->stream));
+  HIPCHK(c, hipMemcpyAsync(missingness, c->d_counts.p, (size_t)n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ICIKT_SUCCESS;
+}
+
+int icikt_selftest(icikt_ctx* c) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, c->d_self.reserve(192));
+  HIPCHK(c, icikt::launch_selftest(c->d_self.p, c->stream));
+  uint32_t h[192];
+  HIPCHK(c, hipMemcpyAsync(h, c->d_self.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (uint32_t l = 0; l < 64; ++l) {
+    if (h[l] != (l + 1) * (l + 2) / 2) return fail(c, ICIKT_E_HIP, "selftest: wave_incl_scan mismatch");
+    if (h[64 + l] != (l == 0 ? 0xABCDu : 3u * (l - 1))) return fail(c, ICIKT_E_HIP, "selftest: wave_shr1 mismatch");
+    if (h[128 + l] != (l < 5 ? 0xFFFFFFFFu : l - 5)) return fail(c, ICIKT_E_HIP, "selftest: repeated wave_shr1 mismatch");
+  }
+  return ICIKT_SUCCESS;
+}
+
+}  // extern "C"

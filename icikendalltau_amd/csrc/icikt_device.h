@@ -1,0 +1,68 @@
+// icikt_device.h -- structures shared by the kernels (icikt_kernels.hip) and the C-ABI host side
+// (icikt_capi.cpp).  Internal; the public boundary is include/icikt.h.
+#ifndef ICIKT_DEVICE_H
+#define ICIKT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icikt {
+
+constexpr int ICIKT_PERSPECTIVE_LOCAL_ = 0;  // == ICIKT_PERSPECTIVE_LOCAL
+constexpr int ICIKT_CNT_FIELDS_ = 11;        // == ICIKT_CNT_FIELDS
+
+// Per-column result of the pre-pass (K0).
+struct ColStats {
+  int32_t nna;       // missing rows
+  int32_t ngroups;   // distinct values after the fill (unique(), kendallc.cpp:234-235)
+  int32_t tfill;     // size of the fill group (missing rows + rows equal to min-0.1); 0 if nna == 0
+  int32_t maxgroup;  // largest tie group
+  uint32_t s0, s1, s2;  // count_rank_tie sums in wrapping int32: t(t-1), t(t-1)(t-2), t(t-1)(2t+5)
+  uint32_t pad;
+  long long e0, e1, e2;  // the same sums exactly
+  double fill;           // min - 0.1
+};
+
+// Per-pair integers produced by K1 for the global perspective.
+struct PairRaw {
+  unsigned long long dis;   // #{(i,j): x_i < x_j, y_i > y_j}
+  unsigned long long ntie;  // #{i<j: x_i == x_j, y_i == y_j}
+  uint32_t c_both;          // rows missing in both columns
+  uint32_t g;               // rows in both fill groups (== c_both unless fl(min-0.1) == min)
+};
+
+// Device pointers + sizes of the prepared matrix (HBM layout).
+struct PrepView {
+  int n;       // n_feat (rows per column)
+  int n_pad;   // n rounded up to a multiple of 64
+  int W;       // ceil(n / 64) bitset words
+  int Wp;      // W + 1 (one zero guard word)
+  int npow2;   // sort scratch length per column
+  int n_samp;
+  // per column, stride n_pad
+  uint16_t* order;   // [S][n_pad]  row at processing position k (descending value)
+  uint32_t* rec;     // [S][n_pad]  per row: q | lo << 16  (ascending stable position, group start)
+  uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
+  // per column, stride Wp
+  unsigned long long* mask;      // [S][Wp] missing rows
+  unsigned long long* fillmask;  // [S][Wp] rows in the fill group
+  unsigned long long* gflag;     // [S][Wp] bit k: processing position k starts a tie group
+  ColStats* stats;               // [S]
+  // sort scratch (per column of the current chunk)
+  unsigned long long* sort_keys;  // [chunk][npow2]
+  uint32_t* sort_idx;             // [chunk][npow2]
+};
+
+hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
+hipError_t launch_k1(const PrepView& pv, const int32_t* unit_start, int n_units, const int32_t* pi,
+                     const int32_t* pj, PairRaw* raw, int wpb, bool stage, size_t lds_bytes,
+                     int perwave_bytes, hipStream_t s);
+hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, const PairRaw* raw,
+                     int64_t n_pairs, int perspective, int alternative, int continuity, int exact64,
+                     double* out4, int64_t* counts, int32_t* reasons, hipStream_t s);
+hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                              int64_t* missing, hipStream_t s);
+hipError_t launch_selftest(uint32_t* d_out, hipStream_t s);
+
+}  // namespace icikt
+#endif

@@ -1,0 +1,791 @@
+// icikt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ICI-Kendall-tau pair engine.
+//
+// What is computed is what the reference's ici_kt() computes (src/kendallc.cpp:166-366); how it is
+// computed is re-designed for a 64-wide wavefront with LDS-resident bitsets -- see DESIGN.md.
+//
+//   K0  k0_prepare   one workgroup per column: NA bitset, fill = min - 0.1, stable sort, tie groups,
+//                    tie sums.  Replaces the two std::stable_sort calls per PAIR (kendallc.cpp:247,254)
+//                    by one sort per COLUMN.
+//   K1  k1_pairs     one column pair per wavefront: strict-discordance count and joint-tie count.
+//                    Replaces kendall_discordant's Fenwick tree (:69-100) and compare_both (:33-51).
+//   K2  k2_epilogue  one pair per lane: tau, tau_max, completeness, variance, z, p (:280-335), with
+//                    perspective = "local" DERIVED from the global counts.
+//
+// No MFMA: the work is integer compare / popcount / prefix-sum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "icikt_device.h"
+
+namespace icikt {
+
+// ------------------------------------------------------------------------------------------------
+// wavefront primitives (wave64, DPP)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// whole-wave shift right by one lane; lane 0 keeps `old`
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 / 31
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Orders this wave's LDS traffic for the compiler: lanes of one wave exchange data through LDS
+// (atomic OR by one lane, read by another).  The hardware keeps one wave's DS operations in order;
+// this keeps the compiler from moving accesses across the hand-off.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
+  return (1ull << bits) - 1ull;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: per-column pre-pass
+// ------------------------------------------------------------------------------------------------
+constexpr int K0_THREADS = 1024;
+
+__device__ __forceinline__ unsigned long long sortable_key(double v) {
+  if (v == 0.0) v = 0.0;  // -0.0 and +0.0 tie (x[i] < x[j] is false both ways, kendallc.cpp:9,23)
+  long long b = __double_as_longlong(v);
+  unsigned long long u = (unsigned long long)b;
+  return (b < 0) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// block-wide reductions through LDS scratch (K0_THREADS entries)
+template <typename T, typename Op>
+__device__ T block_reduce(T v, T* scratch, Op op) {
+  const int tid = threadIdx.x;
+  scratch[tid] = v;
+  __syncthreads();
+  for (int s = K0_THREADS / 2; s > 0; s >>= 1) {
+    if (tid < s) scratch[tid] = op(scratch[tid], scratch[tid + s]);
+    __syncthreads();
+  }
+  T r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(K0_THREADS)
+k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin) {
+  __shared__ long long sh_ll[K0_THREADS];
+  __shared__ int sh_i[K0_THREADS];
+  __shared__ unsigned long long sh_bits[1024];  // fill-group bitset, W <= 1024 words
+
+  const int c = col_begin + blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int n = pv.n;
+  const int W = pv.W;
+  const int npow2 = pv.npow2;
+  const double* col = X + (int64_t)c * ld;
+  unsigned long long* keys = pv.sort_keys + (int64_t)blockIdx.x * npow2;
+  uint32_t* idx = pv.sort_idx + (int64_t)blockIdx.x * npow2;
+  unsigned long long* mask = pv.mask + (int64_t)c * pv.Wp;
+  unsigned long long* fmask = pv.fillmask + (int64_t)c * pv.Wp;
+  unsigned long long* gflag = pv.gflag + (int64_t)c * pv.Wp;
+  uint16_t* order = pv.order + (int64_t)c * pv.n_pad;
+  uint32_t* rec = pv.rec + (int64_t)c * pv.n_pad;
+  uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
+
+  // ---- phase 1: NA bitset, NA count, min of the non-missing values (kendallc.cpp:187-218) --------
+  double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
+  int nna = 0;
+  for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+    const int i = base + tid;
+    const double v = (i < n) ? col[i] : 0.0;
+    const bool isna = (i < n) && (v != v);
+    const unsigned long long b = __ballot(isna);
+    if (lane == 0 && (i >> 6) < W) mask[i >> 6] = b;
+    if (i < n && !isna) tmin = (v < tmin) ? v : tmin;
+    nna += isna ? 1 : 0;
+  }
+  if (tid == 0) { mask[W] = 0ull; }
+  // plain double min (no NaN among candidates)
+  {
+    __shared__ double sh_d[K0_THREADS];
+    sh_d[tid] = tmin;
+    __syncthreads();
+    for (int s = K0_THREADS / 2; s > 0; s >>= 1) {
+      if (tid < s) { double a = sh_d[tid], b = sh_d[tid + s]; sh_d[tid] = (b < a) ? b : a; }
+      __syncthreads();
+    }
+    tmin = sh_d[0];
+    __syncthreads();
+  }
+  nna = block_reduce<int>(nna, sh_i, [](int a, int b) { return a + b; });
+  const double fill = tmin - 0.1;  // kendallc.cpp:214-215, double arithmetic
+
+  // ---- phase 1b: sortable keys ------------------------------------------------------------------
+  for (int i = tid; i < npow2; i += K0_THREADS) {
+    unsigned long long k = ~0ull;
+    uint32_t id = 0xFFFFFFFFu;
+    if (i < n) {
+      double v = col[i];
+      if (v != v) v = fill;
+      k = sortable_key(v);
+      id = (uint32_t)i;
+    }
+    keys[i] = k;
+    idx[i] = id;
+  }
+  __syncthreads();
+
+  // ---- phase 2: bitonic sort of (key, row): the row index breaks ties, which makes the result the
+  //      stable order std::stable_sort gives in sortedIndex (kendallc.cpp:5-12) -------------------
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool up = ((i & k) == 0);
+        const unsigned long long ka = keys[i], kb = keys[l];
+        const uint32_t ia = idx[i], ib = idx[l];
+        const bool gt = (ka > kb) || (ka == kb && ia > ib);
+        if (gt == up) {
+          keys[i] = kb; keys[l] = ka;
+          idx[i] = ib; idx[l] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- phase 3: tie groups in ascending order -----------------------------------------------------
+  // thread t owns positions [k0, k1)
+  const int CH = (n + K0_THREADS - 1) / K0_THREADS;
+  const int k0 = min(n, tid * CH);
+  const int k1 = min(n, k0 + CH);
+  // last group start at or before the end of my chunk / first group end at or after its start
+  int last_start = -1;
+  int first_end = 0x7FFFFFFF;
+  for (int k = k0; k < k1; ++k) {
+    const unsigned long long kk = keys[k];
+    const bool st = (k == 0) || (keys[k - 1] != kk);
+    const bool en = (k == n - 1) || (keys[k + 1] != kk);
+    if (st) last_start = k;
+    if (en && first_end == 0x7FFFFFFF) first_end = k;
+  }
+  // exclusive max-scan of last_start over threads (Hillis-Steele in LDS)
+  sh_i[tid] = last_start;
+  __syncthreads();
+  for (int s = 1; s < K0_THREADS; s <<= 1) {
+    int v = sh_i[tid];
+    int o = (tid >= s) ? sh_i[tid - s] : -1;
+    __syncthreads();
+    sh_i[tid] = max(v, o);
+    __syncthreads();
+  }
+  int run_lo = (tid > 0) ? sh_i[tid - 1] : -1;
+  __syncthreads();
+  // exclusive reverse min-scan of first_end
+  sh_i[tid] = first_end;
+  __syncthreads();
+  for (int s = 1; s < K0_THREADS; s <<= 1) {
+    int v = sh_i[tid];
+    int o = (tid + s < K0_THREADS) ? sh_i[tid + s] : 0x7FFFFFFF;
+    __syncthreads();
+    sh_i[tid] = min(v, o);
+    __syncthreads();
+  }
+  const int next_end = (tid + 1 < K0_THREADS) ? sh_i[tid + 1] : 0x7FFFFFFF;
+  __syncthreads();
+
+  for (int w = tid; w < 1024; w += K0_THREADS) sh_bits[w] = 0ull;
+  __syncthreads();
+
+  // per-thread tie statistics over the groups that START in my chunk
+  int ngroups = 0, maxgroup = 0, tfill = 0;
+  uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
+  long long e0 = 0, e1 = 0, e2 = 0;     // exact
+  {  // backward sweep: last position of each row's tie group
+    int cur_hi = next_end;
+    for (int k = k1 - 1; k >= k0; --k) {
+      if ((k == n - 1) || (keys[k + 1] != keys[k])) cur_hi = k;
+      hirow[idx[k]] = (uint16_t)cur_hi;
+    }
+  }
+  for (int k = k0; k < k1; ++k) {
+    const unsigned long long kk = keys[k];
+    const bool st = (k == 0) || (keys[k - 1] != kk);
+    if (st) run_lo = k;
+    const int lo = run_lo;
+    const uint32_t row = idx[k];
+    const int hi = (int)hirow[row];  // written by this thread above
+    rec[row] = (uint32_t)k | ((uint32_t)lo << 16);
+    order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
+    if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
+    if (st) {
+      const int t = hi - lo + 1;
+      ++ngroups;
+      maxgroup = max(maxgroup, t);
+      if (lo == 0) tfill = t;
+      if (t >= 2) {
+        const uint32_t ut = (uint32_t)t;
+        const uint32_t tt1 = ut * (ut - 1u);
+        s0 += tt1;
+        s1 += tt1 * (ut - 2u);
+        s2 += tt1 * (2u * ut + 5u);
+        const long long lt = t;
+        e0 += lt * (lt - 1);
+        e1 += lt * (lt - 1) * (lt - 2);
+        e2 += lt * (lt - 1) * (2 * lt + 5);
+      }
+    }
+  }
+  __syncthreads();
+
+  // group-start flags in PROCESSING order k' = n-1-k: a group starts at k' where it ends at k
+  for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+    const int kp = base + tid;
+    bool flag = false;
+    if (kp < n) {
+      const int k = n - 1 - kp;
+      flag = (k == n - 1) || (keys[k] != keys[k + 1]);
+    }
+    const unsigned long long b = __ballot(flag);
+    if (lane == 0 && (kp >> 6) < W) gflag[kp >> 6] = b;
+  }
+  if (tid == 0) { gflag[W] = 0ull; }
+  for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
+
+  ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });
+  maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return a > b ? a : b; });
+  tfill = block_reduce<int>(tfill, sh_i, [](int a, int b) { return a > b ? a : b; });
+  s0 = (uint32_t)block_reduce<int>((int)s0, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
+  s1 = (uint32_t)block_reduce<int>((int)s1, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
+  s2 = (uint32_t)block_reduce<int>((int)s2, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
+  e0 = block_reduce<long long>(e0, sh_ll, [](long long a, long long b) { return a + b; });
+  e1 = block_reduce<long long>(e1, sh_ll, [](long long a, long long b) { return a + b; });
+  e2 = block_reduce<long long>(e2, sh_ll, [](long long a, long long b) { return a + b; });
+
+  if (tid == 0) {
+    ColStats st;
+    st.nna = nna;
+    st.ngroups = ngroups;
+    st.tfill = (nna > 0) ? tfill : 0;
+    st.maxgroup = maxgroup;
+    st.s0 = s0; st.s1 = s1; st.s2 = s2; st.pad = 0;
+    st.e0 = e0; st.e1 = e1; st.e2 = e2;
+    st.fill = fill;
+    pv.stats[c] = st;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one column pair per wavefront
+// ------------------------------------------------------------------------------------------------
+// Column B (= pi[p]) is the random-access side: rec[row] = q | lo << 16, where q is the row's
+// position in B's ascending stable order and lo the first position of its tie group.
+// Column A (= pj[p]) is the streamed side: order[k] = row at position k of A's DESCENDING order,
+// gflag bit k = "position k starts a new tie group of A".
+//
+// The wave walks A from the largest value down, 64 positions per step, and keeps in LDS
+//   seen : bitset over B-positions of every row whose A-group is strictly above the current one
+//   spre : per-64-bit-word exclusive prefix popcounts of seen
+// so that   #{rows j : a_j > a_l, b_j < b_l} = spre[lo_l >> 6] + popc(seen[lo_l >> 6] & below(lo_l)).
+// Rows of the SAME step are compared all-pairs with 63 whole-wave DPP shifts.  Rows of an A tie group
+// that is still open wait in `pend` (with prefix ppre) and are merged when the group closes; pend also
+// yields the joint ties of groups that span several steps.
+struct WaveLds {
+  unsigned long long* seen;
+  unsigned long long* pend;
+  uint16_t* spre;
+  uint16_t* ppre;
+};
+
+// prefix popcounts of bits[0..Wp); optionally first merges pend into bits and clears pend.
+__device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_t* pre,
+                                               unsigned long long* merge_from, int Wp, int items,
+                                               uint32_t lane) {
+  const int base = (int)lane * items;
+  uint32_t local = 0;
+  for (int i = 0; i < items; ++i) {
+    const int w = base + i;
+    if (w < Wp) {
+      unsigned long long v = bits[w];
+      if (merge_from) {
+        v |= merge_from[w];
+        bits[w] = v;
+        merge_from[w] = 0ull;
+      }
+      local += (uint32_t)__popcll(v);
+    }
+  }
+  uint32_t run = wave_incl_scan(local) - local;
+  for (int i = 0; i < items; ++i) {
+    const int w = base + i;
+    if (w < Wp) {
+      pre[w] = (uint16_t)run;
+      run += (uint32_t)__popcll(bits[w]);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t prefix_query(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
+  const uint32_t w = pos >> 6;
+  return (uint32_t)pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
+}
+
+template <bool STAGE>
+__global__ void __launch_bounds__(1024)
+k1_pairs(PrepView pv, const int32_t* __restrict__ unit_start, int n_units,
+         const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
+         int perwave_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // XCD-aware unit mapping: consecutive units share their staged column, so keep them on one XCD
+  // (workgroups are dealt round-robin over the 8 XCDs).  Bijective for any grid size.
+  int u;
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
+    const int qd = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    u = ((xcd < r) ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (orig >> 3);
+  }
+  if (u >= n_units) return;
+
+  const int n = pv.n, W = pv.W, Wp = pv.Wp;
+  const uint32_t lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int p0 = unit_start[u], p1 = unit_start[u + 1];
+  const int bcol = pi[p0];
+
+  uint32_t* recL = reinterpret_cast<uint32_t*>(smem);
+  const size_t stage_bytes = STAGE ? (size_t)pv.n_pad * 4u : 0u;
+  const uint32_t* recG = pv.rec + (int64_t)bcol * pv.n_pad;
+  if (STAGE) {
+    const uint4* src = reinterpret_cast<const uint4*>(recG);
+    uint4* dst = reinterpret_cast<uint4*>(recL);
+    const int nvec = pv.n_pad >> 2;  // n_pad is a multiple of 64
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int p = p0 + wave;
+  if (p >= p1) return;  // no barrier after this point
+  const int acol = pj[p];
+
+  unsigned char* wbase = smem + stage_bytes + (size_t)wave * perwave_bytes;
+  WaveLds L;
+  const int Wp4 = (Wp + 3) & ~3;
+  L.seen = reinterpret_cast<unsigned long long*>(wbase);
+  L.pend = L.seen + Wp4;
+  L.spre = reinterpret_cast<uint16_t*>(L.pend + Wp4);
+  L.ppre = L.spre + Wp4;
+  for (int w = lane; w < Wp4; w += 64) {
+    L.seen[w] = 0ull; L.pend[w] = 0ull; L.spre[w] = 0; L.ppre[w] = 0;
+  }
+
+  // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
+  uint32_t cb = 0, gg = 0;
+  {
+    const unsigned long long* ma = pv.mask + (int64_t)acol * Wp;
+    const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
+    const unsigned long long* fa = pv.fillmask + (int64_t)acol * Wp;
+    const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
+    for (int w = lane; w < W; w += 64) {
+      cb += (uint32_t)__popcll(ma[w] & mb[w]);
+      gg += (uint32_t)__popcll(fa[w] & fb[w]);
+    }
+  }
+  wave_lds_fence();
+
+  const uint16_t* ord = pv.order + (int64_t)acol * pv.n_pad;
+  const unsigned long long* gf = pv.gflag + (int64_t)acol * Wp;
+  const uint16_t* hiG = pv.hirow + (int64_t)bcol * pv.n_pad;
+  const int items = (Wp + 63) >> 6;
+  const int nb = (n + 63) >> 6;
+
+  uint32_t dis_acc = 0, tie_acc = 0;
+  unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
+
+  for (int t = 0; t < nb; ++t) {
+    const unsigned long long F = __builtin_amdgcn_readfirstlane((uint32_t)Fnext) |
+                                 ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(Fnext >> 32)) << 32);
+    Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
+    const bool Fn = (__builtin_amdgcn_readfirstlane((uint32_t)Fnext) & 1u) != 0u;  // next step opens a new group (or end)
+
+    const int k = t * 64 + (int)lane;
+    const bool valid = k < n;
+    const uint32_t row = valid ? (uint32_t)ord[k] : 0u;
+    const uint32_t r = STAGE ? recL[row] : recG[row];
+    const uint32_t q = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;   // never "below" anything
+    const uint32_t lo = valid ? (r >> 16) : 0u;               // nothing is below 0
+
+    // (1) rows of strictly higher A-groups that are already in `seen`
+    uint32_t cnt = prefix_query(L.seen, L.spre, lo);
+    dis_acc += valid ? cnt : 0u;
+
+    // (2) pairs inside this step
+    if (F == ~0ull) {
+      // every lane starts its own A-group: no A ties in this step
+      // lane 0 takes ~0 on the first shift and then keeps it (old = the register itself), so a lane
+      // that has run out of earlier rows compares against "never below"
+      uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
+      uint32_t c2 = (qs < lo) ? 1u : 0u;
+#pragma unroll
+      for (int s = 2; s < 64; ++s) {
+        qs = dpp_wave_shr1(qs, qs);
+        c2 += (qs < lo) ? 1u : 0u;
+      }
+      dis_acc += c2;
+    } else {
+      // general: xg = A-group ordinal inside the step; ties in A do not count as discordant, and
+      // rows tied in A and in B are joint ties (compare_both, kendallc.cpp:33-51)
+      const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
+      const uint32_t lot = valid ? lo : 0xFFFFFFFFu;
+      uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
+      uint32_t xs = dpp_wave_shr1(0xFFFFFFFFu, xg);
+      uint32_t ls = dpp_wave_shr1(0xFFFFFFFEu, lot);
+      uint32_t c2 = 0, c3 = 0;
+      for (int s = 1; s < 64; ++s) {
+        const bool same = (xs == xg);
+        c2 += (!same && qs < lo) ? 1u : 0u;
+        c3 += (same && ls == lot) ? 1u : 0u;
+        qs = dpp_wave_shr1(qs, qs);
+        xs = dpp_wave_shr1(xs, xs);
+        ls = dpp_wave_shr1(ls, ls);
+      }
+      dis_acc += valid ? c2 : 0u;
+      tie_acc += valid ? c3 : 0u;
+    }
+
+    // (3) joint ties with earlier steps of an A-group that is still open
+    const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
+    const bool olane = valid && ((int)lane < first_start);
+    if ((F & 1ull) == 0ull) {
+      uint32_t c4 = 0;
+      if (olane) {
+        const uint32_t ph = (uint32_t)hiG[row] + 1u;
+        c4 = prefix_query(L.pend, L.ppre, ph) - prefix_query(L.pend, L.ppre, lo);
+      }
+      tie_acc += c4;
+    }
+
+    // (4) insert this step's rows
+    wave_lds_fence();
+    const unsigned long long bit = 1ull << (q & 63u);
+    const uint32_t qw = (q & 0xFFFFu) >> 6;
+    if (F == 0ull) {
+      if (valid) atomicOr(&L.pend[qw], bit);
+      wave_lds_fence();
+      if (Fn) rebuild_prefix(L.seen, L.spre, L.pend, Wp, items, lane);
+      else rebuild_prefix(L.pend, L.ppre, nullptr, Wp, items, lane);
+    } else {
+      const int last_start = 63 - (int)__builtin_clzll(F);
+      const bool tlane = valid && ((int)lane >= last_start);
+      if (olane) atomicOr(&L.pend[qw], bit);
+      else if (valid && (Fn || !tlane)) atomicOr(&L.seen[qw], bit);
+      wave_lds_fence();
+      rebuild_prefix(L.seen, L.spre, ((F & 1ull) == 0ull) ? L.pend : nullptr, Wp, items, lane);
+      if (!Fn) {
+        wave_lds_fence();
+        if (tlane) atomicOr(&L.pend[qw], bit);
+        wave_lds_fence();
+        rebuild_prefix(L.pend, L.ppre, nullptr, Wp, items, lane);
+      }
+    }
+    wave_lds_fence();
+  }
+
+  const unsigned long long dis = wave_sum_u64(dis_acc);
+  const unsigned long long ntie = wave_sum_u64(tie_acc);
+  const unsigned long long cbs = wave_sum_u64(cb);
+  const unsigned long long ggs = wave_sum_u64(gg);
+  if (lane == 0) {
+    PairRaw o;
+    o.dis = dis;
+    o.ntie = ntie;
+    o.c_both = (uint32_t)cbs;
+    o.g = (uint32_t)ggs;
+    raw[p] = o;
+  }
+}
+
+template __global__ void k1_pairs<true>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
+template __global__ void k1_pairs<false>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
+
+// ------------------------------------------------------------------------------------------------
+// K2: epilogue, one pair per lane
+// ------------------------------------------------------------------------------------------------
+// R's pnorm (libR nmath pnorm_both): W. J. Cody, Math. Comp. 23 (1969) 631-637.
+__device__ void pnorm_both_dev(double x, double& cum, double& ccum) {
+  const double a[5] = {2.2352520354606839287, 161.02823106855587881, 1067.6894854603709582,
+                       18154.981253343561249, 0.065682337918207449113};
+  const double b[4] = {47.20258190468824187, 976.09855173777669322, 10260.932208618978205,
+                       45507.789335026729956};
+  const double c[9] = {0.39894151208813466764, 8.8831497943883759412, 93.506656132177855979,
+                       597.27027639480026226,  2494.5375852903726711, 6848.1904505362823326,
+                       11602.651437647350124,  9842.7148383839780218, 1.0765576773720192317e-8};
+  const double d[8] = {22.266688044328115691, 235.38790178262499861, 1519.377599407554805,
+                       6485.558298266760755,  18615.571640885098091, 34900.952721145977266,
+                       38912.003286093271411, 19685.429676859990727};
+  const double pp[6] = {0.21589853405795699,    0.1274011611602473639, 0.022235277870649807,
+                        0.001421619193227893466, 2.9112874951168792e-5, 0.02307344176494017303};
+  const double qq[5] = {1.28426009614491121,   0.468238212480865118, 0.0659881378689285515,
+                        0.00378239633202758244, 7.29751555083966205e-5};
+  if (x != x) { cum = x; ccum = x; return; }
+  const double y = fabs(x);
+  double xnum, xden, temp, xsq, del;
+  if (y <= 0.67448975) {
+    if (y > 1.1102230246251565e-16) {
+      xsq = x * x;
+      xnum = a[4] * xsq;
+      xden = xsq;
+      for (int i = 0; i < 3; ++i) { xnum = (xnum + a[i]) * xsq; xden = (xden + b[i]) * xsq; }
+    } else {
+      xnum = xden = 0.0;
+    }
+    temp = x * (xnum + a[3]) / (xden + b[3]);
+    cum = 0.5 + temp;
+    ccum = 0.5 - temp;
+  } else if (y <= 5.656854249492380195206754896838) {
+    xnum = c[8] * y;
+    xden = y;
+    for (int i = 0; i < 7; ++i) { xnum = (xnum + c[i]) * y; xden = (xden + d[i]) * y; }
+    temp = (xnum + c[7]) / (xden + d[7]);
+    xsq = trunc(y * 16) / 16;
+    del = (y - xsq) * (y + xsq);
+    cum = exp(-xsq * xsq * 0.5) * exp(-del * 0.5) * temp;
+    ccum = 1.0 - cum;
+    if (x > 0.) { temp = cum; cum = ccum; ccum = temp; }
+  } else if ((-37.5193 < x && x < 8.2924) || (-8.2924 < x && x < 37.5193)) {
+    xsq = 1.0 / (x * x);
+    xnum = pp[5] * xsq;
+    xden = xsq;
+    for (int i = 0; i < 4; ++i) { xnum = (xnum + pp[i]) * xsq; xden = (xden + qq[i]) * xsq; }
+    temp = xsq * (xnum + pp[4]) / (xden + qq[4]);
+    temp = (0.398942280401432677939946059934 - temp) / y;
+    xsq = trunc(x * 16) / 16;
+    del = (x - xsq) * (x + xsq);
+    cum = exp(-xsq * xsq * 0.5) * exp(-del * 0.5) * temp;
+    ccum = 1.0 - cum;
+    if (x > 0.) { temp = cum; cum = ccum; ccum = temp; }
+  } else {
+    if (x > 0) { cum = 1.; ccum = 0.; } else { cum = 0.; ccum = 1.; }
+  }
+}
+
+__device__ __forceinline__ void pnorm_tails(double z, double& lower, double& upper) {
+  if (isinf(z)) { lower = z > 0 ? 1.0 : 0.0; upper = 1.0 - lower; return; }
+  pnorm_both_dev(z, lower, upper);
+}
+
+// element of count_rank_tie's three sums for one tie group of size t, int32 arithmetic as uint32
+__device__ __forceinline__ void tie_terms32(int t, uint32_t& a0, uint32_t& a1, uint32_t& a2) {
+  if (t < 2) { a0 = a1 = a2 = 0; return; }
+  const uint32_t ut = (uint32_t)t, tt1 = ut * (ut - 1u);
+  a0 = tt1; a1 = tt1 * (ut - 2u); a2 = tt1 * (2u * ut + 5u);
+}
+__device__ __forceinline__ void tie_terms64(long long t, long long& a0, long long& a1, long long& a2) {
+  if (t < 2) { a0 = a1 = a2 = 0; return; }
+  a0 = t * (t - 1); a1 = t * (t - 1) * (t - 2); a2 = t * (t - 1) * (2 * t + 5);
+}
+
+__global__ void __launch_bounds__(256)
+k2_epilogue(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restrict__ pj,
+            const PairRaw* __restrict__ raw, int64_t n_pairs, int perspective, int alternative,
+            int continuity, int exact64, double* __restrict__ out4, int64_t* __restrict__ counts,
+            int32_t* __restrict__ reasons) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const double NA = __longlong_as_double(0x7FF00000000007A2ll);  // R's NA_real_
+  const ColStats sx = pv.stats[pi[p]];
+  const ColStats sy = pv.stats[pj[p]];
+  const PairRaw rw = (pv.n > 0) ? raw[p] : PairRaw{0ull, 0ull, 0u, 0u};
+  const long long n = pv.n;
+  const long long cb = rw.c_both;
+  const bool local = (perspective == ICIKT_PERSPECTIVE_LOCAL_);
+
+  int reason = 0;
+  double o_tau = NA, o_p = NA, o_tmax = NA, o_comp = NA;
+  long long cnt[ICIKT_CNT_FIELDS_] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  // kendallc.cpp:190-199; dropping the both-missing rows cannot change "all missing"
+  if (sx.nna == n || sy.nna == n) {
+    reason = 1;
+  } else {
+    const long long ne = local ? (n - cb) : n;                               // :180-185, :221
+    const long long missing = (long long)sx.nna + sy.nna - (local ? 2 * cb : cb);  // :208-211
+    const double completeness = 1.0 - (double)missing / (double)ne;
+    // a fill group vanishes under "local" when every member was a both-missing row
+    const int kx = sx.ngroups - ((local && sx.nna > 0 && sx.tfill == cb) ? 1 : 0);
+    const int ky = sy.ngroups - ((local && sy.nna > 0 && sy.tfill == cb) ? 1 : 0);
+    if (ne < 2) {
+      reason = 2;                                                            // :224-231
+    } else if (kx == 1 || ky == 1) {
+      reason = 3;                                                            // :234-244
+    } else {
+      const long long shrink = local ? cb : 0;
+      double xtie, x0, x1, ytie, y0, y1, ntie;
+      const long long g = rw.g, g2 = g - shrink;
+      const long long others = (long long)rw.ntie - g * (g - 1) / 2;          // joint ties outside the fill/fill cell
+      if (exact64) {
+        long long a0, a1, a2, b0, b1, b2;
+        tie_terms64(sx.tfill, a0, a1, a2); tie_terms64(sx.tfill - shrink, b0, b1, b2);
+        xtie = (double)((sx.e0 - a0 + b0) / 2); x0 = (double)((sx.e1 - a1 + b1) / 2); x1 = (double)(sx.e2 - a2 + b2);
+        tie_terms64(sy.tfill, a0, a1, a2); tie_terms64(sy.tfill - shrink, b0, b1, b2);
+        ytie = (double)((sy.e0 - a0 + b0) / 2); y0 = (double)((sy.e1 - a1 + b1) / 2); y1 = (double)(sy.e2 - a2 + b2);
+        ntie = (double)(others + (g2 >= 2 ? g2 * (g2 - 1) / 2 : 0));
+      } else {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        tie_terms32(sx.tfill, a0, a1, a2); tie_terms32((int)(sx.tfill - shrink), b0, b1, b2);
+        xtie = (double)((int32_t)(sx.s0 - a0 + b0) / 2); x0 = (double)((int32_t)(sx.s1 - a1 + b1) / 2);
+        x1 = (double)(int32_t)(sx.s2 - a2 + b2);
+        tie_terms32(sy.tfill, a0, a1, a2); tie_terms32((int)(sy.tfill - shrink), b0, b1, b2);
+        ytie = (double)((int32_t)(sy.s0 - a0 + b0) / 2); y0 = (double)((int32_t)(sy.s1 - a1 + b1) / 2);
+        y1 = (double)(int32_t)(sy.s2 - a2 + b2);
+        // sum((cnt * (cnt - 1)) / 2) in int32 (:267): only a cell of >= 46342 rows can wrap
+        const int32_t cell = (g2 >= 2) ? ((int32_t)((uint32_t)g2 * (uint32_t)(g2 - 1)) / 2) : 0;
+        ntie = (double)(int32_t)((uint32_t)others + (uint32_t)cell);
+      }
+      const long long dis = (long long)rw.dis;  // both-missing rows are never discordant
+      const long long tot = ne * (ne - 1) / 2;                                // :280
+      cnt[0] = ne; cnt[1] = missing; cnt[2] = dis; cnt[3] = (long long)ntie;
+      cnt[4] = (long long)xtie; cnt[5] = (long long)ytie; cnt[6] = (long long)x0; cnt[7] = (long long)x1;
+      cnt[8] = (long long)y0; cnt[9] = (long long)y1; cnt[10] = tot;
+      if (xtie == (double)tot || ytie == (double)tot) {
+        reason = 4;                                                           // :291-298
+      } else {
+        const double dtot = (double)tot;
+        const double con_minus_dis = dtot - xtie - ytie + ntie - 2.0 * (double)dis;  // :300
+        const double den = sqrt((dtot - xtie) * (dtot - ytie));
+        double tau = con_minus_dis / den;
+        const double con_plus_dis = dtot - xtie - ytie + ntie;
+        const double tau_max = con_plus_dis / den;                            // not clipped (:303)
+        if (tau > 1) tau = 1; else if (tau < -1) tau = -1;
+        const long long m = ne * (ne - 1);                                    // :310
+        const double var = (((double)(m * (2 * ne + 5)) - x1 - y1) / 18 + (2 * xtie * ytie) / (double)m +
+                            x0 * y0 / (double)(9 * m * (ne - 2)));            // :311-312
+        double s_adj = tau * sqrt(((double)(m / 2) - xtie) * ((double)(m / 2) - ytie));  // :315
+        if (continuity) {
+          const double sg = s_adj > 0 ? 1.0 : (s_adj == 0 ? 0.0 : -1.0);
+          s_adj = sg * (fabs(s_adj) - 1);                                     // :316-319
+        }
+        const double z = s_adj / sqrt(var);
+        double pval = 0.0, plo, pup;
+        pnorm_tails(z, plo, pup);
+        if (alternative == 1) pval = plo;                                     // "less"
+        else if (alternative == 2) pval = pup;                                // "greater"
+        else if (alternative == 0) {                                          // "two.sided": 2 * min
+          double mn = plo;
+          if (!(plo != plo)) { if (pup != pup) mn = pup; else if (pup < mn) mn = pup; }
+          pval = 2 * mn;
+        }
+        o_tau = tau; o_p = pval; o_tmax = tau_max; o_comp = completeness;
+      }
+    }
+  }
+  out4[4 * p + 0] = o_tau;
+  out4[4 * p + 1] = o_p;
+  out4[4 * p + 2] = o_tmax;
+  out4[4 * p + 3] = o_comp;
+  if (reasons) reasons[p] = reason;
+  if (counts) {
+    for (int f = 0; f < ICIKT_CNT_FIELDS_; ++f) counts[p * ICIKT_CNT_FIELDS_ + f] = cnt[f];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pairwise missingness (pairwise_completeness, R/kendalltau.R:611-629): popcount of mask OR
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_missingness(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, int64_t n_pairs,
+              int64_t* __restrict__ missing) {
+  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one pair per wave
+  if (p >= n_pairs) return;
+  const uint32_t lane = lane_id();
+  const unsigned long long* ma = pv.mask + (int64_t)pi[p] * pv.Wp;
+  const unsigned long long* mb = pv.mask + (int64_t)pj[p] * pv.Wp;
+  uint32_t c = 0;
+  for (int w = lane; w < pv.W; w += 64) c += (uint32_t)__popcll(ma[w] | mb[w]);
+  const unsigned long long tot = wave_sum_u64(c);
+  if (lane == 0) missing[p] = (int64_t)tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test of the DPP primitives
+// ------------------------------------------------------------------------------------------------
+__global__ void k_selftest(uint32_t* out) {
+  const uint32_t lane = lane_id();
+  out[lane] = wave_incl_scan(lane + 1u);                       // (lane+1)(lane+2)/2
+  out[64 + lane] = dpp_wave_shr1(0xABCDu, lane * 3u);          // lane 0: 0xABCD, else 3*(lane-1)
+  uint32_t v = dpp_wave_shr1(0xFFFFFFFFu, lane);
+  for (int s = 1; s < 5; ++s) v = dpp_wave_shr1(v, v);
+  out[128 + lane] = v;                                         // lanes < 5: ~0, else lane-5
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from icikt_capi.cpp; keeps <<<>>> syntax inside the .hip translation unit)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s) {
+  hipLaunchKernelGGL(k0_prepare, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
+  return hipGetLastError();
+}
+
+hipError_t launch_k1(const PrepView& pv, const int32_t* unit_start, int n_units, const int32_t* pi,
+                     const int32_t* pj, PairRaw* raw, int wpb, bool stage, size_t lds_bytes,
+                     int perwave_bytes, hipStream_t s) {
+  if (n_units <= 0) return hipSuccess;
+  hipError_t e;
+  if (stage) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_pairs<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k1_pairs<true>, dim3(n_units), dim3(wpb * 64), lds_bytes, s, pv, unit_start, n_units,
+                       pi, pj, raw, perwave_bytes);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_pairs<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k1_pairs<false>, dim3(n_units), dim3(wpb * 64), lds_bytes, s, pv, unit_start, n_units,
+                       pi, pj, raw, perwave_bytes);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, const PairRaw* raw,
+                     int64_t n_pairs, int perspective, int alternative, int continuity, int exact64,
+                     double* out4, int64_t* counts, int32_t* reasons, hipStream_t s) {
+  if (n_pairs <= 0) return hipSuccess;
+  const int threads = 256;
+  const int64_t blocks = (n_pairs + threads - 1) / threads;
+  hipLaunchKernelGGL(k2_epilogue, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, raw, n_pairs,
+                     perspective, alternative, continuity, exact64, out4, counts, reasons);
+  return hipGetLastError();
+}
+
+hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                              int64_t* missing, hipStream_t s) {
+  if (n_pairs <= 0) return hipSuccess;
+  const int threads = 256;
+  const int64_t blocks = (n_pairs * 64 + threads - 1) / threads;
+  hipLaunchKernelGGL(k_missingness, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, n_pairs, missing);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest(uint32_t* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
+  return hipGetLastError();
+}
+
+}  // namespace icikt

@@ -1,0 +1,157 @@
+/*
+ * icikt.h -- C ABI of the MI355X (gfx950) ICI-Kendall-tau pair engine.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *   ici_kendalltau() -> ici_split() -> ici_kt()   (R/kendalltau.R:96-308, src/kendallc.cpp:166-366).
+ * The reference crosses its FFI once per pair:
+ *   .Call('_ICIKendallTau_ici_kt', x, y, perspective, alternative, continuity, output)
+ *     R/RcppExports.R:62-64, C symbol SEXP _ICIKendallTau_ici_kt(SEXP x6) src/RcppExports.cpp:83-96
+ * This library moves the boundary up to the batch (ici_split, R/kendalltau.R:280-308): one call per
+ * pair LIST.  Plain pointers and sizes only; no R, Rcpp or torch types.  The R-side .Call glue a
+ * maintainer adds is in icikendalltau_amd/r/ and INTEGRATION.md.
+ *
+ * Conventions
+ *   - X is column-major n_feat x n_samp with leading dimension ld (R matrix layout; columns are
+ *     samples, R/kendalltau.R:6).  Missing = NaN of any payload (R's NA_real_ is a NaN;
+ *     Rcpp is_na() is true for NA and NaN, src/kendallc.cpp:181).
+ *   - Pair indices are 0-based column indices; pair p is ici_kt(x = X[, pi[p]], y = X[, pj[p]]).
+ *   - out4 is P x 4 row-major: tau, pvalue, tau_max, completeness (src/kendallc.cpp:171-172).
+ *     Degenerate pairs get R's NA_real_ bit pattern (0x7FF00000000007A2) in all four and a reason.
+ *   - All functions return ICIKT_SUCCESS (0) or a negative ICIKT_E_* code; the message is kept in
+ *     the context (icikt_last_error).  Nothing throws across the boundary.
+ *   - A context owns one HIP device, one stream and its workspaces.  Calls on one context must come
+ *     from one thread at a time.  Must not be used in a fork()ed child of a process that has
+ *     already created a context (R/utils.R:68-80 furrr multicore workers).
+ */
+#ifndef ICIKT_H
+#define ICIKT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICIKT_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define ICIKT_SUCCESS 0
+#define ICIKT_E_INVALID (-1)    /* bad argument (message says which) */
+#define ICIKT_E_HIP (-2)        /* HIP runtime error */
+#define ICIKT_E_NOMEM (-3)      /* host allocation failure */
+#define ICIKT_E_TOO_LONG (-4)   /* n_feat > ICIKT_MAX_FEATURES */
+#define ICIKT_E_STATE (-5)      /* call order: prepare / set_pairs before run */
+#define ICIKT_E_NO_DEVICE (-6)  /* no usable HIP device: the product path never falls back to CPU */
+
+/* n_feat limit of the uint16 rank path.  The reference's `int dis` (src/kendallc.cpp:78) and
+ * int32 tie sums are themselves only safe to n ~ 65 535. */
+#define ICIKT_MAX_FEATURES 65535
+
+/* perspective (src/kendallc.cpp:180) */
+#define ICIKT_PERSPECTIVE_LOCAL 0
+#define ICIKT_PERSPECTIVE_GLOBAL 1
+/* alternative (src/kendallc.cpp:323-332); OTHER = any unrecognised string: p-value stays 0 */
+#define ICIKT_ALT_TWO_SIDED 0
+#define ICIKT_ALT_LESS 1
+#define ICIKT_ALT_GREATER 2
+#define ICIKT_ALT_OTHER 3
+
+/* flags */
+#define ICIKT_FLAG_EXACT_INT64 1u /* tie sums in int64 instead of the reference's wrapping int32
+                                     (count_rank_tie, src/kendallc.cpp:112-114) */
+#define ICIKT_FLAG_TIMING 2u      /* record HIP events around each kernel (icikt_kernel_ms) */
+
+/* per-pair reason codes; the host wrapper raises the reference's warnings from them */
+#define ICIKT_OK 0
+#define ICIKT_NA_ALL_MISSING 1   /* src/kendallc.cpp:190-199: silent NA x4 */
+#define ICIKT_NA_SHORT 2         /* :224-231 "The vectors only have a single value, NA returned!" */
+#define ICIKT_NA_SINGLE_UNIQUE 3 /* :234-244 "Either 'X' or 'Y' have only a single unique value, NA returned!" */
+#define ICIKT_NA_TIES_EQ_TOTAL 4 /* :291-298 "Ties equal the total, NA returned!" */
+
+/* int64 counts record per pair (the integers src/kendallc.cpp:342-363 prints when output != "simple") */
+#define ICIKT_CNT_N 0        /* n_entry after the perspective's row filter */
+#define ICIKT_CNT_MISSING 1  /* rows with x or y missing (:208-211) */
+#define ICIKT_CNT_DIS 2      /* kendall_discordant (:69-100) */
+#define ICIKT_CNT_NTIE 3     /* joint ties (:267) */
+#define ICIKT_CNT_XTIE 4     /* count_rank_tie(x): ntie, t0, t1 (:102-118) */
+#define ICIKT_CNT_YTIE 5
+#define ICIKT_CNT_X0 6
+#define ICIKT_CNT_X1 7
+#define ICIKT_CNT_Y0 8
+#define ICIKT_CNT_Y1 9
+#define ICIKT_CNT_TOT 10     /* n(n-1)/2 (:280) */
+#define ICIKT_CNT_FIELDS 11
+
+/* kernel ids for icikt_kernel_ms */
+#define ICIKT_K_PREPARE 0  /* per-column rank pre-pass */
+#define ICIKT_K_PAIRS 1    /* pair kernel (discordance / joint-tie counting) */
+#define ICIKT_K_EPILOGUE 2 /* tau / p-value epilogue */
+#define ICIKT_K_COUNT 3
+
+typedef struct icikt_ctx icikt_ctx;
+
+int icikt_version(void);
+/* Number of visible HIP devices (0 and ICIKT_E_NO_DEVICE when none). */
+int icikt_device_count(int *count);
+
+int icikt_ctx_create(int device, icikt_ctx **ctx);
+void icikt_ctx_destroy(icikt_ctx *ctx);
+const char *icikt_last_error(const icikt_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int icikt_ctx_set_stream(icikt_ctx *ctx, void *hip_stream);
+int icikt_sync(icikt_ctx *ctx);
+
+/* ---- device-resident path (what bench.py and the multi-GPU driver call) -------------------- */
+
+/* Per-column pre-pass over a DEVICE matrix: NA bitsets, fill value min-0.1 (src/kendallc.cpp:214-219),
+ * stable argsort + dense tie groups (sortedIndex/compare_self, :5-31), tie sums (count_rank_tie).
+ * Asynchronous on the context's stream.  dX must stay valid until the stream reaches this point. */
+int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                      uint32_t flags);
+
+/* Pair list (HOST arrays, copied).  Mirrors setup_comparisons' output order (R/kendalltau.R:181-278). */
+int icikt_set_pairs(icikt_ctx *ctx, const int32_t *pi, const int32_t *pj, int64_t n_pairs);
+/* Pairs [begin, end) of utils::combn(n_samp, 2) order: (0,1),(0,2)...(0,S-1),(1,2)... (R/kendalltau.R:189).
+ * This is how ranks shard the upper triangle (reference: ceiling(n_todo/ncore) chunks, :250-255). */
+int icikt_set_pairs_combn(icikt_ctx *ctx, int64_t n_samp, int64_t begin, int64_t end);
+/* Number of pairs currently set. */
+int64_t icikt_num_pairs(const icikt_ctx *ctx);
+
+/* Pair kernel + epilogue into DEVICE buffers: d_out4 [P*4] doubles, d_counts [P*ICIKT_CNT_FIELDS]
+ * int64 or NULL, d_reasons [P] int32 or NULL.  Asynchronous on the context's stream. */
+int icikt_run_dev(icikt_ctx *ctx, int perspective, int alternative, int continuity, uint32_t flags,
+                  double *d_out4, int64_t *d_counts, int32_t *d_reasons);
+
+/* Accumulated HIP-event time (ms) and launch count of one kernel since the last reset; needs
+ * ICIKT_FLAG_TIMING on the calls being measured.  Synchronises the stream. */
+int icikt_kernel_ms(icikt_ctx *ctx, int kernel, double *ms, int64_t *launches);
+int icikt_reset_timers(icikt_ctx *ctx);
+
+/* ---- host-buffer path (what the R .Call glue binds) ----------------------------------------- */
+
+/* ici_split() replacement (R/kendalltau.R:280-308): H2D, pre-pass, pair kernel, epilogue, D2H.
+ * pi == NULL means all C(n_samp, 2) pairs in combn order.  counts / reasons may be NULL. */
+int icikt_pairs_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                    const int32_t *pi, const int32_t *pj, int64_t n_pairs, int perspective,
+                    int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
+                    int32_t *reasons);
+
+/* ici_kt() replacement for one pair of host vectors of equal length n (the caller checks lengths,
+ * src/kendallc.cpp:168-170). */
+int icikt_pair_f64(icikt_ctx *ctx, const double *x, const double *y, int64_t n, int perspective,
+                   int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
+                   int32_t *reason);
+
+/* pairwise_completeness() arithmetic (R/kendalltau.R:611-629): missingness[p] = #rows missing in
+ * either column, from a host matrix whose missing cells are NaN.  Self pairs allowed. */
+int icikt_missingness_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                          const int32_t *pi, const int32_t *pj, int64_t n_pairs, int64_t *missingness);
+
+/* Device self-test of the wavefront primitives the pair kernel relies on (DPP scan / shift). */
+int icikt_selftest(icikt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICIKT_H */

@@ -1,0 +1,196 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): integer pair counts bit-exact; tau / p-value / tau_max / completeness
+within 1e-10 absolute (double).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-10  # north_star tolerance for the four doubles
+
+
+def _oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _check(ctx, X, pi=None, pj=None, perspective="global", alternative="two.sided", continuity=False, flags=0):
+    O = _oracle()
+    S = X.shape[1]
+    if pi is None:
+        pi_o, pj_o = np.triu_indices(S, k=1)
+    else:
+        pi_o, pj_o = pi, pj
+    out, cnt, rsn = ctx.pairs(X, pi, pj, perspective, alternative, continuity, flags)
+    ref, rcnt, rrsn = O.ici_pairs(X, pi_o, pj_o, perspective, alternative, continuity, int32_compat=not (flags & 1))
+    assert np.array_equal(rsn, rrsn), (rsn[:20], rrsn[:20])
+    ok = rrsn == 0
+    assert np.array_equal(cnt[ok], rcnt[ok][:, :cnt.shape[1]]), "integer counts differ"
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    d = np.nanmax(np.abs(out - ref)) if np.any(~np.isnan(ref)) else 0.0
+    assert d <= ATOL, d
+    # NA pairs carry R's NA_real_ payload
+    na = np.isnan(out[:, 0]) & (rrsn != 0)
+    if na.any():
+        assert np.all(out[na].view(np.uint64) == np.uint64(0x7FF00000000007A2))
+    return out, cnt, rsn
+
+
+def test_selftest(hip_ctx):
+    hip_ctx.selftest()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 63, 64, 65, 127, 128, 129, 1000, 4097])
+@pytest.mark.parametrize("perspective", ["global", "local"])
+def test_random_with_na(hip_ctx, n, perspective):
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 6))
+    X[rng.random(X.shape) < 0.15] = np.nan
+    _check(hip_ctx, X, perspective=perspective)
+
+
+@pytest.mark.parametrize("levels", [2, 3, 7, 50])
+@pytest.mark.parametrize("perspective", ["global", "local"])
+def test_heavy_ties(hip_ctx, levels, perspective):
+    # both columns with tie groups >= 3 everywhere (exercises the reference's t0/2 quirk, Q1)
+    rng = np.random.default_rng(levels)
+    X = rng.integers(0, levels, size=(777, 8)).astype(np.float64)
+    X[rng.random(X.shape) < 0.1] = np.nan
+    _check(hip_ctx, X, perspective=perspective)
+    _check(hip_ctx, X, perspective=perspective, flags=1)
+
+
+def test_long_tie_groups_span_steps(hip_ctx):
+    # tie groups far longer than one 64-row step in both columns, sorted and shuffled
+    rng = np.random.default_rng(5)
+    n = 3000
+    a = np.repeat(np.arange(6.0), n // 6)
+    b = np.tile(np.repeat(np.arange(3.0), 100), n // 300)
+    c = rng.permutation(a)
+    d = rng.standard_normal(n)
+    d[:900] = np.nan
+    e = a.copy()
+    e[rng.random(n) < 0.3] = np.nan
+    X = np.stack([a, b, c, d, e, -a], axis=1)
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+
+
+def test_degenerate_columns(hip_ctx):
+    rng = np.random.default_rng(11)
+    n = 200
+    X = rng.standard_normal((n, 7))
+    X[:, 1] = np.nan                      # all missing -> NA x4, silent
+    X[:, 2] = 3.25                        # constant -> single unique value
+    X[5:, 3] = np.nan                     # 5 values, rest missing
+    X[:, 4] = np.where(np.arange(n) < 100, np.nan, 1.0)   # NA + constant: two groups
+    X[:, 5] = np.where(np.arange(n) < 100, 1.0, np.nan)   # complementary to col 4 in local mode
+    X[0, 6] = -0.0
+    X[1, 6] = 0.0
+    for p in ("global", "local"):
+        out, cnt, rsn = _check(hip_ctx, X, perspective=p)
+        assert set(rsn.tolist()) >= {0, 1, 3}
+
+
+def test_short_vectors(hip_ctx):
+    O = _oracle()
+    for n in (0, 1, 2):
+        x = np.arange(n, dtype=np.float64)
+        y = x[::-1].copy()
+        out, cnt, rsn = hip_ctx.pair(x, y, "global")
+        ref, rcnt, rr = O.ici_kt(x, y, "global")
+        assert rsn == rr
+        assert np.array_equal(np.isnan(out), np.isnan(ref))
+    # local: one surviving row
+    x = np.array([np.nan, np.nan, 1.0])
+    y = np.array([np.nan, np.nan, 2.0])
+    out, cnt, rsn = hip_ctx.pair(x, y, "local")
+    assert rsn == 2 and np.all(np.isnan(out))
+
+
+def test_fill_collides_with_min(hip_ctx):
+    # fl(min - 0.1) == min: missing values tie with the minimum (kendallc.cpp:214-219 taken literally)
+    rng = np.random.default_rng(3)
+    n = 500
+    X = rng.standard_normal((n, 4)) * 1e18
+    X[:, 0] = np.abs(X[:, 0]) + 1e18
+    X[rng.random(X.shape) < 0.2] = np.nan
+    X[:10, 0] = 1e18
+    X[:, 3] = np.where(np.isnan(X[:, 3]), np.nan, -np.inf)
+    X[::3, 3] = 7.0
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+
+
+@pytest.mark.parametrize("alternative", ["two.sided", "less", "greater", "bogus"])
+@pytest.mark.parametrize("continuity", [False, True])
+def test_alternatives(hip_ctx, alternative, continuity):
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((300, 5))
+    X[:, 1] = X[:, 0] + 0.5 * X[:, 1]
+    X[:, 2] = -X[:, 0] + 0.1 * X[:, 2]
+    X[rng.random(X.shape) < 0.05] = np.nan
+    _check(hip_ctx, X, alternative=alternative, continuity=continuity)
+
+
+def test_explicit_pair_list_and_self_pairs(hip_ctx):
+    rng = np.random.default_rng(23)
+    X = rng.standard_normal((400, 9))
+    X[rng.random(X.shape) < 0.1] = np.nan
+    pi = np.array([0, 0, 5, 8, 3, 3, 3, 2, 7, 1, 4], dtype=np.int32)
+    pj = np.array([1, 0, 2, 8, 4, 5, 6, 2, 0, 0, 4], dtype=np.int32)
+    _check(hip_ctx, X, pi, pj, perspective="global")
+    _check(hip_ctx, X, pi, pj, perspective="local")
+
+
+def test_golden_snapshot_50000(hip_ctx, golden_dir, expected):
+    # reference snapshot: tests/testthat/_snaps/kendall-tau.md:6-7 (n = 50 000, no ties)
+    z = np.load(f"{golden_dir}/snapshot_50000.npz")
+    out, cnt, rsn = hip_ctx.pair(z["x"], z["y"], "global")
+    e = expected["snapshot_50000"]
+    assert abs(out[0] - e["tau"]) < 5e-9 and abs(out[1] - e["pvalue"]) < 5e-9
+    assert out[2] == 1.0 and out[3] == 1.0
+    ref, rcnt, _ = _oracle().ici_kt(z["x"], z["y"], "global")
+    assert cnt["dis"] == rcnt["dis"] and np.max(np.abs(out - ref)) <= ATOL
+
+
+def test_golden_readme(hip_ctx, golden_dir, expected):
+    z = np.load(f"{golden_dir}/readme_s1_s4.npz")
+    e = expected["readme"]["r_4"]
+    out, cnt, rsn = hip_ctx.pair(z["s3"], z["s4"], "global")
+    assert abs(out[0] - e["raw"]) < 5e-8 and abs(out[2] - e["taumax"]) < 5e-7 and abs(out[3] - e["completeness"]) < 1e-12
+    assert abs(out[0] / out[2] - e["cor"]) < 5e-8
+    out, _, _ = hip_ctx.pair(z["s1"], z["s2"], "global")
+    assert out[0] == 1.0
+
+
+def test_yeast_config_c2(hip_ctx, golden_dir):
+    # BASELINE config c2: yeast_missing 6887 x 96, zeros -> NA, perspective = global (4 560 pairs);
+    # the oracle is checked on a pair subsample to keep the CPU side short.
+    z = np.load(f"{golden_dir}/yeast_missing.npz")
+    X = z["X"].copy()
+    X[X == 0] = np.nan
+    out, cnt, rsn = hip_ctx.pairs(X, perspective="global")
+    iu, ju = np.triu_indices(X.shape[1], k=1)
+    rng = np.random.default_rng(0)
+    sel = rng.choice(len(iu), 400, replace=False)
+    ref, rcnt, rrsn = _oracle().ici_pairs(X, iu[sel], ju[sel], "global")
+    assert np.array_equal(rsn[sel], rrsn)
+    assert np.array_equal(cnt[sel], rcnt[:, :cnt.shape[1]])
+    assert np.nanmax(np.abs(out[sel] - ref)) <= ATOL
+    out_l, cnt_l, rsn_l = hip_ctx.pairs(X, iu[sel], ju[sel], perspective="local")
+    ref_l, rcnt_l, rrsn_l = _oracle().ici_pairs(X, iu[sel], ju[sel], "local")
+    assert np.array_equal(cnt_l, rcnt_l[:, :cnt_l.shape[1]])
+    assert np.nanmax(np.abs(out_l - ref_l)) <= ATOL
+
+
+def test_missingness(hip_ctx):
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((333, 10))
+    X[rng.random(X.shape) < 0.2] = np.nan
+    pi, pj = np.triu_indices(10, k=0)
+    m = hip_ctx.missingness(X, pi, pj)
+    ref = np.array([(np.isnan(X[:, i]) | np.isnan(X[:, j])).sum() for i, j in zip(pi, pj)])
+    assert np.array_equal(m, ref)

@@ -79,6 +79,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.
+    # Importing torch FIRST lets the dynamic linker satisfy this library's NEEDED sonames with torch's
+    # copies; the other order loads /opt/rocm's runtime beside torch's and the second one finds no device.
+    if os.environ.get("ICIKT_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise IciktError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "

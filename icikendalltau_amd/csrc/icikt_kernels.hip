@@ -55,6 +55,14 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// a wave-uniform 64-bit value moved to scalar registers (readfirstlane returns a SIGNED int:
+// widen through uint32_t, or bit 31 smears into the upper word)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
 __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
   return (1ull << bits) - 1ull;
 }
@@ -419,10 +427,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ unit_start, int n_units,
   unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
 
   for (int t = 0; t < nb; ++t) {
-    const unsigned long long F = __builtin_amdgcn_readfirstlane((uint32_t)Fnext) |
-                                 ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(Fnext >> 32)) << 32);
+    const unsigned long long F = uniform_u64(Fnext);
     Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
-    const bool Fn = (__builtin_amdgcn_readfirstlane((uint32_t)Fnext) & 1u) != 0u;  // next step opens a new group (or end)
+    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // next step opens a new group (or end)
 
     const int k = t * 64 + (int)lane;
     const bool valid = k < n;
@@ -473,12 +480,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ unit_start, int n_units,
     const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
     const bool olane = valid && ((int)lane < first_start);
     if ((F & 1ull) == 0ull) {
-      uint32_t c4 = 0;
+      uint32_t c4 = 0, c5 = 0;
       if (olane) {
         const uint32_t ph = (uint32_t)hiG[row] + 1u;
         c4 = prefix_query(L.pend, L.ppre, ph) - prefix_query(L.pend, L.ppre, lo);
+      } else if (valid) {
+        // rows of later groups of this step also see the open group's earlier rows, still in pend
+        c5 = prefix_query(L.pend, L.ppre, lo);
       }
       tie_acc += c4;
+      dis_acc += c5;
     }
 
     // (4) insert this step's rows
@@ -730,8 +741,8 @@ __global__ void k_selftest(uint32_t* out) {
   out[lane] = wave_incl_scan(lane + 1u);                       // (lane+1)(lane+2)/2
   out[64 + lane] = dpp_wave_shr1(0xABCDu, lane * 3u);          // lane 0: 0xABCD, else 3*(lane-1)
   uint32_t v = dpp_wave_shr1(0xFFFFFFFFu, lane);
-  for (int s = 1; s < 5; ++s) v = dpp_wave_shr1(v, v);
-  out[128 + lane] = v;                                         // lanes < 5: ~0, else lane-5
+  for (int s = 1; s < 41; ++s) v = dpp_wave_shr1(v, v);        // in-place chain, crosses DPP rows
+  out[128 + lane] = v;                                         // lanes < 41: ~0, else lane-41
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ REASON_WARNINGS = {
 
 EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
-    "icikt_ctx_set_stream", "icikt_sync", "icikt_prepare_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
+    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
     "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest",
 )
@@ -102,6 +102,7 @@ def lib():
     L.icikt_last_error.argtypes = [c_vp]
     L.icikt_last_error.restype = ctypes.c_char_p
     L.icikt_ctx_set_stream.argtypes = [c_vp, c_vp]
+    L.icikt_ctx_use_own_stream.argtypes = [c_vp]
     L.icikt_sync.argtypes = [c_vp]
     L.icikt_prepare_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_u32]
     L.icikt_set_pairs.argtypes = [c_vp, c_vp, c_vp, c_i64]
@@ -163,7 +164,11 @@ class Context:
 
     # -- device-resident path --------------------------------------------------------------------
     def set_stream(self, hip_stream: int | None):
+        """Run on an existing hipStream_t (0 / None = HIP's default stream, e.g. torch's default)."""
         self._chk(lib().icikt_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "icikt_ctx_set_stream")
+
+    def use_own_stream(self):
+        self._chk(lib().icikt_ctx_use_own_stream(self._h), "icikt_ctx_use_own_stream")
 
     def sync(self):
         self._chk(lib().icikt_sync(self._h), "icikt_sync")

@@ -244,7 +244,7 @@ int icikt_ctx_create(int device, icikt_ctx** out) {
 void icikt_ctx_destroy(icikt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->mask.release(); c->fillmask.release();
   c->gflag.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
@@ -260,8 +260,15 @@ const char* icikt_last_error(const icikt_ctx* c) { return c ? c->err.c_str() : "
 
 int icikt_ctx_set_stream(icikt_ctx* c, void* hip_stream) {
   if (!c) return ICIKT_E_INVALID;
+  (void)hipStreamSynchronize(c->stream);
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL is HIP's default (null) stream
+  return ICIKT_SUCCESS;
+}
+
+int icikt_ctx_use_own_stream(icikt_ctx* c) {
+  if (!c) return ICIKT_E_INVALID;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = c->own_stream;
   return ICIKT_SUCCESS;
 }
 

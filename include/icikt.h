@@ -98,8 +98,10 @@ int icikt_device_count(int *count);
 int icikt_ctx_create(int device, icikt_ctx **ctx);
 void icikt_ctx_destroy(icikt_ctx *ctx);
 const char *icikt_last_error(const icikt_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own;
+ * NULL selects HIP's default (null) stream.  icikt_ctx_use_own_stream() switches back. */
 int icikt_ctx_set_stream(icikt_ctx *ctx, void *hip_stream);
+int icikt_ctx_use_own_stream(icikt_ctx *ctx);
 int icikt_sync(icikt_ctx *ctx);
 
 /* ---- device-resident path (what bench.py and the multi-GPU driver call) -------------------- */

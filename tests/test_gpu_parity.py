@@ -194,3 +194,51 @@ def test_missingness(hip_ctx):
     m = hip_ctx.missingness(X, pi, pj)
     ref = np.array([(np.isnan(X[:, i]) | np.isnan(X[:, j])).sum() for i, j in zip(pi, pj)])
     assert np.array_equal(m, ref)
+
+
+def test_combn_ranges_concatenate_to_full(hip_ctx):
+    """The multi-GPU sharding unit: contiguous [begin, end) blocks of combn order (bench.py, one per rank)."""
+    import torch
+    rng = np.random.default_rng(31)
+    n, S = 700, 23
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random(X.shape) < 0.1] = np.nan
+    full, _, _ = hip_ctx.pairs(X, perspective="global", want_counts=False)
+    P = S * (S - 1) // 2
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    hip_ctx.prepare_dev(dX.data_ptr(), n, S, n)
+    parts = []
+    world = 3
+    n_each = -(-P // world)
+    for r in range(world):
+        b, e = min(P, r * n_each), min(P, (r + 1) * n_each)
+        hip_ctx.set_pairs_combn(S, b, e)
+        assert hip_ctx.num_pairs() == e - b
+        out = torch.empty((e - b, 4), dtype=torch.float64, device="cuda")
+        hip_ctx.run_dev(1, 0, False, 0, out.data_ptr())
+        hip_ctx.sync()
+        parts.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(parts), full, equal_nan=True)
+
+
+def test_api_through_hip_engine(hip_ctx, golden_dir, expected):
+    """ici_kendalltau() / ici_kt() / pairwise_completeness() with the default (MI355X) engine."""
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+    z = np.load(f"{golden_dir}/readme_s1_s4.npz")
+    m2 = np.c_[z["s3"], z["s4"]]
+    r4 = api.ici_kendalltau(m2, colnames=["s3", "s4"], return_matrix=False)["cor"]
+    e = expected["readme"]["r_4"]
+    assert round(r4["raw"][0], 7) == e["raw"] and round(r4["cor"][0], 7) == e["cor"]
+    X = np.load(f"{golden_dir}/completeness_50x100.npz")["X"]
+    names = [f"s{i}" for i in range(1, 101)]
+    g = api.ici_kendalltau(X, colnames=names)
+    o = api.ici_kendalltau(X, colnames=names, engine=OracleEngine())
+    for k in ("cor", "raw", "pvalue", "taumax", "completeness"):
+        assert np.nanmax(np.abs(g[k].to_numpy() - o[k].to_numpy())) <= ATOL
+    assert np.array_equal(api.pairwise_completeness(X, colnames=names).to_numpy(),
+                          api.pairwise_completeness(X, colnames=names, engine=OracleEngine()).to_numpy())
+    res = api.ici_kt(z["s3"], z["s4"], "global")
+    assert round(res.tau, 7) == e["raw"]
+    with pytest.warns(RuntimeWarning, match="single unique value"):
+        api.ici_kt(np.arange(10.0), np.ones(10))

@@ -1,0 +1,118 @@
+/*
+ * icikt_rglue.c -- R .Call glue over the C ABI of include/icikt.h.
+ *
+ * NOT compiled in the build container (Rinternals.h is absent there); it is what a maintainer of the
+ * reference adds to src/ (or ships as a small companion package) to route ici_split()
+ * (R/kendalltau.R:280-308) and ici_kt() (R/RcppExports.R:62-64) through the MI355X library:
+ *
+ *   R CMD SHLIB icikt_rglue.c -I<repo>/include -L<repo>/icikendalltau_amd -licikt_hip
+ *
+ * Registered routines (R_CallMethodDef, as src/RcppExports.cpp:113-128 does for the Rcpp path):
+ *   .Call("icikt_R_pairs", exclude_data, pi, pj, perspective, alternative, continuity, device)
+ *       exclude_data  REALSXP matrix n_feat x n_samp (column-major, NA = missing; integer input is
+ *                     coerced by the R wrapper, as Rcpp does for NumericVector)
+ *       pi, pj        INTSXP, 1-based column indices (R convention); NULL = all combn pairs
+ *       returns list(raw, pvalue, taumax, completeness, reason) of length-P vectors
+ *   .Call("icikt_R_missingness", exclude_data, pi, pj, device) -> numeric(P)
+ * Errors become R errors (Rf_error), as BEGIN_RCPP/END_RCPP does (src/RcppExports.cpp:84,95);
+ * per-pair degenerate cases are returned as NA_real_ x4 plus a reason code so that the R wrapper can
+ * raise the reference's warning texts (src/kendallc.cpp:225,238,292).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <string.h>
+
+#include "icikt.h"
+
+static icikt_ctx *g_ctx = NULL;
+static int g_dev = -1;
+
+static icikt_ctx *get_ctx(int device) {
+  if (g_ctx && g_dev == device) return g_ctx;
+  if (g_ctx) { icikt_ctx_destroy(g_ctx); g_ctx = NULL; }
+  int rc = icikt_ctx_create(device, &g_ctx);
+  if (rc == ICIKT_E_NO_DEVICE) Rf_error("icikt: no usable HIP device (there is no CPU fallback)");
+  if (rc != ICIKT_SUCCESS) Rf_error("icikt: icikt_ctx_create(%d) failed with code %d", device, rc);
+  g_dev = device;
+  return g_ctx;
+}
+
+static int perspective_code(SEXP s) {
+  /* anything other than "local" is the global behaviour (src/kendallc.cpp:180) */
+  return strcmp(CHAR(STRING_ELT(s, 0)), "local") == 0 ? ICIKT_PERSPECTIVE_LOCAL : ICIKT_PERSPECTIVE_GLOBAL;
+}
+
+static int alternative_code(SEXP s) {
+  const char *a = CHAR(STRING_ELT(s, 0));
+  if (strcmp(a, "two.sided") == 0) return ICIKT_ALT_TWO_SIDED;
+  if (strcmp(a, "less") == 0) return ICIKT_ALT_LESS;
+  if (strcmp(a, "greater") == 0) return ICIKT_ALT_GREATER;
+  return ICIKT_ALT_OTHER; /* p-value stays 0, as in the reference (:323-332) */
+}
+
+SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative, SEXP continuity, SEXP device) {
+  if (!Rf_isReal(x) || !Rf_isMatrix(x)) Rf_error("icikt: exclude_data must be a double matrix");
+  const int64_t n_feat = Rf_nrows(x), n_samp = Rf_ncols(x);
+  icikt_ctx *ctx = get_ctx(Rf_asInteger(device));
+  int64_t P;
+  int32_t *pi0 = NULL, *pj0 = NULL;
+  if (Rf_isNull(pi)) {
+    P = n_samp * (n_samp - 1) / 2;
+  } else {
+    P = XLENGTH(pi);
+    if (XLENGTH(pj) != P) Rf_error("icikt: pi and pj differ in length");
+    pi0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+    pj0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+    for (int64_t p = 0; p < P; ++p) { pi0[p] = INTEGER(pi)[p] - 1; pj0[p] = INTEGER(pj)[p] - 1; }
+  }
+  double *out4 = (double *)R_alloc(P > 0 ? 4 * P : 1, sizeof(double));
+  int32_t *reasons = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+  int rc = icikt_pairs_f64(ctx, REAL(x), n_feat, n_samp, n_feat, pi0, pj0, P, perspective_code(perspective),
+                           alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u, out4, NULL, reasons);
+  if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_last_error(ctx), rc);
+  const char *nm[] = {"raw", "pvalue", "taumax", "completeness", "reason", ""};
+  SEXP res = PROTECT(Rf_mkNamed(VECSXP, nm));
+  for (int f = 0; f < 4; ++f) {
+    SEXP v = PROTECT(Rf_allocVector(REALSXP, P));
+    for (int64_t p = 0; p < P; ++p) REAL(v)[p] = out4[4 * p + f];
+    SET_VECTOR_ELT(res, f, v);
+    UNPROTECT(1);
+  }
+  SEXP r = PROTECT(Rf_allocVector(INTSXP, P));
+  for (int64_t p = 0; p < P; ++p) INTEGER(r)[p] = reasons[p];
+  SET_VECTOR_ELT(res, 4, r);
+  UNPROTECT(2);
+  return res;
+}
+
+SEXP icikt_R_missingness(SEXP x, SEXP pi, SEXP pj, SEXP device) {
+  if (!Rf_isReal(x) || !Rf_isMatrix(x)) Rf_error("icikt: exclude_data must be a double matrix");
+  const int64_t n_feat = Rf_nrows(x), n_samp = Rf_ncols(x), P = XLENGTH(pi);
+  icikt_ctx *ctx = get_ctx(Rf_asInteger(device));
+  int32_t *pi0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+  int32_t *pj0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+  int64_t *m = (int64_t *)R_alloc(P > 0 ? P : 1, sizeof(int64_t));
+  for (int64_t p = 0; p < P; ++p) { pi0[p] = INTEGER(pi)[p] - 1; pj0[p] = INTEGER(pj)[p] - 1; }
+  int rc = icikt_missingness_f64(ctx, REAL(x), n_feat, n_samp, n_feat, pi0, pj0, P, m);
+  if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_last_error(ctx), rc);
+  SEXP v = PROTECT(Rf_allocVector(REALSXP, P));
+  for (int64_t p = 0; p < P; ++p) REAL(v)[p] = (double)m[p];
+  UNPROTECT(1);
+  return v;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"icikt_R_pairs", (DL_FUNC)&icikt_R_pairs, 7},
+    {"icikt_R_missingness", (DL_FUNC)&icikt_R_missingness, 4},
+    {NULL, NULL, 0}};
+
+void R_init_icikt_rglue(DllInfo *dll) {
+  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
+
+void R_unload_icikt_rglue(DllInfo *dll) {
+  (void)dll;
+  if (g_ctx) { icikt_ctx_destroy(g_ctx); g_ctx = NULL; }
+}

@@ -68,7 +68,7 @@ struct icikt_ctx {
   int64_t n_pairs = -1;
   int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
   int n_units = 0;
-  int wpb = 0;  // waves per block the units were built for
+  int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<PairRaw> d_raw;
   std::vector<int32_t> h_pi, h_pj, h_units;
@@ -132,39 +132,38 @@ int timer_end(icikt_ctx* c, int k, uint32_t flags) {
   return ICIKT_SUCCESS;
 }
 
-// LDS plan of the pair kernel for a given n
+// launch plan of the pair kernel for a given n
 struct K1Plan {
-  int wpb;
-  bool stage;
+  int np;    // pairs per wave (1, 2 or 4), all sharing the streamed column
+  int wpb;   // waves per workgroup
   size_t lds_bytes;
-  int perwave_bytes;
+  int perpair_bytes;
 };
 
 K1Plan plan_k1(const PrepView& pv) {
   K1Plan pl{};
   const int Wp4 = (pv.Wp + 3) & ~3;
-  pl.perwave_bytes = Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16); multiple of 16
+  pl.perpair_bytes = Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16); multiple of 16
   const size_t lds_cap = 160 * 1024;
-  const size_t stage_bytes = (size_t)pv.n_pad * 4;
-  // stage the random-access column in LDS when it leaves room for >= 8 waves in a 2-block-per-CU
-  // layout; otherwise gather it from L2.
-  const char* env = getenv("ICIKT_K1_STAGE");
-  bool want_stage = stage_bytes + 8 * (size_t)pl.perwave_bytes <= lds_cap / 2;
-  if (env) want_stage = (env[0] == '1') && (stage_bytes + (size_t)pl.perwave_bytes <= lds_cap);
-  pl.stage = want_stage;
-  int wpb = 8;
-  const char* envw = getenv("ICIKT_K1_WPB");
-  if (envw) wpb = std::max(1, std::min(16, atoi(envw)));
-  size_t avail = lds_cap - (pl.stage ? stage_bytes : 0);
-  int fit = (int)(avail / (size_t)pl.perwave_bytes);
-  if (fit < 1) fit = 1;
+  // two pairs per wave ride the packed-u16 all-pairs loop; fall back to one when the per-wave LDS
+  // state would leave fewer than 8 waves per CU
+  int np = ((size_t)pl.perpair_bytes * 2 * 8 <= lds_cap) ? 2 : 1;
+  if (const char* e = getenv("ICIKT_K1_NP")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) np = v;
+  }
+  while (np > 1 && (size_t)pl.perpair_bytes * np > lds_cap) np >>= 1;
+  int wpb = 4;
+  if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
+  const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
+  pl.np = np;
   pl.wpb = std::min(wpb, fit);
-  pl.lds_bytes = (pl.stage ? stage_bytes : 0) + (size_t)pl.wpb * pl.perwave_bytes;
+  pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
   return pl;
 }
 
-// units: maximal runs of <= wpb consecutive pairs sharing pi
-void build_units(icikt_ctx* c, int wpb) {
+// tasks: maximal runs of <= np consecutive pairs sharing pi (one wave each)
+void build_units(icikt_ctx* c, int np) {
   c->h_units.clear();
   const int64_t P = c->n_pairs;
   int64_t p = 0;
@@ -172,12 +171,12 @@ void build_units(icikt_ctx* c, int wpb) {
     c->h_units.push_back((int32_t)p);
     const int32_t b = c->h_pi[p];
     int64_t e = p + 1;
-    while (e < P && e - p < wpb && c->h_pi[e] == b) ++e;
+    while (e < P && e - p < np && c->h_pi[e] == b) ++e;
     p = e;
   }
   c->h_units.push_back((int32_t)P);
   c->n_units = (int)c->h_units.size() - 1;
-  c->wpb = wpb;
+  c->wpb = np;
 }
 
 int upload_pairs(icikt_ctx* c) {
@@ -410,16 +409,16 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   if (c->n_pairs == 0) return ICIKT_SUCCESS;
 
   const K1Plan pl = plan_k1(c->pv);
-  if (c->wpb != pl.wpb) {
-    build_units(c, pl.wpb);
+  if (c->wpb != pl.np) {
+    build_units(c, pl.np);
     rc = upload_units(c);
     if (rc) return rc;
   }
   if (c->pv.n > 0) {
     rc = timer_begin(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
-    HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.wpb,
-                               pl.stage, pl.lds_bytes, pl.perwave_bytes, c->stream));
+    HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
+                               pl.wpb, pl.lds_bytes, pl.perpair_bytes, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
   }

@@ -301,20 +301,22 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one column pair per wavefront
+// K1: NP column pairs per wavefront (all NP pairs share the streamed column)
 // ------------------------------------------------------------------------------------------------
-// Column B (= pi[p]) is the random-access side: rec[row] = q | lo << 16, where q is the row's
-// position in B's ascending stable order and lo the first position of its tie group.
-// Column A (= pj[p]) is the streamed side: order[k] = row at position k of A's DESCENDING order,
-// gflag bit k = "position k starts a new tie group of A".
+// Column A (= pi of the task) is the streamed side: order[k] = row at position k of A's DESCENDING
+// order, gflag bit k = "position k starts a new tie group of A".
+// Columns B_0..B_{NP-1} (= pj of the task's pairs) are the random-access side: rec[row] = q | lo << 16,
+// q = the row's position in B's ascending stable order (unique), lo = first position of its tie group.
 //
-// The wave walks A from the largest value down, 64 positions per step, and keeps in LDS
+// The wave walks A from the largest value down, 64 positions per step (one row per lane), and keeps
+// per pair in LDS
 //   seen : bitset over B-positions of every row whose A-group is strictly above the current one
 //   spre : per-64-bit-word exclusive prefix popcounts of seen
 // so that   #{rows j : a_j > a_l, b_j < b_l} = spre[lo_l >> 6] + popc(seen[lo_l >> 6] & below(lo_l)).
-// Rows of the SAME step are compared all-pairs with 63 whole-wave DPP shifts.  Rows of an A tie group
-// that is still open wait in `pend` (with prefix ppre) and are merged when the group closes; pend also
-// yields the joint ties of groups that span several steps.
+// Rows of the SAME step are compared all-pairs with 63 whole-wave DPP shifts; two pairs ride in one
+// register as packed u16 (v_pk_sub_u16 clamp / v_pk_min_u16 / v_pk_add_u16), 4 VALU per shift for 2 pairs.
+// Rows of an A tie group that is still open wait in `pend` (prefix ppre) and are merged when the group
+// closes; pend also yields the joint ties (compare_both, kendallc.cpp:33-51) of groups spanning steps.
 struct WaveLds {
   unsigned long long* seen;
   unsigned long long* pend;
@@ -322,11 +324,72 @@ struct WaveLds {
   uint16_t* ppre;
 };
 
-// prefix popcounts of bits[0..Wp); optionally first merges pend into bits and clears pend.
+// In-step all-pairs loop for TWO pairs packed as u16 halves of one register.  One step is
+//   qs  = whole-wave shift right by one lane of qs (lane 0 keeps its value)
+//   acc.half += (qs.half < lo.half) ? 1 : 0      as  acc += min(sat_sub(lo, qs), 1)
+// All 62 in-place steps are ONE inline-asm statement because (a) from the equivalent C++ hipcc builds
+// each packed result out of two v_cmp, two v_cndmask and a v_perm, (b) with the DPP move inside the
+// statement the three packed ops of a step cover the two wait states a DPP needs after a VALU write
+// of its source (the first in-place DPP is likewise three instructions behind the out-of-place shift
+// that produced qs_first), and (c) hipcc pads every asm statement boundary with an s_nop.
+#define ICIKT_PKSTEP                                                      \
+  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_pk_sub_u16 %2, %3, %0 clamp\n\t"                                     \
+  "v_pk_min_u16 %2, %2, %4\n\t"                                           \
+  "v_pk_add_u16 %1, %1, %2\n\t"
+#define ICIKT_PKSTEP2 ICIKT_PKSTEP ICIKT_PKSTEP
+#define ICIKT_PKSTEP4 ICIKT_PKSTEP2 ICIKT_PKSTEP2
+#define ICIKT_PKSTEP8 ICIKT_PKSTEP4 ICIKT_PKSTEP4
+#define ICIKT_PKSTEP16 ICIKT_PKSTEP8 ICIKT_PKSTEP8
+#define ICIKT_PKSTEP32 ICIKT_PKSTEP16 ICIKT_PKSTEP16
+#define ICIKT_PKSTEP62 ICIKT_PKSTEP32 ICIKT_PKSTEP16 ICIKT_PKSTEP8 ICIKT_PKSTEP4 ICIKT_PKSTEP2
+
+// qs_first = the packed q's already shifted by one lane (lane 0 = 0xFFFF|0xFFFF, "never below").
+// Returns the packed per-lane counts over all 63 shift distances.
+__device__ __forceinline__ uint32_t pk_allpairs(uint32_t qs_first, uint32_t lop, uint32_t ones) {
+  uint32_t qs = qs_first, acc = 0, d;
+  asm volatile("v_pk_sub_u16 %2, %3, %0 clamp\n\t"
+               "v_pk_min_u16 %2, %2, %4\n\t"
+               "v_pk_add_u16 %1, %1, %2\n\t"
+               ICIKT_PKSTEP62
+               : "+v"(qs), "+v"(acc), "=&v"(d)
+               : "v"(lop), "v"(ones));
+  return acc;
+}
+
+// prefix popcounts of bits[0..Wp); optionally first merges merge_from into bits and clears merge_from.
+// Lane l owns words [l*items, (l+1)*items).
 __device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_t* pre,
                                                unsigned long long* merge_from, int Wp, int items,
                                                uint32_t lane) {
   const int base = (int)lane * items;
+  if (items <= 4) {
+    uint32_t pc[4];
+    uint32_t local = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int w = base + i;
+      pc[i] = 0;
+      if (i < items && w < Wp) {
+        unsigned long long v = bits[w];
+        if (merge_from) {
+          v |= merge_from[w];
+          bits[w] = v;
+          merge_from[w] = 0ull;
+        }
+        pc[i] = (uint32_t)__popcll(v);
+      }
+      local += pc[i];
+    }
+    uint32_t run = wave_incl_scan(local) - local;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int w = base + i;
+      if (i < items && w < Wp) pre[w] = (uint16_t)run;
+      run += pc[i];
+    }
+    return;
+  }
   uint32_t local = 0;
   for (int i = 0; i < items; ++i) {
     const int w = base + i;
@@ -355,185 +418,261 @@ __device__ __forceinline__ uint32_t prefix_query(const unsigned long long* bits,
   return (uint32_t)pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
 }
 
-template <bool STAGE>
-__global__ void __launch_bounds__(1024)
-k1_pairs(PrepView pv, const int32_t* __restrict__ unit_start, int n_units,
+template <int NP>
+__global__ void __launch_bounds__(512)
+k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
-         int perwave_bytes) {
+         int perpair_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // XCD-aware unit mapping: consecutive units share their staged column, so keep them on one XCD
+  // XCD-aware mapping: consecutive tasks share their streamed column, so keep them on one XCD
   // (workgroups are dealt round-robin over the 8 XCDs).  Bijective for any grid size.
-  int u;
+  int blk;
   {
     const int nwg = (int)gridDim.x, orig = (int)blockIdx.x;
     const int qd = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    u = ((xcd < r) ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (orig >> 3);
+    blk = ((xcd < r) ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (orig >> 3);
   }
-  if (u >= n_units) return;
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int task = __builtin_amdgcn_readfirstlane(blk * wpb + wave);
+  if (task >= n_tasks) return;  // the kernel has no workgroup barrier
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const uint32_t lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int p0 = unit_start[u], p1 = unit_start[u + 1];
-  const int bcol = pi[p0];
+  const int p0 = __builtin_amdgcn_readfirstlane(task_start[task]);
+  const int np = __builtin_amdgcn_readfirstlane(task_start[task + 1]) - p0;  // 1..NP pairs, same pi
+  const int acol = __builtin_amdgcn_readfirstlane(pi[p0]);
 
-  uint32_t* recL = reinterpret_cast<uint32_t*>(smem);
-  const size_t stage_bytes = STAGE ? (size_t)pv.n_pad * 4u : 0u;
-  const uint32_t* recG = pv.rec + (int64_t)bcol * pv.n_pad;
-  if (STAGE) {
-    const uint4* src = reinterpret_cast<const uint4*>(recG);
-    uint4* dst = reinterpret_cast<uint4*>(recL);
-    const int nvec = pv.n_pad >> 2;  // n_pad is a multiple of 64
-    for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-  }
-  const int p = p0 + wave;
-  if (p >= p1) return;  // no barrier after this point
-  const int acol = pj[p];
-
-  unsigned char* wbase = smem + stage_bytes + (size_t)wave * perwave_bytes;
-  WaveLds L;
   const int Wp4 = (Wp + 3) & ~3;
-  L.seen = reinterpret_cast<unsigned long long*>(wbase);
-  L.pend = L.seen + Wp4;
-  L.spre = reinterpret_cast<uint16_t*>(L.pend + Wp4);
-  L.ppre = L.spre + Wp4;
-  for (int w = lane; w < Wp4; w += 64) {
-    L.seen[w] = 0ull; L.pend[w] = 0ull; L.spre[w] = 0; L.ppre[w] = 0;
+  WaveLds L[NP];
+  const uint32_t* recG[NP];
+  const uint16_t* hiG[NP];
+  int bcol[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    // an unused slot repeats the task's last pair; its result is not written
+    bcol[k] = __builtin_amdgcn_readfirstlane(pj[p0 + (k < np ? k : np - 1)]);
+    recG[k] = pv.rec + (int64_t)bcol[k] * pv.n_pad;
+    hiG[k] = pv.hirow + (int64_t)bcol[k] * pv.n_pad;
+    unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
+    L[k].seen = reinterpret_cast<unsigned long long*>(wbase);
+    L[k].pend = L[k].seen + Wp4;
+    L[k].spre = reinterpret_cast<uint16_t*>(L[k].pend + Wp4);
+    L[k].ppre = L[k].spre + Wp4;
+    for (int w = lane; w < Wp4; w += 64) {
+      L[k].seen[w] = 0ull; L[k].pend[w] = 0ull; L[k].spre[w] = 0; L[k].ppre[w] = 0;
+    }
   }
 
   // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
-  uint32_t cb = 0, gg = 0;
+  uint32_t cb[NP], gg[NP];
   {
     const unsigned long long* ma = pv.mask + (int64_t)acol * Wp;
-    const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
     const unsigned long long* fa = pv.fillmask + (int64_t)acol * Wp;
-    const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
-    for (int w = lane; w < W; w += 64) {
-      cb += (uint32_t)__popcll(ma[w] & mb[w]);
-      gg += (uint32_t)__popcll(fa[w] & fb[w]);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const unsigned long long* mb = pv.mask + (int64_t)bcol[k] * Wp;
+      const unsigned long long* fb = pv.fillmask + (int64_t)bcol[k] * Wp;
+      cb[k] = 0; gg[k] = 0;
+      for (int w = lane; w < W; w += 64) {
+        cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
+        gg[k] += (uint32_t)__popcll(fa[w] & fb[w]);
+      }
     }
   }
   wave_lds_fence();
 
   const uint16_t* ord = pv.order + (int64_t)acol * pv.n_pad;
   const unsigned long long* gf = pv.gflag + (int64_t)acol * Wp;
-  const uint16_t* hiG = pv.hirow + (int64_t)bcol * pv.n_pad;
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
 
-  uint32_t dis_acc = 0, tie_acc = 0;
+  uint32_t dis_acc[NP], tie_acc[NP], tie2_acc[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) { dis_acc[k] = 0; tie_acc[k] = 0; tie2_acc[k] = 0; }
+
+  uint32_t pk_ones = 0x00010001u;
+  asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
   unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
+  uint32_t row_next = ((int)lane < n) ? (uint32_t)ord[lane] : 0u;
 
   for (int t = 0; t < nb; ++t) {
     const unsigned long long F = uniform_u64(Fnext);
     Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
-    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // next step opens a new group (or end)
+    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
 
-    const int k = t * 64 + (int)lane;
-    const bool valid = k < n;
-    const uint32_t row = valid ? (uint32_t)ord[k] : 0u;
-    const uint32_t r = STAGE ? recL[row] : recG[row];
-    const uint32_t q = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;   // never "below" anything
-    const uint32_t lo = valid ? (r >> 16) : 0u;               // nothing is below 0
+    const int kpos = t * 64 + (int)lane;
+    const bool valid = kpos < n;
+    const uint32_t row = row_next;
+    {  // prefetch the next step's rows
+      const int kn = kpos + 64;
+      row_next = (kn < n) ? (uint32_t)ord[kn] : 0u;
+    }
+    uint32_t q[NP], lo[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t r = recG[k][row];
+      q[k] = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
+      lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
+    }
 
     // (1) rows of strictly higher A-groups that are already in `seen`
-    uint32_t cnt = prefix_query(L.seen, L.spre, lo);
-    dis_acc += valid ? cnt : 0u;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t cnt = prefix_query(L[k].seen, L[k].spre, lo[k]);
+      dis_acc[k] += valid ? cnt : 0u;
+    }
 
     // (2) pairs inside this step
     if (F == ~0ull) {
-      // every lane starts its own A-group: no A ties in this step
-      // lane 0 takes ~0 on the first shift and then keeps it (old = the register itself), so a lane
-      // that has run out of earlier rows compares against "never below"
-      uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
-      uint32_t c2 = (qs < lo) ? 1u : 0u;
+      // every lane starts its own A-group: no A ties in this step (all 64 lanes valid)
+      if (NP == 1) {
+        uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q[0]);
+        uint32_t c2 = (qs < lo[0]) ? 1u : 0u;
 #pragma unroll
-      for (int s = 2; s < 64; ++s) {
-        qs = dpp_wave_shr1(qs, qs);
-        c2 += (qs < lo) ? 1u : 0u;
+        for (int s = 2; s < 64; ++s) {
+          qs = dpp_wave_shr1(qs, qs);
+          c2 += (qs < lo[0]) ? 1u : 0u;
+        }
+        dis_acc[0] += c2;
+      } else {
+#pragma unroll
+        for (int k = 0; k + 1 < NP; k += 2) {
+          const uint32_t qp = (q[k] & 0xFFFFu) | (q[k + 1] << 16);
+          const uint32_t lp = lo[k] | (lo[k + 1] << 16);
+          // lane 0 is set to 0xFFFF|0xFFFF by this first (out-of-place) shift and then keeps it:
+          // a lane that has run out of earlier rows compares against "never below"
+          const uint32_t qs1 = dpp_wave_shr1(0xFFFFFFFFu, qp);
+          const uint32_t cu = pk_allpairs(qs1, lp, pk_ones);
+          dis_acc[k] += cu & 0xFFFFu;
+          dis_acc[k + 1] += cu >> 16;
+        }
       }
-      dis_acc += c2;
-    } else {
-      // general: xg = A-group ordinal inside the step; ties in A do not count as discordant, and
-      // rows tied in A and in B are joint ties (compare_both, kendallc.cpp:33-51)
+    } else if (F != 0ull) {
+      // mixed step: xg = A-group ordinal inside the step; rows tied in A are not discordant, and rows
+      // tied in A and in B are joint ties
       const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
-      const uint32_t lot = valid ? lo : 0xFFFFFFFFu;
-      uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
       uint32_t xs = dpp_wave_shr1(0xFFFFFFFFu, xg);
-      uint32_t ls = dpp_wave_shr1(0xFFFFFFFEu, lot);
-      uint32_t c2 = 0, c3 = 0;
+      uint32_t qs[NP], ls[NP], lot[NP], c2[NP], c3[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        lot[k] = valid ? lo[k] : 0xFFFFFFFFu;
+        qs[k] = dpp_wave_shr1(0xFFFFFFFFu, q[k]);
+        ls[k] = dpp_wave_shr1(0xFFFFFFFEu, lot[k]);
+        c2[k] = 0; c3[k] = 0;
+      }
       for (int s = 1; s < 64; ++s) {
         const bool same = (xs == xg);
-        c2 += (!same && qs < lo) ? 1u : 0u;
-        c3 += (same && ls == lot) ? 1u : 0u;
-        qs = dpp_wave_shr1(qs, qs);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          c2[k] += (!same && qs[k] < lo[k]) ? 1u : 0u;
+          c3[k] += (same && ls[k] == lot[k]) ? 1u : 0u;
+          qs[k] = dpp_wave_shr1(qs[k], qs[k]);
+          ls[k] = dpp_wave_shr1(ls[k], ls[k]);
+        }
         xs = dpp_wave_shr1(xs, xs);
-        ls = dpp_wave_shr1(ls, ls);
       }
-      dis_acc += valid ? c2 : 0u;
-      tie_acc += valid ? c3 : 0u;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        dis_acc[k] += valid ? c2[k] : 0u;
+        tie_acc[k] += valid ? c3[k] : 0u;
+      }
     }
+    // F == 0: the whole step lies inside one open A-group: nothing is discordant in-step; its joint
+    // ties are counted below from pend (before / after inserting the step)
 
-    // (3) joint ties with earlier steps of an A-group that is still open
+    // (3) rows of an A-group that is still open from earlier steps
     const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
     const bool olane = valid && ((int)lane < first_start);
+    uint32_t ph[NP], ebefore[NP];
     if ((F & 1ull) == 0ull) {
-      uint32_t c4 = 0, c5 = 0;
-      if (olane) {
-        const uint32_t ph = (uint32_t)hiG[row] + 1u;
-        c4 = prefix_query(L.pend, L.ppre, ph) - prefix_query(L.pend, L.ppre, lo);
-      } else if (valid) {
-        // rows of later groups of this step also see the open group's earlier rows, still in pend
-        c5 = prefix_query(L.pend, L.ppre, lo);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        ph[k] = 0; ebefore[k] = 0;
+        if (olane) {
+          // joint ties with the group's rows of earlier steps
+          ph[k] = (uint32_t)hiG[k][row] + 1u;
+          ebefore[k] = prefix_query(L[k].pend, L[k].ppre, ph[k]) - prefix_query(L[k].pend, L[k].ppre, lo[k]);
+          tie_acc[k] += ebefore[k];
+        } else if (valid) {
+          // rows of later groups of this step also see the open group's earlier rows, still in pend
+          dis_acc[k] += prefix_query(L[k].pend, L[k].ppre, lo[k]);
+        }
       }
-      tie_acc += c4;
-      dis_acc += c5;
     }
 
     // (4) insert this step's rows
     wave_lds_fence();
-    const unsigned long long bit = 1ull << (q & 63u);
-    const uint32_t qw = (q & 0xFFFFu) >> 6;
     if (F == 0ull) {
-      if (valid) atomicOr(&L.pend[qw], bit);
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (valid) atomicOr(&L[k].pend[q[k] >> 6], 1ull << (q[k] & 63u));
       wave_lds_fence();
-      if (Fn) rebuild_prefix(L.seen, L.spre, L.pend, Wp, items, lane);
-      else rebuild_prefix(L.pend, L.ppre, nullptr, Wp, items, lane);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].pend, L[k].ppre, nullptr, Wp, items, lane);
+      wave_lds_fence();
+      // in-step joint ties: sum over rows of (#rows of this step in the same B group, itself included)
+      // = after - before; twice the tie count is that sum minus the rows
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (valid) {
+          const uint32_t after = prefix_query(L[k].pend, L[k].ppre, ph[k]) - prefix_query(L[k].pend, L[k].ppre, lo[k]);
+          tie2_acc[k] += after - ebefore[k] - 1u;
+        }
+      }
+      if (Fn) {
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].seen, L[k].spre, L[k].pend, Wp, items, lane);
+      }
     } else {
       const int last_start = 63 - (int)__builtin_clzll(F);
       const bool tlane = valid && ((int)lane >= last_start);
-      if (olane) atomicOr(&L.pend[qw], bit);
-      else if (valid && (Fn || !tlane)) atomicOr(&L.seen[qw], bit);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const unsigned long long bit = 1ull << (q[k] & 63u);
+        const uint32_t qw = (q[k] & 0xFFFFu) >> 6;
+        if (olane) atomicOr(&L[k].pend[qw], bit);
+        else if (valid && (Fn || !tlane)) atomicOr(&L[k].seen[qw], bit);
+      }
       wave_lds_fence();
-      rebuild_prefix(L.seen, L.spre, ((F & 1ull) == 0ull) ? L.pend : nullptr, Wp, items, lane);
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        rebuild_prefix(L[k].seen, L[k].spre, ((F & 1ull) == 0ull) ? L[k].pend : nullptr, Wp, items, lane);
       if (!Fn) {
         wave_lds_fence();
-        if (tlane) atomicOr(&L.pend[qw], bit);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if (tlane) atomicOr(&L[k].pend[(q[k] & 0xFFFFu) >> 6], 1ull << (q[k] & 63u));
         wave_lds_fence();
-        rebuild_prefix(L.pend, L.ppre, nullptr, Wp, items, lane);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].pend, L[k].ppre, nullptr, Wp, items, lane);
       }
     }
     wave_lds_fence();
   }
 
-  const unsigned long long dis = wave_sum_u64(dis_acc);
-  const unsigned long long ntie = wave_sum_u64(tie_acc);
-  const unsigned long long cbs = wave_sum_u64(cb);
-  const unsigned long long ggs = wave_sum_u64(gg);
-  if (lane == 0) {
-    PairRaw o;
-    o.dis = dis;
-    o.ntie = ntie;
-    o.c_both = (uint32_t)cbs;
-    o.g = (uint32_t)ggs;
-    raw[p] = o;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const unsigned long long dis = wave_sum_u64(dis_acc[k]);
+    const unsigned long long ntie = wave_sum_u64(tie_acc[k]) + (wave_sum_u64(tie2_acc[k]) >> 1);
+    const unsigned long long cbs = wave_sum_u64(cb[k]);
+    const unsigned long long ggs = wave_sum_u64(gg[k]);
+    if (lane == 0 && k < np) {
+      PairRaw o;
+      o.dis = dis;
+      o.ntie = ntie;
+      o.c_both = (uint32_t)cbs;
+      o.g = (uint32_t)ggs;
+      raw[p0 + k] = o;
+    }
   }
 }
 
-template __global__ void k1_pairs<true>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
-template __global__ void k1_pairs<false>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
+template __global__ void k1_pairs<1>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
+template __global__ void k1_pairs<2>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
+template __global__ void k1_pairs<4>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
 
 // ------------------------------------------------------------------------------------------------
 // K2: epilogue, one pair per lane
@@ -753,24 +892,22 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
   return hipGetLastError();
 }
 
-hipError_t launch_k1(const PrepView& pv, const int32_t* unit_start, int n_units, const int32_t* pi,
-                     const int32_t* pj, PairRaw* raw, int wpb, bool stage, size_t lds_bytes,
-                     int perwave_bytes, hipStream_t s) {
-  if (n_units <= 0) return hipSuccess;
-  hipError_t e;
-  if (stage) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_pairs<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k1_pairs<true>, dim3(n_units), dim3(wpb * 64), lds_bytes, s, pv, unit_start, n_units,
-                       pi, pj, raw, perwave_bytes);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_pairs<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k1_pairs<false>, dim3(n_units), dim3(wpb * 64), lds_bytes, s, pv, unit_start, n_units,
-                       pi, pj, raw, perwave_bytes);
-  }
+hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
+                     const int32_t* pj, PairRaw* raw, int np, int wpb, size_t lds_bytes, int perpair_bytes,
+                     hipStream_t s) {
+  if (n_tasks <= 0) return hipSuccess;
+  const int blocks = (n_tasks + wpb - 1) / wpb;
+  const void* fn = (np == 1) ? reinterpret_cast<const void*>(&k1_pairs<1>)
+                 : (np == 2) ? reinterpret_cast<const void*>(&k1_pairs<2>)
+                             : reinterpret_cast<const void*>(&k1_pairs<4>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  if (np == 1)
+    hipLaunchKernelGGL(k1_pairs<1>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
+  else if (np == 2)
+    hipLaunchKernelGGL(k1_pairs<2>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
+  else
+    hipLaunchKernelGGL(k1_pairs<4>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
   return hipGetLastError();
 }
 

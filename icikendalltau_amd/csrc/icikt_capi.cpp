@@ -134,7 +134,7 @@ int timer_end(icikt_ctx* c, int k, uint32_t flags) {
 
 // launch plan of the pair kernel for a given n
 struct K1Plan {
-  int np;    // pairs per wave (1, 2 or 4), all sharing the streamed column
+  int np;    // pairs per wave (1, 2 or 4): consecutive pairs with the same pi (the gathered column)
   int wpb;   // waves per workgroup
   size_t lds_bytes;
   int perpair_bytes;

@@ -14,6 +14,7 @@
 // No MFMA: the work is integer compare / popcount / prefix-sum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "icikt_device.h"
 
@@ -71,6 +72,7 @@ __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/
 // K0: per-column pre-pass
 // ------------------------------------------------------------------------------------------------
 constexpr int K0_THREADS = 1024;
+constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB)
 
 __device__ __forceinline__ unsigned long long sortable_key(double v) {
   if (v == 0.0) v = 0.0;  // -0.0 and +0.0 tie (x[i] < x[j] is false both ways, kendallc.cpp:9,23)
@@ -99,6 +101,8 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   __shared__ long long sh_ll[K0_THREADS];
   __shared__ int sh_i[K0_THREADS];
   __shared__ unsigned long long sh_bits[1024];  // fill-group bitset, W <= 1024 words
+  __shared__ unsigned long long sh_tk[K0_TILE];  // sort tile: keys
+  __shared__ uint32_t sh_ti[K0_TILE];            // sort tile: row indices
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -160,22 +164,67 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   __syncthreads();
 
   // ---- phase 2: bitonic sort of (key, row): the row index breaks ties, which makes the result the
-  //      stable order std::stable_sort gives in sortedIndex (kendallc.cpp:5-12) -------------------
-  for (int k = 2; k <= npow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const bool up = ((i & k) == 0);
-        const unsigned long long ka = keys[i], kb = keys[l];
-        const uint32_t ia = idx[i], ib = idx[l];
-        const bool gt = (ka > kb) || (ka == kb && ia > ib);
-        if (gt == up) {
-          keys[i] = kb; keys[l] = ka;
-          idx[i] = ib; idx[l] = ia;
+  //      stable order std::stable_sort gives in sortedIndex (kendallc.cpp:5-12).  Compare-exchange
+  //      distances below the tile size run on an LDS-resident tile; only the long distances of the
+  //      last merges touch global memory. -------------------------------------------------------------
+  {
+    const int T = (npow2 < K0_TILE) ? npow2 : K0_TILE;
+    const int ntiles = npow2 / T;
+    // stages k = 2..T entirely inside each tile
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int tb = tile * T;
+      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[tb + i]; sh_ti[i] = idx[tb + i]; }
+      __syncthreads();
+      for (int k = 2; k <= T; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (T >> 1); t += K0_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const bool up = (((tb + i) & k) == 0);
+            const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
+            const uint32_t ia = sh_ti[i], ib = sh_ti[l];
+            const bool gt = (ka > kb) || (ka == kb && ia > ib);
+            if (gt == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+          }
+          __syncthreads();
         }
       }
+      for (int i = tid; i < T; i += K0_THREADS) { keys[tb + i] = sh_tk[i]; idx[tb + i] = sh_ti[i]; }
       __syncthreads();
+    }
+    // merges across tiles: distances >= T in global memory, the rest per tile in LDS
+    for (int k = 2 * T; k <= npow2; k <<= 1) {
+      for (int j = k >> 1; j >= T; j >>= 1) {
+        for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const bool up = ((i & k) == 0);
+          const unsigned long long ka = keys[i], kb = keys[l];
+          const uint32_t ia = idx[i], ib = idx[l];
+          const bool gt = (ka > kb) || (ka == kb && ia > ib);
+          if (gt == up) { keys[i] = kb; keys[l] = ka; idx[i] = ib; idx[l] = ia; }
+        }
+        __syncthreads();
+      }
+      for (int tile = 0; tile < ntiles; ++tile) {
+        const int tb = tile * T;
+        for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[tb + i]; sh_ti[i] = idx[tb + i]; }
+        __syncthreads();
+        const bool up = ((tb & k) == 0);  // constant inside a tile because k > T
+        for (int j = T >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (T >> 1); t += K0_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
+            const uint32_t ia = sh_ti[i], ib = sh_ti[l];
+            const bool gt = (ka > kb) || (ka == kb && ia > ib);
+            if (gt == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+          }
+          __syncthreads();
+        }
+        for (int i = tid; i < T; i += K0_THREADS) { keys[tb + i] = sh_tk[i]; idx[tb + i] = sh_ti[i]; }
+        __syncthreads();
+      }
     }
   }
 
@@ -301,12 +350,12 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: NP column pairs per wavefront (all NP pairs share the streamed column)
+// K1: NP column pairs per wavefront (they share the gathered column; each streams its own)
 // ------------------------------------------------------------------------------------------------
-// Column A (= pi of the task) is the streamed side: order[k] = row at position k of A's DESCENDING
-// order, gflag bit k = "position k starts a new tie group of A".
-// Columns B_0..B_{NP-1} (= pj of the task's pairs) are the random-access side: rec[row] = q | lo << 16,
-// q = the row's position in B's ascending stable order (unique), lo = first position of its tie group.
+// Column B (= the pairs' common pi) is the random-access side: rec[row] = q | lo << 16, q = the row's
+// position in B's ascending stable order (unique), lo = first position of its tie group.
+// Columns A_0..A_{NP-1} (= pj of the task's pairs) are the streamed side: order[k] = row at position k
+// of A's DESCENDING order, gflag bit k = "position k starts a new tie group of A".
 //
 // The wave walks A from the largest value down, 64 positions per step (one row per lane), and keeps
 // per pair in LDS
@@ -355,6 +404,65 @@ __device__ __forceinline__ uint32_t pk_allpairs(uint32_t qs_first, uint32_t lop,
                : "+v"(qs), "+v"(acc), "=&v"(d)
                : "v"(lop), "v"(ones));
   return acc;
+}
+
+// The same loop for ONE pair, left to hipcc (cmp / cndmask / addc with two interleaved accumulator
+// updates): inside the kernel it measured 16 % faster than a hand-written 3-instruction chain.
+__device__ __forceinline__ uint32_t s1_allpairs(uint32_t qs_first, uint32_t lo) {
+  uint32_t qs = qs_first;
+  uint32_t c2 = (qs < lo) ? 1u : 0u;
+#pragma unroll
+  for (int s = 2; s < 64; ++s) {
+    qs = dpp_wave_shr1(qs, qs);
+    c2 += (qs < lo) ? 1u : 0u;
+  }
+  return c2;
+}
+
+// Hot-step prefix rebuild for NP bitsets at once (items <= 4 words per lane): all LDS reads are issued
+// before the first wait, and two pairs share one DPP scan as packed u16 running counts (each <= n <= 65535,
+// so the halves never carry into each other).
+template <int NP>
+__device__ __forceinline__ void rebuild_prefix_hot(const WaveLds* L, int Wp, int items, uint32_t lane) {
+  const int base = (int)lane * items;
+  unsigned long long v[NP][4];
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int w = base + i;
+      v[k][i] = (i < items && w < Wp) ? L[k].seen[w] : 0ull;
+    }
+  uint32_t pc[NP][4], local[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    local[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pc[k][i] = (uint32_t)__popcll(v[k][i]);
+      local[k] += pc[k][i];
+    }
+  }
+  uint32_t run[NP];
+  if (NP == 1) {
+    run[0] = wave_incl_scan(local[0]) - local[0];
+  } else {
+#pragma unroll
+    for (int k = 0; k + 1 < NP; k += 2) {
+      const uint32_t lp = local[k] | (local[k + 1] << 16);
+      const uint32_t ex = wave_incl_scan(lp) - lp;
+      run[k] = ex & 0xFFFFu;
+      run[k + 1] = ex >> 16;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int w = base + i;
+      if (i < items && w < Wp) L[k].spre[w] = (uint16_t)run[k];
+      run[k] += pc[k][i];
+    }
 }
 
 // prefix popcounts of bits[0..Wp); optionally first merges merge_from into bits and clears merge_from.
@@ -418,6 +526,115 @@ __device__ __forceinline__ uint32_t prefix_query(const unsigned long long* bits,
   return (uint32_t)pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
 }
 
+// state of one pair inside a wave
+struct PairState {
+  WaveLds L;
+  const uint16_t* ord;              // streamed column: rows in descending order
+  const unsigned long long* gf;     // streamed column: group-start flags
+  unsigned long long Fnext;
+  uint32_t row_next;
+  uint32_t dis, tie, tie2;
+};
+
+// General 64-row step of one pair, after the `seen` query: tie groups of the streamed column, open
+// groups, the last partial step.  Rare on continuous data, so it is a real (noinline) call that takes
+// its state by value and returns the three counter increments: the hot step's registers stay small.
+struct StepCounts { uint32_t dis, tie, tie2; };
+struct StepAcc { WaveLds L; uint32_t dis, tie, tie2; };
+
+__device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const unsigned long long F,
+                                                               const bool Fn, const bool valid, const uint32_t row,
+                                                               const uint32_t q, const uint32_t lo,
+                                                               const uint16_t* hiG, const int Wp, const int items,
+                                                               const uint32_t lane) {
+  StepAcc S;
+  S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
+  const bool allpairs_done = false;
+  // (2) pairs inside this step
+  if (F == ~0ull) {
+    if (!allpairs_done) {
+      // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
+      const uint32_t c2 = s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q), lo);
+      S.dis += c2;
+    }
+  } else if (F != 0ull) {
+    // mixed step: xg = group ordinal inside the step; rows tied in the streamed column are not
+    // discordant, and rows tied in both columns are joint ties (compare_both, kendallc.cpp:33-51)
+    const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
+    const uint32_t lot = valid ? lo : 0xFFFFFFFFu;
+    uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
+    uint32_t xs = dpp_wave_shr1(0xFFFFFFFFu, xg);
+    uint32_t ls = dpp_wave_shr1(0xFFFFFFFEu, lot);
+    uint32_t c2 = 0, c3 = 0;
+    for (int s = 1; s < 64; ++s) {
+      const bool same = (xs == xg);
+      c2 += (!same && qs < lo) ? 1u : 0u;
+      c3 += (same && ls == lot) ? 1u : 0u;
+      qs = dpp_wave_shr1(qs, qs);
+      xs = dpp_wave_shr1(xs, xs);
+      ls = dpp_wave_shr1(ls, ls);
+    }
+    S.dis += valid ? c2 : 0u;
+    S.tie += valid ? c3 : 0u;
+  }
+  // F == 0: the whole step lies inside one open group: nothing is discordant in-step; its joint ties
+  // are counted below from pend (before / after inserting the step)
+
+  // (3) rows of a group that is still open from earlier steps
+  const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
+  const bool olane = valid && ((int)lane < first_start);
+  uint32_t ph = 0, ebefore = 0;
+  if ((F & 1ull) == 0ull) {
+    if (olane) {
+      // joint ties with the group's rows of earlier steps
+      ph = (uint32_t)hiG[row] + 1u;
+      ebefore = prefix_query(S.L.pend, S.L.ppre, ph) - prefix_query(S.L.pend, S.L.ppre, lo);
+      S.tie += ebefore;
+    } else if (valid) {
+      // rows of later groups of this step also see the open group's earlier rows, still in pend
+      S.dis += prefix_query(S.L.pend, S.L.ppre, lo);
+    }
+  }
+
+  // (4) insert this step's rows
+  wave_lds_fence();
+  const unsigned long long bit = 1ull << (q & 63u);
+  const uint32_t qw = (q & 0xFFFFu) >> 6;
+  if (F == 0ull) {
+    if (valid) atomicOr(&S.L.pend[qw], bit);
+    wave_lds_fence();
+    rebuild_prefix(S.L.pend, S.L.ppre, nullptr, Wp, items, lane);
+    wave_lds_fence();
+    // in-step joint ties: sum over rows of (#rows of this step in the same tie group of the gathered
+    // column, itself included) = after - before; twice the tie count is that sum minus the rows
+    if (valid) {
+      const uint32_t after = prefix_query(S.L.pend, S.L.ppre, ph) - prefix_query(S.L.pend, S.L.ppre, lo);
+      S.tie2 += after - ebefore - 1u;
+    }
+    if (Fn) {
+      wave_lds_fence();
+      rebuild_prefix(S.L.seen, S.L.spre, S.L.pend, Wp, items, lane);
+    }
+  } else {
+    const int last_start = 63 - (int)__builtin_clzll(F);
+    const bool tlane = valid && ((int)lane >= last_start);
+    if (olane) atomicOr(&S.L.pend[qw], bit);
+    else if (valid && (Fn || !tlane)) atomicOr(&S.L.seen[qw], bit);
+    wave_lds_fence();
+    rebuild_prefix(S.L.seen, S.L.spre, ((F & 1ull) == 0ull) ? S.L.pend : nullptr, Wp, items, lane);
+    if (!Fn) {
+      wave_lds_fence();
+      if (tlane) atomicOr(&S.L.pend[qw], bit);
+      wave_lds_fence();
+      rebuild_prefix(S.L.pend, S.L.ppre, nullptr, Wp, items, lane);
+    }
+  }
+  wave_lds_fence();
+  StepCounts out;
+  out.dis = S.dis; out.tie = S.tie; out.tie2 = S.tie2;
+  return out;
+}
+
 template <int NP>
 __global__ void __launch_bounds__(512)
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
@@ -425,7 +642,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          int perpair_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // XCD-aware mapping: consecutive tasks share their streamed column, so keep them on one XCD
+  // XCD-aware mapping: consecutive tasks share their gathered column, so keep them on one XCD
   // (workgroups are dealt round-robin over the 8 XCDs).  Bijective for any grid size.
   int blk;
   {
@@ -433,230 +650,156 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     const int qd = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     blk = ((xcd < r) ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (orig >> 3);
   }
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // SGPR: keeps every per-wave pointer scalar
   const int wpb = blockDim.x >> 6;
-  const int task = __builtin_amdgcn_readfirstlane(blk * wpb + wave);
+  const int task = blk * wpb + wave;
   if (task >= n_tasks) return;  // the kernel has no workgroup barrier
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const uint32_t lane = lane_id();
   const int p0 = __builtin_amdgcn_readfirstlane(task_start[task]);
   const int np = __builtin_amdgcn_readfirstlane(task_start[task + 1]) - p0;  // 1..NP pairs, same pi
-  const int acol = __builtin_amdgcn_readfirstlane(pi[p0]);
+  // the gathered (random-access) column is the pairs' common pi: the waves of a workgroup, and the
+  // workgroups of an XCD, mostly share it, which keeps its rec table in L1 / L2
+  const int bcol = __builtin_amdgcn_readfirstlane(pi[p0]);
+  const uint32_t* recG = pv.rec + (int64_t)bcol * pv.n_pad;
+  const uint16_t* hiG = pv.hirow + (int64_t)bcol * pv.n_pad;
+  const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
+  const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
 
   const int Wp4 = (Wp + 3) & ~3;
-  WaveLds L[NP];
-  const uint32_t* recG[NP];
-  const uint16_t* hiG[NP];
-  int bcol[NP];
+  PairState S[NP];
+  uint32_t cb[NP], gg[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     // an unused slot repeats the task's last pair; its result is not written
-    bcol[k] = __builtin_amdgcn_readfirstlane(pj[p0 + (k < np ? k : np - 1)]);
-    recG[k] = pv.rec + (int64_t)bcol[k] * pv.n_pad;
-    hiG[k] = pv.hirow + (int64_t)bcol[k] * pv.n_pad;
+    const int acol = __builtin_amdgcn_readfirstlane(pj[p0 + (k < np ? k : np - 1)]);
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
-    L[k].seen = reinterpret_cast<unsigned long long*>(wbase);
-    L[k].pend = L[k].seen + Wp4;
-    L[k].spre = reinterpret_cast<uint16_t*>(L[k].pend + Wp4);
-    L[k].ppre = L[k].spre + Wp4;
+    S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
+    S[k].L.pend = S[k].L.seen + Wp4;
+    S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.pend + Wp4);
+    S[k].L.ppre = S[k].L.spre + Wp4;
     for (int w = lane; w < Wp4; w += 64) {
-      L[k].seen[w] = 0ull; L[k].pend[w] = 0ull; L[k].spre[w] = 0; L[k].ppre[w] = 0;
+      S[k].L.seen[w] = 0ull; S[k].L.pend[w] = 0ull; S[k].L.spre[w] = 0; S[k].L.ppre[w] = 0;
     }
-  }
-
-  // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
-  uint32_t cb[NP], gg[NP];
-  {
+    S[k].ord = pv.order + (int64_t)acol * pv.n_pad;
+    S[k].gf = pv.gflag + (int64_t)acol * Wp;
+    S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
+    // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
     const unsigned long long* ma = pv.mask + (int64_t)acol * Wp;
     const unsigned long long* fa = pv.fillmask + (int64_t)acol * Wp;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const unsigned long long* mb = pv.mask + (int64_t)bcol[k] * Wp;
-      const unsigned long long* fb = pv.fillmask + (int64_t)bcol[k] * Wp;
-      cb[k] = 0; gg[k] = 0;
-      for (int w = lane; w < W; w += 64) {
-        cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
-        gg[k] += (uint32_t)__popcll(fa[w] & fb[w]);
-      }
+    cb[k] = 0; gg[k] = 0;
+    for (int w = lane; w < W; w += 64) {
+      cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
+      gg[k] += (uint32_t)__popcll(fa[w] & fb[w]);
     }
   }
   wave_lds_fence();
 
-  const uint16_t* ord = pv.order + (int64_t)acol * pv.n_pad;
-  const unsigned long long* gf = pv.gflag + (int64_t)acol * Wp;
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
-
-  uint32_t dis_acc[NP], tie_acc[NP], tie2_acc[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) { dis_acc[k] = 0; tie_acc[k] = 0; tie2_acc[k] = 0; }
-
   uint32_t pk_ones = 0x00010001u;
   asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
-  unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
-  uint32_t row_next = ((int)lane < n) ? (uint32_t)ord[lane] : 0u;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    S[k].Fnext = (nb > 0) ? S[k].gf[0] : 0ull;
+    S[k].row_next = ((int)lane < n) ? (uint32_t)S[k].ord[lane] : 0u;
+  }
 
   for (int t = 0; t < nb; ++t) {
-    const unsigned long long F = uniform_u64(Fnext);
-    Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
-    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
-
     const int kpos = t * 64 + (int)lane;
     const bool valid = kpos < n;
-    const uint32_t row = row_next;
-    {  // prefetch the next step's rows
-      const int kn = kpos + 64;
-      row_next = (kn < n) ? (uint32_t)ord[kn] : 0u;
-    }
-    uint32_t q[NP], lo[NP];
+    unsigned long long F[NP];
+    bool Fn[NP];
+    uint32_t row[NP], q[NP], lo[NP];
+    bool all_fast = true;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t r = recG[k][row];
-      q[k] = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
-      lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
+      F[k] = uniform_u64(S[k].Fnext);
+      S[k].Fnext = (t + 1 < nb) ? S[k].gf[t + 1] : 1ull;
+      Fn[k] = (uniform_u64(S[k].Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
+      all_fast = all_fast && (F[k] == ~0ull) && Fn[k];
+      row[k] = S[k].row_next;
     }
 
-    // (1) rows of strictly higher A-groups that are already in `seen`
+    if (all_fast) {
+      // ---- hot step: in every pair of the wave all 64 rows are valid, each row is its own tie group
+      //      of the streamed column, and no group stays open: gather, count, insert into `seen`.
+      //      Loads of all pairs are issued before the first use. ------------------------------------
+      uint32_t r[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const uint32_t cnt = prefix_query(L[k].seen, L[k].spre, lo[k]);
-      dis_acc[k] += valid ? cnt : 0u;
-    }
-
-    // (2) pairs inside this step
-    if (F == ~0ull) {
-      // every lane starts its own A-group: no A ties in this step (all 64 lanes valid)
+      for (int k = 0; k < NP; ++k) r[k] = recG[row[k]];
+      {
+        const int kn = kpos + 64;  // prefetch the next step's rows behind the gathers
+#pragma unroll
+        for (int k = 0; k < NP; ++k) S[k].row_next = (kn < n) ? (uint32_t)S[k].ord[kn] : 0u;
+      }
+      uint32_t pre[NP];
+      unsigned long long wv[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        q[k] = r[k] & 0xFFFFu;
+        lo[k] = r[k] >> 16;
+        pre[k] = S[k].L.spre[lo[k] >> 6];
+        wv[k] = S[k].L.seen[lo[k] >> 6];
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        S[k].dis += pre[k] + (uint32_t)__popcll(wv[k] & low_mask64(lo[k] & 63u));
       if (NP == 1) {
-        uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q[0]);
-        uint32_t c2 = (qs < lo[0]) ? 1u : 0u;
-#pragma unroll
-        for (int s = 2; s < 64; ++s) {
-          qs = dpp_wave_shr1(qs, qs);
-          c2 += (qs < lo[0]) ? 1u : 0u;
-        }
-        dis_acc[0] += c2;
+        S[0].dis += s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q[0]), lo[0]);
       } else {
 #pragma unroll
         for (int k = 0; k + 1 < NP; k += 2) {
-          const uint32_t qp = (q[k] & 0xFFFFu) | (q[k + 1] << 16);
+          const uint32_t qp = q[k] | (q[k + 1] << 16);
           const uint32_t lp = lo[k] | (lo[k + 1] << 16);
-          // lane 0 is set to 0xFFFF|0xFFFF by this first (out-of-place) shift and then keeps it:
-          // a lane that has run out of earlier rows compares against "never below"
-          const uint32_t qs1 = dpp_wave_shr1(0xFFFFFFFFu, qp);
-          const uint32_t cu = pk_allpairs(qs1, lp, pk_ones);
-          dis_acc[k] += cu & 0xFFFFu;
-          dis_acc[k + 1] += cu >> 16;
+          // lane 0 is set to the "never below" value by this first (out-of-place) shift and then
+          // keeps it: a lane that has run out of earlier rows counts nothing
+          const uint32_t cu = pk_allpairs(dpp_wave_shr1(0xFFFFFFFFu, qp), lp, pk_ones);
+          S[k].dis += cu & 0xFFFFu;
+          S[k + 1].dis += cu >> 16;
         }
       }
-    } else if (F != 0ull) {
-      // mixed step: xg = A-group ordinal inside the step; rows tied in A are not discordant, and rows
-      // tied in A and in B are joint ties
-      const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
-      uint32_t xs = dpp_wave_shr1(0xFFFFFFFFu, xg);
-      uint32_t qs[NP], ls[NP], lot[NP], c2[NP], c3[NP];
+      wave_lds_fence();
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        lot[k] = valid ? lo[k] : 0xFFFFFFFFu;
-        qs[k] = dpp_wave_shr1(0xFFFFFFFFu, q[k]);
-        ls[k] = dpp_wave_shr1(0xFFFFFFFEu, lot[k]);
-        c2[k] = 0; c3[k] = 0;
-      }
-      for (int s = 1; s < 64; ++s) {
-        const bool same = (xs == xg);
+      for (int k = 0; k < NP; ++k) atomicOr(&S[k].L.seen[q[k] >> 6], 1ull << (q[k] & 63u));
+      wave_lds_fence();
+      if (items <= 4) {
+        WaveLds Ls[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          c2[k] += (!same && qs[k] < lo[k]) ? 1u : 0u;
-          c3[k] += (same && ls[k] == lot[k]) ? 1u : 0u;
-          qs[k] = dpp_wave_shr1(qs[k], qs[k]);
-          ls[k] = dpp_wave_shr1(ls[k], ls[k]);
-        }
-        xs = dpp_wave_shr1(xs, xs);
-      }
+        for (int k = 0; k < NP; ++k) Ls[k] = S[k].L;
+        rebuild_prefix_hot<NP>(Ls, Wp, items, lane);
+      } else {
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        dis_acc[k] += valid ? c2[k] : 0u;
-        tie_acc[k] += valid ? c3[k] : 0u;
+        for (int k = 0; k < NP; ++k) rebuild_prefix(S[k].L.seen, S[k].L.spre, nullptr, Wp, items, lane);
       }
-    }
-    // F == 0: the whole step lies inside one open A-group: nothing is discordant in-step; its joint
-    // ties are counted below from pend (before / after inserting the step)
-
-    // (3) rows of an A-group that is still open from earlier steps
-    const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
-    const bool olane = valid && ((int)lane < first_start);
-    uint32_t ph[NP], ebefore[NP];
-    if ((F & 1ull) == 0ull) {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        ph[k] = 0; ebefore[k] = 0;
-        if (olane) {
-          // joint ties with the group's rows of earlier steps
-          ph[k] = (uint32_t)hiG[k][row] + 1u;
-          ebefore[k] = prefix_query(L[k].pend, L[k].ppre, ph[k]) - prefix_query(L[k].pend, L[k].ppre, lo[k]);
-          tie_acc[k] += ebefore[k];
-        } else if (valid) {
-          // rows of later groups of this step also see the open group's earlier rows, still in pend
-          dis_acc[k] += prefix_query(L[k].pend, L[k].ppre, lo[k]);
-        }
-      }
+      wave_lds_fence();
+      continue;
     }
 
-    // (4) insert this step's rows
-    wave_lds_fence();
-    if (F == 0ull) {
+    // ---- general step (tie groups in a streamed column, open groups, the last partial step) ----------
 #pragma unroll
-      for (int k = 0; k < NP; ++k)
-        if (valid) atomicOr(&L[k].pend[q[k] >> 6], 1ull << (q[k] & 63u));
-      wave_lds_fence();
-#pragma unroll
-      for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].pend, L[k].ppre, nullptr, Wp, items, lane);
-      wave_lds_fence();
-      // in-step joint ties: sum over rows of (#rows of this step in the same B group, itself included)
-      // = after - before; twice the tie count is that sum minus the rows
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        if (valid) {
-          const uint32_t after = prefix_query(L[k].pend, L[k].ppre, ph[k]) - prefix_query(L[k].pend, L[k].ppre, lo[k]);
-          tie2_acc[k] += after - ebefore[k] - 1u;
-        }
-      }
-      if (Fn) {
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].seen, L[k].spre, L[k].pend, Wp, items, lane);
-      }
-    } else {
-      const int last_start = 63 - (int)__builtin_clzll(F);
-      const bool tlane = valid && ((int)lane >= last_start);
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const unsigned long long bit = 1ull << (q[k] & 63u);
-        const uint32_t qw = (q[k] & 0xFFFFu) >> 6;
-        if (olane) atomicOr(&L[k].pend[qw], bit);
-        else if (valid && (Fn || !tlane)) atomicOr(&L[k].seen[qw], bit);
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int k = 0; k < NP; ++k)
-        rebuild_prefix(L[k].seen, L[k].spre, ((F & 1ull) == 0ull) ? L[k].pend : nullptr, Wp, items, lane);
-      if (!Fn) {
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if (tlane) atomicOr(&L[k].pend[(q[k] & 0xFFFFu) >> 6], 1ull << (q[k] & 63u));
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rebuild_prefix(L[k].pend, L[k].ppre, nullptr, Wp, items, lane);
-      }
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t r = recG[row[k]];
+      const int kn = kpos + 64;
+      S[k].row_next = (kn < n) ? (uint32_t)S[k].ord[kn] : 0u;
+      q[k] = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
+      lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
+      // (1) rows of strictly higher groups of the streamed column that are already in `seen`
+      const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
+      S[k].dis += valid ? cnt : 0u;
     }
-    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const StepCounts c = pair_step_rest(S[k].L, F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, Wp, items, lane);
+      S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
+    }
   }
 
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const unsigned long long dis = wave_sum_u64(dis_acc[k]);
-    const unsigned long long ntie = wave_sum_u64(tie_acc[k]) + (wave_sum_u64(tie2_acc[k]) >> 1);
+    const unsigned long long dis = wave_sum_u64(S[k].dis);
+    const unsigned long long ntie = wave_sum_u64(S[k].tie) + (wave_sum_u64(S[k].tie2) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);
     const unsigned long long ggs = wave_sum_u64(gg[k]);
     if (lane == 0 && k < np) {

@@ -1,0 +1,82 @@
+// Issue-rate microbenchmark for the instruction classes the pair kernel uses (gfx950).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define REP2(x) x x
+#define REP4(x) REP2(x) REP2(x)
+#define REP8(x) REP4(x) REP4(x)
+#define REP16(x) REP8(x) REP8(x)
+#define REP32(x) REP16(x) REP16(x)
+#define REP64(x) REP32(x) REP32(x)
+
+// each variant: 64 copies of a small instruction group on 4 independent register sets
+#define G_FMA   "v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5\n\t"
+#define G_ADD   "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t"
+#define G_DPP   "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define G_DPPR  "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define G_MOV   "v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %0\n\t"
+#define G_CMP   "v_cmp_lt_u32_e32 vcc, %0, %4\n\tv_cmp_lt_u32_e32 vcc, %1, %4\n\tv_cmp_lt_u32_e32 vcc, %2, %4\n\tv_cmp_lt_u32_e32 vcc, %3, %4\n\t"
+#define G_ADDC  "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\tv_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+#define G_PKSUB "v_pk_sub_u16 %0, %0, %4 clamp\n\tv_pk_sub_u16 %1, %1, %4 clamp\n\tv_pk_sub_u16 %2, %2, %4 clamp\n\tv_pk_sub_u16 %3, %3, %4 clamp\n\t"
+#define G_PKADD "v_pk_add_u16 %0, %0, %4\n\tv_pk_add_u16 %1, %1, %4\n\tv_pk_add_u16 %2, %2, %4\n\tv_pk_add_u16 %3, %3, %4\n\t"
+#define G_CNDM  "v_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc\n\t"
+#define G_BCNT  "v_bcnt_u32_b32 %0, %0, %4\n\tv_bcnt_u32_b32 %1, %1, %4\n\tv_bcnt_u32_b32 %2, %2, %4\n\tv_bcnt_u32_b32 %3, %3, %4\n\t"
+#define G_SUBF  "v_sub_f32_e64 %0, %4, %0 clamp\n\tv_sub_f32_e64 %1, %4, %1 clamp\n\tv_sub_f32_e64 %2, %4, %2 clamp\n\tv_sub_f32_e64 %3, %4, %3 clamp\n\t"
+#define G_ADDF  "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4\n\t"
+#define G_ADDFDPP "v_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %2, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define G_MIX1  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_cmp_lt_u32_e32 vcc, %0, %4\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_add_u32 %3, %3, %2\n\t"
+#define G_MIXF  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_sub_f32_e64 %1, %4, %0 clamp\n\tv_add_f32 %2, %2, %1\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+
+template <int V>
+__global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
+  uint32_t a = threadIdx.x, b = threadIdx.x * 3, c = threadIdx.x * 5, d = threadIdx.x * 7, e = 0x00010001u, f = 3;
+  for (int it = 0; it < iters; ++it) {
+#define RUN(G) asm volatile(REP64(G) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc")
+    if (V == 0) RUN(G_FMA); else if (V == 1) RUN(G_ADD); else if (V == 2) RUN(G_DPP); else if (V == 3) RUN(G_DPPR);
+    else if (V == 4) RUN(G_MOV); else if (V == 5) RUN(G_CMP); else if (V == 6) RUN(G_ADDC); else if (V == 7) RUN(G_PKSUB);
+    else if (V == 8) RUN(G_PKADD); else if (V == 9) RUN(G_CNDM); else if (V == 10) RUN(G_BCNT); else if (V == 11) RUN(G_SUBF);
+    else if (V == 12) RUN(G_ADDF); else if (V == 13) RUN(G_ADDFDPP); else if (V == 14) RUN(G_MIX1); else if (V == 15) RUN(G_MIXF);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+}
+
+template <int V>
+int run(const char* name, uint32_t* d) {
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  const int iters = 4000, wpc = 32, blocks = 256 * wpc / 4;
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, d, iters);  // warm clocks
+  CHK(hipDeviceSynchronize());
+  CHK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, d, iters);
+  CHK(hipEventRecord(e1));
+  CHK(hipEventSynchronize(e1));
+  float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+  const double instr_per_simd = (double)wpc / 4.0 * iters * 256.0;
+  printf("%-22s %.2f ms  %.3f ns per wave-instruction per SIMD\n", name, ms, ms * 1e6 / instr_per_simd);
+  return 0;
+}
+
+int main() {
+  uint32_t* d;
+  CHK(hipMalloc(&d, 256 * 8 * 256 * 4));
+  if (run<0>("v_fma_f32", d)) return 1;
+  if (run<1>("v_add_u32", d)) return 1;
+  if (run<2>("v_mov_dpp wave_shr", d)) return 1;
+  if (run<3>("v_mov_dpp row_shr", d)) return 1;
+  if (run<4>("v_mov_b32", d)) return 1;
+  if (run<5>("v_cmp_lt_u32", d)) return 1;
+  if (run<6>("v_addc_co_u32", d)) return 1;
+  if (run<7>("v_pk_sub_u16 clamp", d)) return 1;
+  if (run<8>("v_pk_add_u16", d)) return 1;
+  if (run<9>("v_cndmask_b32", d)) return 1;
+  if (run<10>("v_bcnt_u32_b32", d)) return 1;
+  if (run<11>("v_sub_f32 clamp", d)) return 1;
+  if (run<12>("v_add_f32", d)) return 1;
+  if (run<13>("v_add_f32_dpp", d)) return 1;
+  if (run<14>("mix dpp/cmp/cndm/add", d)) return 1;
+  if (run<15>("mix dpp/subf/addf/dpp", d)) return 1;
+  if (run<0>("v_fma_f32 (again)", d)) return 1;
+  return 0;
+}

@@ -293,6 +293,7 @@ int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_
   pv.n = (int)n_feat;
   pv.n_pad = (int)((n_feat + 63) / 64 * 64);
   if (pv.n_pad == 0) pv.n_pad = 64;
+  pv.n_ord = pv.n_pad + 64;
   pv.W = (int)((n_feat + 63) / 64);
   pv.Wp = pv.W + 1;
   int np2 = 2;
@@ -301,7 +302,7 @@ int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_
   pv.n_samp = (int)n_samp;
   const size_t S = (size_t)std::max<int64_t>(n_samp, 1);
 
-  HIPCHK(c, c->order.reserve(S * pv.n_pad));
+  HIPCHK(c, c->order.reserve(S * pv.n_ord));
   HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
   HIPCHK(c, c->rec.reserve(S * pv.n_pad));
   HIPCHK(c, c->mask.reserve(S * pv.Wp));

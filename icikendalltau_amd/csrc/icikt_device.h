@@ -35,12 +35,13 @@ struct PairRaw {
 struct PrepView {
   int n;       // n_feat (rows per column)
   int n_pad;   // n rounded up to a multiple of 64
+  int n_ord;   // n_pad + 64: stride of `order`, zero padded so that K1 can prefetch one step ahead
   int W;       // ceil(n / 64) bitset words
   int Wp;      // W + 1 (one zero guard word)
   int npow2;   // sort scratch length per column
   int n_samp;
   // per column, stride n_pad
-  uint16_t* order;   // [S][n_pad]  row at processing position k (descending value)
+  uint16_t* order;   // [S][n_ord]  row at processing position k (descending value)
   uint32_t* rec;     // [S][n_pad]  per row: q | lo << 16  (ascending stable position, group start)
   uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
   // per column, stride Wp

@@ -64,6 +64,14 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
   return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
 
+// global loads addressed as uniform base + 32-bit per-lane offset (saddr form: no 64-bit VALU address math)
+__device__ __forceinline__ uint32_t gload_u32(const uint32_t* base, uint32_t idx) {
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + (size_t)(idx << 2));
+}
+__device__ __forceinline__ uint32_t gload_u16(const uint16_t* base, uint32_t idx) {
+  return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(base) + (size_t)(idx << 1));
+}
+
 __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
   return (1ull << bits) - 1ull;
 }
@@ -116,7 +124,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   unsigned long long* mask = pv.mask + (int64_t)c * pv.Wp;
   unsigned long long* fmask = pv.fillmask + (int64_t)c * pv.Wp;
   unsigned long long* gflag = pv.gflag + (int64_t)c * pv.Wp;
-  uint16_t* order = pv.order + (int64_t)c * pv.n_pad;
+  uint16_t* order = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + (int64_t)c * pv.n_pad;
   uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
 
@@ -269,6 +277,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   __syncthreads();
 
   for (int w = tid; w < 1024; w += K0_THREADS) sh_bits[w] = 0ull;
+  for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) order[k] = 0;  // zero padding: K1 prefetches one step ahead
   __syncthreads();
 
   // per-thread tie statistics over the groups that START in my chunk
@@ -682,7 +691,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     for (int w = lane; w < Wp4; w += 64) {
       S[k].L.seen[w] = 0ull; S[k].L.pend[w] = 0ull; S[k].L.spre[w] = 0; S[k].L.ppre[w] = 0;
     }
-    S[k].ord = pv.order + (int64_t)acol * pv.n_pad;
+    S[k].ord = pv.order + (int64_t)acol * pv.n_ord;
     S[k].gf = pv.gflag + (int64_t)acol * Wp;
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
@@ -703,7 +712,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     S[k].Fnext = (nb > 0) ? S[k].gf[0] : 0ull;
-    S[k].row_next = ((int)lane < n) ? (uint32_t)S[k].ord[lane] : 0u;
+    S[k].row_next = gload_u16(S[k].ord, lane);
   }
 
   for (int t = 0; t < nb; ++t) {
@@ -728,12 +737,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       //      Loads of all pairs are issued before the first use. ------------------------------------
       uint32_t r[NP];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) r[k] = recG[row[k]];
-      {
-        const int kn = kpos + 64;  // prefetch the next step's rows behind the gathers
+      for (int k = 0; k < NP; ++k) r[k] = gload_u32(recG, row[k]);
+      // prefetch the next step's rows behind the gathers (order[] is zero-padded by one step)
 #pragma unroll
-        for (int k = 0; k < NP; ++k) S[k].row_next = (kn < n) ? (uint32_t)S[k].ord[kn] : 0u;
-      }
+      for (int k = 0; k < NP; ++k) S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
       uint32_t pre[NP];
       unsigned long long wv[NP];
 #pragma unroll
@@ -780,9 +787,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     // ---- general step (tie groups in a streamed column, open groups, the last partial step) ----------
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t r = recG[row[k]];
-      const int kn = kpos + 64;
-      S[k].row_next = (kn < n) ? (uint32_t)S[k].ord[kn] : 0u;
+      const uint32_t r = gload_u32(recG, row[k]);
+      S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
       q[k] = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
       lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
       // (1) rows of strictly higher groups of the streamed column that are already in `seen`

@@ -107,16 +107,23 @@ def main():
                              f"{args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ICIKT_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: every rank uses the visible device
+    # and the gather goes through host memory.  The driver's N > 1 runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("ICIKT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from icikendalltau_amd import _lib
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n, S = args.n_feat, args.n_samp
@@ -128,14 +135,17 @@ def main():
     ctx.set_pairs_combn(S, begin, end)
     P_local = end - begin
     out_local = torch.full((n_each, 4), float("nan"), dtype=torch.float64, device=dev)
-    gathered = [torch.empty_like(out_local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = ([torch.empty((n_each, 4), dtype=torch.float64, device=comm_dev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
     flags = _lib.FLAG_TIMING
 
     def step():
         ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
         ctx.run_dev(_lib.PERSPECTIVE["global"], _lib.ALTERNATIVE["two.sided"], False, flags, out_local.data_ptr())
         if world > 1:
-            dist.gather(out_local, gathered, dst=0)  # RCCL over xGMI
+            # the one exchange step of the path: every rank's P/N x 4 results to rank 0 (RCCL over xGMI)
+            dist.gather(out_local if backend == "nccl" else out_local.cpu(), gathered, dst=0)
 
     def fence():
         if world > 1:
@@ -152,7 +162,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -197,6 +207,10 @@ def main():
             got = out_local[:P_local].cpu().numpy()[sel]
             line["check"] = {"pairs_checked_against_oracle": int(len(sel)),
                              "max_abs_diff": float(np.nanmax(np.abs(got - ref_out)))}
+        if world > 1:
+            # the assembled result: rank blocks concatenated in combn order (no NaN may be left in real pairs)
+            full = torch.cat([g[:min(n_each, P_total - r * n_each)] for r, g in enumerate(gathered)]).cpu().numpy()
+            line["check"] = {"assembled_pairs": int(full.shape[0]), "nan_rows": int(np.isnan(full[:, 0]).sum())}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -242,3 +242,63 @@ def test_api_through_hip_engine(hip_ctx, golden_dir, expected):
     assert round(res.tau, 7) == e["raw"]
     with pytest.warns(RuntimeWarning, match="single unique value"):
         api.ici_kt(np.arange(10.0), np.ones(10))
+
+
+@pytest.mark.parametrize("np_", ["1", "2", "4"])
+def test_pairs_per_wave_variants(hip_ctx, np_, monkeypatch):
+    """K1 launch plans: 1, 2 or 4 pairs per wave; odd run lengths leave partly filled waves."""
+    monkeypatch.setenv("ICIKT_K1_NP", np_)
+    rng = np.random.default_rng(41)
+    X = rng.standard_normal((2500, 11))
+    X[rng.random(X.shape) < 0.12] = np.nan
+    X[:, 2] = np.round(X[:, 2] * 3)          # ties inside the streamed/gathered columns
+    X[:, 7] = np.round(X[:, 7])
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+    pi = np.array([0, 0, 0, 1, 3, 3, 3, 3, 3, 9, 2], dtype=np.int32)
+    pj = np.array([4, 5, 6, 1, 0, 1, 2, 4, 5, 10, 7], dtype=np.int32)
+    _check(hip_ctx, X, pi, pj, perspective="global")
+
+
+def test_long_columns_generic_rebuild(hip_ctx):
+    """n = 30 000: more than 4 bitset words per lane (generic prefix rebuild), multi-tile K0 merges."""
+    rng = np.random.default_rng(43)
+    n = 30000
+    X = rng.standard_normal((n, 5))
+    X[rng.random(X.shape) < 0.05] = np.nan
+    X[:, 1] = np.round(X[:, 1] * 20)         # ~100 distinct values: tie groups of hundreds of rows
+    X[:, 4] = np.where(rng.random(n) < 0.5, np.nan, X[:, 4])
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+
+
+def test_max_length_65535(hip_ctx):
+    rng = np.random.default_rng(47)
+    n = 65535
+    x = rng.standard_normal(n)
+    y = 0.3 * x + rng.standard_normal(n)
+    y[rng.random(n) < 0.03] = np.nan
+    O = _oracle()
+    for p in ("global", "local"):
+        out, cnt, rsn = hip_ctx.pair(x, y, p)
+        ref, rcnt, rr = O.ici_kt(x, y, p)
+        assert rsn == rr == 0
+        assert all(cnt[k] == rcnt[k] for k in cnt)
+        assert np.max(np.abs(out - ref)) <= ATOL
+    from icikendalltau_amd._lib import IciktError
+    with pytest.raises(IciktError, match="65535"):
+        hip_ctx.pair(np.zeros(65536), np.zeros(65536))
+
+
+def test_int32_wrap_regime_matches_oracle(hip_ctx):
+    """Q2: tie groups >= 1024 rows make the reference's int32 tie sums wrap; default mode reproduces the
+    wrap, ICIKT_FLAG_EXACT_INT64 does not (both against the oracle's two modes)."""
+    rng = np.random.default_rng(53)
+    n = 6000
+    X = rng.standard_normal((n, 4))
+    X[:1500, 0] = np.nan
+    X[rng.random(n) < 0.25, 1] = np.nan
+    X[:, 2] = np.round(X[:, 2])              # a few huge non-missing tie groups
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p, flags=0)
+        _check(hip_ctx, X, perspective=p, flags=1)

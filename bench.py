@@ -10,9 +10,10 @@ Workload (the configuration the metric is quoted on): synthetic 
 perspective = "global": 523 776 column pairs, each a pair of length-10 000 vectors.
 
 One "step" = one full pass of the hot path over the matrix, input already resident in HBM:
-  K0 per-column pre-pass (all columns, replicated on every rank) -> K1 pair kernel over this rank's
-  contiguous block of the combn-ordered pair list (the reference's `core` chunks, R/kendalltau.R:250-255)
-  -> K2 epilogue -> (N > 1) RCCL gather of the P/N x 4 results to rank 0.
+  K0 per-column pre-pass (N > 1: each rank sorts S/N columns, then one RCCL all-gather of the prepared state;
+  falls back to every rank sorting all columns) -> K1 pair kernel over this rank's contiguous block of the
+  combn-ordered pair list (the reference's `core` chunks, R/kendalltau.R:250-255) -> K2 epilogue ->
+  (N > 1) RCCL gather of the P/N x 4 results to rank 0.
 value = pairs of the whole job / wall time (max over ranks); total work is fixed, so scaling = strong.
 """
 from __future__ import annotations
@@ -140,11 +141,56 @@ def main():
                 if (world > 1 and rank == 0) else None)
     flags = _lib.FLAG_TIMING
 
+    class _DevBytes:
+        """Zero-copy view of a device allocation of the C library as a torch uint8 tensor."""
+
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    # N > 1: each rank sorts only its S/N columns (K0) and the prepared state is all-gathered (RCCL over xGMI)
+    # instead of every rank repeating the whole pre-pass; falls back to the replicated pre-pass if that fails.
+    prep_mode = "single"
+    cols_per = -(-S // world)
+    alloc_cols = cols_per * world
+    c0, c1 = min(S, rank * cols_per), min(S, (rank + 1) * cols_per)
+    shards = None
+
+    def prepare_sharded():
+        ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, flags)
+        for full, nbytes in shards:
+            mine = full[rank * nbytes:(rank + 1) * nbytes]
+            if backend == "nccl":
+                dist.all_gather_into_tensor(full, mine.clone())
+            else:  # rehearsal: through host memory
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, mine.cpu())
+                full.copy_(torch.cat(parts))
+
+    if world > 1 and os.environ.get("ICIKT_BENCH_PREP", "sharded") == "sharded":
+        try:
+            ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, 0)
+            shards = [(torch.as_tensor(_DevBytes(ptr, bpc * alloc_cols), device=dev), bpc * cols_per)
+                      for ptr, bpc in ctx.prep_arrays()]
+            prepare_sharded()  # one trial pass, so that a collective that cannot run shows up here
+            torch.cuda.synchronize()
+            prep_mode = "sharded+allgather"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] sharded pre-pass unavailable ({e!r}); every rank runs the whole pre-pass", file=sys.stderr)
+            shards = None
+    if world > 1 and shards is None:
+        prep_mode = "replicated"
+
+    def prepare():
+        if shards is None:
+            ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
+        else:
+            prepare_sharded()
+
     def step():
-        ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
+        prepare()
         ctx.run_dev(_lib.PERSPECTIVE["global"], _lib.ALTERNATIVE["two.sided"], False, flags, out_local.data_ptr())
         if world > 1:
-            # the one exchange step of the path: every rank's P/N x 4 results to rank 0 (RCCL over xGMI)
+            # every rank's P/N x 4 results to rank 0 (RCCL over xGMI)
             dist.gather(out_local if backend == "nccl" else out_local.cpu(), gathered, dst=0)
 
     def fence():
@@ -194,7 +240,7 @@ def main():
             "dtype": "int32 rank/popcount counting + f64 epilogue", "data": "synthetic",
             "config": {"workload": f"c4: {n} features x {S} samples, {args.n_na} smallest per column missing, "
                                    f"perspective=global, {P_total} column pairs",
-                       "pairs": P_total, "n_feat": n, "n_samp": S, "sharding": f"combn-order blocks over {world} rank(s)"},
+                       "pairs": P_total, "n_feat": n, "n_samp": S, "sharding": f"combn-order blocks over {world} rank(s)", "pre_pass": prep_mode},
             "full_matrix_wall_ms": ms_per_step,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k1_pairs",
@@ -211,6 +257,14 @@ def main():
             # the assembled result: rank blocks concatenated in combn order (no NaN may be left in real pairs)
             full = torch.cat([g[:min(n_each, P_total - r * n_each)] for r, g in enumerate(gathered)]).cpu().numpy()
             line["check"] = {"assembled_pairs": int(full.shape[0]), "nan_rows": int(np.isnan(full[:, 0]).sum())}
+            if args.cpu_sample > 0:
+                from oracle import oracle as O
+                rng = np.random.default_rng(1)
+                sel = rng.choice(P_total, size=min(2000, P_total), replace=False)
+                iu, ju = np.triu_indices(S, k=1)
+                ref, _c, _r = O.ici_pairs(X, iu[sel], ju[sel], "global", want_counts=False)
+                line["check"].update(pairs_checked_against_oracle=int(len(sel)),
+                                     max_abs_diff=float(np.nanmax(np.abs(full[sel] - ref))))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -28,6 +28,7 @@ FLAG_TIMING = 2
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
 MAX_FEATURES = 65535
+PREP_ARRAYS = 7
 
 REASON_OK, REASON_ALL_MISSING, REASON_SHORT, REASON_SINGLE_UNIQUE, REASON_TIES_EQ_TOTAL = range(5)
 REASON_WARNINGS = {
@@ -38,7 +39,7 @@ REASON_WARNINGS = {
 
 EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
-    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
+    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prep_arrays", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
     "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest",
 )
@@ -105,6 +106,8 @@ def lib():
     L.icikt_ctx_use_own_stream.argtypes = [c_vp]
     L.icikt_sync.argtypes = [c_vp]
     L.icikt_prepare_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_u32]
+    L.icikt_prepare_cols_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_u32]
+    L.icikt_prep_arrays.argtypes = [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)]
     L.icikt_set_pairs.argtypes = [c_vp, c_vp, c_vp, c_i64]
     L.icikt_set_pairs_combn.argtypes = [c_vp, c_i64, c_i64, c_i64]
     L.icikt_num_pairs.argtypes = [c_vp]
@@ -176,6 +179,19 @@ class Context:
     def prepare_dev(self, d_ptr: int, n_feat: int, n_samp: int, ld: int, flags: int = 0):
         self._chk(lib().icikt_prepare_dev(self._h, ctypes.c_void_p(d_ptr), n_feat, n_samp, ld, flags),
                   "icikt_prepare_dev")
+
+    def prepare_cols_dev(self, d_ptr: int, n_feat: int, n_samp: int, ld: int, col_begin: int, col_end: int,
+                         alloc_cols: int, flags: int = 0):
+        """Pre-pass over columns [col_begin, col_end) only (multi-rank: all-gather prep_arrays() afterwards)."""
+        self._chk(lib().icikt_prepare_cols_dev(self._h, ctypes.c_void_p(d_ptr), n_feat, n_samp, ld, col_begin,
+                                               col_end, alloc_cols, flags), "icikt_prepare_cols_dev")
+
+    def prep_arrays(self):
+        """[(device pointer, bytes per column)] of the prepared-state arrays."""
+        ptrs = (ctypes.c_void_p * PREP_ARRAYS)()
+        bpc = (ctypes.c_int64 * PREP_ARRAYS)()
+        self._chk(lib().icikt_prep_arrays(self._h, ptrs, bpc), "icikt_prep_arrays")
+        return [(int(ptrs[i] or 0), int(bpc[i])) for i in range(PREP_ARRAYS)]
 
     def set_pairs(self, pi, pj):
         pi = np.ascontiguousarray(pi, dtype=np.int32)

@@ -63,6 +63,7 @@ struct icikt_ctx {
   DevBuf<uint32_t> sort_idx;
   DevBuf<ColStats> stats;
   int sort_chunk = 0;
+  int64_t alloc_cols = 0;  // columns the prepared-state arrays are allocated for (>= n_samp)
 
   // pair list
   int64_t n_pairs = -1;
@@ -279,12 +280,17 @@ int icikt_sync(icikt_ctx* c) {
   return ICIKT_SUCCESS;
 }
 
-int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags) {
+// Shared body of icikt_prepare_dev / icikt_prepare_cols_dev: allocate the prepared state for alloc_cols
+// columns and run the pre-pass over columns [col_begin, col_end).
+static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                        int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags) {
   if (!c) return ICIKT_E_INVALID;
   if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, "prepare: bad matrix shape");
   if (n_feat > ICIKT_MAX_FEATURES)
     return fail(c, ICIKT_E_TOO_LONG, "prepare: n_feat exceeds ICIKT_MAX_FEATURES (65535)");
   if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
+  if (col_begin < 0 || col_end < col_begin || col_end > n_samp || alloc_cols < n_samp)
+    return fail(c, ICIKT_E_INVALID, "prepare: bad column range");
   int rc = use_device(c);
   if (rc) return rc;
   c->prepared = false;
@@ -300,7 +306,8 @@ int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_
   while (np2 < pv.n) np2 <<= 1;
   pv.npow2 = np2;
   pv.n_samp = (int)n_samp;
-  const size_t S = (size_t)std::max<int64_t>(n_samp, 1);
+  const size_t S = (size_t)std::max<int64_t>(alloc_cols, 1);
+  const size_t ncols = (size_t)std::max<int64_t>(col_end - col_begin, 1);
 
   HIPCHK(c, c->order.reserve(S * pv.n_ord));
   HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
@@ -310,7 +317,7 @@ int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_
   HIPCHK(c, c->gflag.reserve(S * pv.Wp));
   HIPCHK(c, c->stats.reserve(S));
   // sort scratch: bounded to ~1 GiB
-  size_t chunk = std::min<size_t>(S, std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)np2 * 12)));
+  size_t chunk = std::min<size_t>(ncols, std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)np2 * 12)));
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
   c->sort_chunk = (int)chunk;
@@ -319,19 +326,44 @@ int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_
   pv.mask = c->mask.p; pv.fillmask = c->fillmask.p; pv.gflag = c->gflag.p;
   pv.stats = c->stats.p; pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   c->pv = pv;
+  c->alloc_cols = (int64_t)S;
 
   rc = timer_begin(c, ICIKT_K_PREPARE, flags);
   if (rc) return rc;
-  HIPCHK(c, hipMemsetAsync(c->stats.p, 0, S * sizeof(ColStats), c->stream));
+  if (col_end > col_begin)
+    HIPCHK(c, hipMemsetAsync(c->stats.p + col_begin, 0, (size_t)(col_end - col_begin) * sizeof(ColStats), c->stream));
   if (n_feat > 0) {
-    for (int64_t c0 = 0; c0 < n_samp; c0 += (int64_t)chunk) {
-      const int nc = (int)std::min<int64_t>((int64_t)chunk, n_samp - c0);
+    for (int64_t c0 = col_begin; c0 < col_end; c0 += (int64_t)chunk) {
+      const int nc = (int)std::min<int64_t>((int64_t)chunk, col_end - c0);
       HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->stream));
     }
   }
   rc = timer_end(c, ICIKT_K_PREPARE, flags);
   if (rc) return rc;
   c->prepared = true;
+  return ICIKT_SUCCESS;
+}
+
+int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags) {
+  return prepare_impl(c, dX, n_feat, n_samp, ld, 0, n_samp, n_samp, flags);
+}
+
+int icikt_prepare_cols_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags) {
+  return prepare_impl(c, dX, n_feat, n_samp, ld, col_begin, col_end, alloc_cols, flags);
+}
+
+int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
+  if (!c || !ptrs || !bytes_per_col) return ICIKT_E_INVALID;
+  if (!c->prepared) return fail(c, ICIKT_E_STATE, "prep_arrays: nothing prepared");
+  const PrepView& pv = c->pv;
+  ptrs[0] = pv.order;    bytes_per_col[0] = (int64_t)pv.n_ord * 2;
+  ptrs[1] = pv.rec;      bytes_per_col[1] = (int64_t)pv.n_pad * 4;
+  ptrs[2] = pv.hirow;    bytes_per_col[2] = (int64_t)pv.n_pad * 2;
+  ptrs[3] = pv.mask;     bytes_per_col[3] = (int64_t)pv.Wp * 8;
+  ptrs[4] = pv.fillmask; bytes_per_col[4] = (int64_t)pv.Wp * 8;
+  ptrs[5] = pv.gflag;    bytes_per_col[5] = (int64_t)pv.Wp * 8;
+  ptrs[6] = pv.stats;    bytes_per_col[6] = (int64_t)sizeof(ColStats);
   return ICIKT_SUCCESS;
 }
 

@@ -112,6 +112,16 @@ int icikt_sync(icikt_ctx *ctx);
 int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
                       uint32_t flags);
 
+/* Column-sharded pre-pass for multi-rank use: the prepared state is allocated for alloc_cols >= n_samp
+ * columns (so that every rank's slice has the same size) but only columns [col_begin, col_end) are computed.
+ * The caller then all-gathers the column slices of the ICIKT_PREP_ARRAYS arrays returned by
+ * icikt_prep_arrays() across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
+ * [alloc_cols][bytes_per_col[i]] bytes, column-contiguous. */
+#define ICIKT_PREP_ARRAYS 7
+int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);
+int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);
+
 /* Pair list (HOST arrays, copied).  Mirrors setup_comparisons' output order (R/kendalltau.R:181-278). */
 int icikt_set_pairs(icikt_ctx *ctx, const int32_t *pi, const int32_t *pj, int64_t n_pairs);
 /* Pairs [begin, end) of utils::combn(n_samp, 2) order: (0,1),(0,2)...(0,S-1),(1,2)... (R/kendalltau.R:189).

@@ -302,3 +302,30 @@ def test_int32_wrap_regime_matches_oracle(hip_ctx):
     for p in ("global", "local"):
         _check(hip_ctx, X, perspective=p, flags=0)
         _check(hip_ctx, X, perspective=p, flags=1)
+
+
+def test_sharded_prepass_matches_full(hip_ctx):
+    """icikt_prepare_cols_dev over column ranges (what ranks do before the all-gather) fills the same
+    prepared state as one full icikt_prepare_dev."""
+    import torch
+    rng = np.random.default_rng(59)
+    n, S = 900, 10
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random(X.shape) < 0.1] = np.nan
+    X[:, 3] = np.round(X[:, 3] * 2)
+    full, _, _ = hip_ctx.pairs(X, perspective="global", want_counts=False)
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    world = 4
+    cols_per = -(-S // world)
+    alloc = cols_per * world
+    for r in range(world):  # one context plays all ranks in turn: the slices land in the same arrays
+        c0, c1 = min(S, r * cols_per), min(S, (r + 1) * cols_per)
+        hip_ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc)
+    arrays = hip_ctx.prep_arrays()
+    assert len(arrays) == 7 and all(ptr and bpc > 0 for ptr, bpc in arrays)
+    P = S * (S - 1) // 2
+    hip_ctx.set_pairs_combn(S, 0, P)
+    out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
+    hip_ctx.run_dev(1, 0, False, 0, out.data_ptr())
+    hip_ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), full, equal_nan=True)

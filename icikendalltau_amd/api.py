@@ -382,3 +382,94 @@ def pairwise_completeness(data_matrix, global_na=(float("nan"), float("inf"), 0)
     cols = {"s1": names_arr[pi], "s2": names_arr[pj], "core": core.astype(np.float64), "missingness": missingness,
             "completeness": completeness}
     return pd.DataFrame(cols) if pd is not None else cols
+
+
+# --------------------------------------------------------------------------------------------------
+# kt_fast (R/kendalltau.R:448-545) and kt_split (:310-354) -- SURVEY.md section 8(f) row 3
+# --------------------------------------------------------------------------------------------------
+_KT_USE = ("all.obs", "complete.obs", "pairwise.complete.obs", "everything", "na.or.complete")
+
+
+def _match_use(use: str) -> str:
+    """R's match.arg(): exact or unique partial match."""
+    hits = [u for u in _KT_USE if u == use] or [u for u in _KT_USE if u.startswith(use)]
+    if len(hits) != 1:
+        raise ValueError("'arg' should be one of " + ", ".join(f"'{u}'" for u in _KT_USE))
+    return hits[0]
+
+
+def kt_fast(x, y=None, use="everything", alternative="two.sided", continuity=False, return_matrix=True,
+            colnames=None, engine=None, max_pair_chunk=4096):
+    """Kendall tau-b with stats::cor-like NA policies over the ici_kt kernel (R/kendalltau.R:448-545).
+
+    As in the reference, ``alternative`` and ``continuity`` are accepted but NOT forwarded (kt_split calls
+    ici_kt with its defaults, :342), and self comparisons are part of the result.  ``use``:
+    "everything"/"all.obs": any NA anywhere in ``x`` -> every entry NA; "complete.obs": rows with an NA in
+    any column are dropped first; "pairwise.complete.obs": per pair, rows with an NA in either vector are
+    dropped.  The last one runs on the GPU as ici_kt(..., perspective = "local") of the two vectors with both
+    entries of such rows set missing -- identical to dropping the rows, since "local" removes rows missing in
+    both (src/kendallc.cpp:180-185) and nothing missing remains.
+    """
+    na_method = _match_use(use)
+    if na_method == "na.or.complete":
+        raise ValueError("'na.or.complete' is not a supported value for `use`. "
+                         "Please use one of all.obs complete.obs pairwise.complete everthing.")  # R/utils.R:86-90 (sic)
+    if y is None:
+        if not (pd is not None and isinstance(x, pd.DataFrame)) and np.ndim(x) < 2:
+            raise ValueError("`x` and `y` should both be provided as vectors, or `x` should be matrix-like.")
+        X, names = _as_matrix(x, colnames, "x")
+    else:
+        if np.ndim(x) > 1 or np.ndim(y) > 1:
+            raise ValueError("Both `x` and `y` must be vectors.")
+        X = np.column_stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
+        names = list(colnames) if colnames is not None else ["x", "y"]
+    eng = engine or _default_engine()
+    _dist, _rank, world = _dist_info()
+    pi, pj, core = setup_comparisons(names, None, diag_good=False, ncore=world)
+    P = len(pi)
+    tau = np.full(P, np.nan)
+    pvalue = np.full(P, np.nan)
+    na_vals = np.isnan(X)
+    t_diff = 0.0
+    do_computation = True
+    if na_method in ("everything", "all.obs") and na_vals.any():
+        do_computation = False
+    if na_method == "complete.obs":
+        keep = ~na_vals.any(axis=1)
+        if keep.sum() == 0:
+            do_computation = False
+        else:
+            X = X[keep]
+    if do_computation:
+        t1 = time.perf_counter()
+        if na_method == "pairwise.complete.obs" and np.isnan(X).any():
+            na = np.isnan(X)
+            for b in range(0, P, max_pair_chunk):
+                sl = slice(b, min(P, b + max_pair_chunk))
+                m = sl.stop - sl.start
+                either = na[:, pi[sl]] | na[:, pj[sl]]
+                Xp = np.empty((X.shape[0], 2 * m), dtype=np.float64, order="F")
+                Xp[:, 0::2] = np.where(either, np.nan, X[:, pi[sl]])
+                Xp[:, 1::2] = np.where(either, np.nan, X[:, pj[sl]])
+                idx = np.arange(m, dtype=np.int32)
+                out, rsn = eng.pairs(Xp, 2 * idx, 2 * idx + 1, "local", "two.sided", False)
+                for r in rsn[rsn > 1]:
+                    _warn_reason(r)
+                tau[sl], pvalue[sl] = out[:, 0], out[:, 1]
+        else:
+            out, rsn = eng.pairs(np.asfortranarray(X), pi, pj, "local", "two.sided", False)
+            for r in rsn[rsn > 1]:
+                _warn_reason(r)
+            tau, pvalue = out[:, 0].copy(), out[:, 1].copy()
+        t_diff = time.perf_counter() - t1
+    if return_matrix:
+        S = len(names)
+        tm, pm = np.zeros((S, S)), np.zeros((S, S))
+        tm[pi, pj] = tau
+        tm[pj, pi] = tau
+        pm[pi, pj] = pvalue
+        pm[pj, pi] = pvalue
+        return {"tau": _named_matrix(tm, names), "pvalue": _named_matrix(pm, names), "run_time": t_diff}
+    names_arr = np.asarray(names, dtype=object)
+    cols = {"s1": names_arr[pi], "s2": names_arr[pj], "core": core.astype(np.float64), "tau": tau, "pvalue": pvalue}
+    return {"tau": pd.DataFrame(cols) if pd is not None else cols, "run_time": t_diff}

@@ -329,3 +329,34 @@ def test_sharded_prepass_matches_full(hip_ctx):
     hip_ctx.run_dev(1, 0, False, 0, out.data_ptr())
     hip_ctx.sync()
     assert np.array_equal(out.cpu().numpy(), full, equal_nan=True)
+
+
+def test_kt_fast_through_hip_engine(hip_ctx, golden_dir, expected):
+    """kt_fast() NA policies on the MI355X engine against the reference's snapshots and the checker engine."""
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+    X = np.load(f"{golden_dir}/ktfast_100x4.npz")["X"]
+    names = ["s1", "s2", "s3", "s4"]
+    e = expected["ktfast"]
+    x_na2 = X.copy()
+    x_na2[9, 0] = np.nan
+    for use in ("complete.obs", "pairwise.complete.obs", "everything"):
+        g = api.kt_fast(x_na2, use=use, colnames=names)
+        o = api.kt_fast(x_na2, use=use, colnames=names, engine=OracleEngine())
+        for k in ("tau", "pvalue"):
+            a, b = g[k].to_numpy(), o[k].to_numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            assert np.all(np.isnan(a)) or np.nanmax(np.abs(a - b)) <= ATOL
+    mp = api.kt_fast(x_na2, use="pairwise.complete.obs", colnames=names)
+    assert float(f"{mp['tau'].iloc[1, 2]:.7g}") == e["pairwise_tau"]["1-2"]
+    assert float(f"{mp['pvalue'].iloc[1, 1]:.7g}") == e["self_p_n100"]
+    # a larger pairwise case with scattered NAs (every pair drops different rows)
+    rng = np.random.default_rng(61)
+    Y = rng.standard_normal((400, 12))
+    Y[rng.random(Y.shape) < 0.1] = np.nan
+    Y[:, 5] = np.round(Y[:, 5] * 2)
+    nm = [f"c{i}" for i in range(12)]
+    g = api.kt_fast(Y, use="pairwise.complete.obs", colnames=nm)
+    o = api.kt_fast(Y, use="pairwise.complete.obs", colnames=nm, engine=OracleEngine())
+    assert np.nanmax(np.abs(g["tau"].to_numpy() - o["tau"].to_numpy())) <= ATOL
+    assert np.nanmax(np.abs(g["pvalue"].to_numpy() - o["pvalue"].to_numpy())) <= ATOL

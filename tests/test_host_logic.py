@@ -150,3 +150,56 @@ def test_setup_comparisons_order_and_cores():
     assert list(core) == [1, 1, 1, 1, 2, 2, 2, 2, 3, 3]                      # ceiling(10 / 3) = 4 per core
     pi, pj, _ = api.setup_comparisons(_names(3), diag_good=False)
     assert list(zip(pi, pj)) == [(0, 1), (0, 2), (1, 2), (0, 0), (1, 1), (2, 2)]
+
+
+def _sig7(v):
+    return float(f"{v:.7g}")
+
+
+def test_kt_fast_snapshots(expected):
+    # tests/testthat/test-kendall-tau.R:153-205 and _snaps/kendall-tau.md:19-88
+    X = np.load("tests/golden/ktfast_100x4.npz")["X"]
+    names = _names(4)
+    e = expected["ktfast"]
+    from scipy import stats
+    fast = api.kt_fast(X, colnames=names, engine=ENG)
+    base = np.array([[stats.kendalltau(X[:, i], X[:, j]).statistic for j in range(4)] for i in range(4)])
+    assert np.allclose(fast["tau"].to_numpy(), base, atol=1e-14)
+    x_na = X.copy()
+    x_na[:, 0] = np.nan
+    assert np.all(np.isnan(api.kt_fast(x_na, use="complete.obs", colnames=names, engine=ENG)["tau"].to_numpy()))
+    x_na2 = X.copy()
+    x_na2[9, 0] = np.nan
+    ev = api.kt_fast(x_na2[:, 0], x_na2[:, 1], engine=ENG)
+    assert np.all(np.isnan(ev["tau"].to_numpy())) and np.all(np.isnan(ev["pvalue"].to_numpy()))
+    pc = api.kt_fast(x_na2[:, 0], x_na2[:, 1], use="complete.obs", engine=ENG)
+    assert _sig7(pc["tau"].iloc[0, 1]) == e["complete_tau"]["0-1"] and _sig7(pc["pvalue"].iloc[0, 1]) == e["complete_p"]["0-1"]
+    assert pc["tau"].iloc[0, 0] == 1.0 and _sig7(pc["pvalue"].iloc[0, 0]) == e["self_p_n99"]
+    pp = api.kt_fast(x_na2[:, 0], x_na2[:, 1], use="pairwise.complete.obs", engine=ENG)
+    # the reference's expect_equal() passes on all.equal's mean relative difference; entry by entry only the
+    # second self comparison differs (100 rows instead of 99: 3.48e-49 vs 1.08e-48)
+    assert np.array_equal(pp["tau"].to_numpy(), pc["tau"].to_numpy())
+    assert np.allclose(pp["pvalue"].to_numpy(), pc["pvalue"].to_numpy(), rtol=0, atol=1.5e-8)
+    assert _sig7(pp["pvalue"].iloc[1, 1]) == e["self_p_n100"] and _sig7(pp["pvalue"].iloc[0, 0]) == e["self_p_n99"]
+    assert np.all(np.isnan(api.kt_fast(x_na2, use="everything", colnames=names, engine=ENG)["tau"].to_numpy()))
+    mc = api.kt_fast(x_na2, use="complete.obs", colnames=names, engine=ENG)
+    for key, t in e["complete_tau"].items():
+        i, j = map(int, key.split("-"))
+        assert mc["tau"].iloc[i, j] == pytest.approx(t, rel=2e-7) and _sig7(mc["pvalue"].iloc[i, j]) == pytest.approx(e["complete_p"][key], rel=1e-6)
+    mp = api.kt_fast(x_na2, use="pairwise.complete.obs", colnames=names, engine=ENG)
+    for key, t in e["pairwise_tau"].items():
+        i, j = map(int, key.split("-"))
+        assert mp["tau"].iloc[i, j] == pytest.approx(t, rel=2e-7) and _sig7(mp["pvalue"].iloc[i, j]) == pytest.approx(e["pairwise_p"][key], rel=1e-6)
+    assert _sig7(mp["pvalue"].iloc[1, 1]) == e["self_p_n100"] and _sig7(mp["pvalue"].iloc[0, 0]) == e["self_p_n99"]
+    assert np.array_equal(mp["tau"].to_numpy()[:, 0], mc["tau"].to_numpy()[:, 0])
+    df = api.kt_fast(X, return_matrix=False, colnames=names, engine=ENG)["tau"]
+    assert list(df.columns) == ["s1", "s2", "core", "tau", "pvalue"] and len(df) == 10
+    assert df["tau"][3] == fast["tau"].loc["s2", "s3"]
+    with pytest.raises(ValueError, match="is not a supported"):
+        api.kt_fast(X, use="na.or.complete", colnames=names, engine=ENG)
+    with pytest.raises(ValueError, match="Colnames of `x` must be be specified."):
+        api.kt_fast(X, engine=ENG)
+    with pytest.raises(ValueError, match="should both be provided as vectors"):
+        api.kt_fast(X[:, 0], engine=ENG)
+    with pytest.raises(ValueError, match="must be vectors"):
+        api.kt_fast(X, X, colnames=names, engine=ENG)

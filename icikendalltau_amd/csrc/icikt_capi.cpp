@@ -72,6 +72,8 @@ struct icikt_ctx {
   int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<PairRaw> d_raw;
+  DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
+  DevBuf<uint32_t> d_pend_pre;
   std::vector<int32_t> h_pi, h_pj, h_units;
 
   // host-path staging
@@ -135,8 +137,9 @@ int timer_end(icikt_ctx* c, int k, uint32_t flags) {
 
 // launch plan of the pair kernel for a given n
 struct K1Plan {
-  int np;    // pairs per wave (1, 2 or 4): consecutive pairs with the same pi (the gathered column)
-  int wpb;   // waves per workgroup
+  int np;            // pairs per wave (1, 2 or 4): consecutive pairs with the same pi (the gathered column)
+  bool pend_global;  // open-group bitset in global memory (long columns) instead of LDS
+  int wpb;           // waves per workgroup
   size_t lds_bytes;
   int perpair_bytes;
 };
@@ -144,11 +147,17 @@ struct K1Plan {
 K1Plan plan_k1(const PrepView& pv) {
   K1Plan pl{};
   const int Wp4 = (pv.Wp + 3) & ~3;
-  pl.perpair_bytes = Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16); multiple of 16
   const size_t lds_cap = 160 * 1024;
-  // two pairs per wave ride the packed-u16 all-pairs loop; fall back to one when the per-wave LDS
-  // state would leave fewer than 8 waves per CU
+  const size_t full = (size_t)Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16)
+  const size_t slim = ((size_t)Wp4 * (8 + 2) + 15) & ~(size_t)15;  // seen + spre only
+  // pend stays in LDS while two pairs per wave still leave 16 waves per CU (n <~ 16 000); beyond that the
+  // LDS state is what limits occupancy and pend moves to global memory (slower general steps)
+  pl.pend_global = full * 2 * 16 > lds_cap;
+  if (const char* e = getenv("ICIKT_K1_PEND")) pl.pend_global = (e[0] == 'g');
+  pl.perpair_bytes = (int)(pl.pend_global ? slim : full);
+  // two pairs per wave ride the packed-u16 all-pairs loop; one when that leaves fewer than 8 waves per CU
   int np = ((size_t)pl.perpair_bytes * 2 * 8 <= lds_cap) ? 2 : 1;
+  if (pl.pend_global && (size_t)pl.perpair_bytes * 2 * 16 > lds_cap) np = 1;  // long columns: waves over packing
   if (const char* e = getenv("ICIKT_K1_NP")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) np = v;
@@ -248,6 +257,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->order.release(); c->hirow.release(); c->rec.release(); c->mask.release(); c->fillmask.release();
   c->gflag.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
+  c->d_pend_bits.release(); c->d_pend_pre.release();
   c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (int j = 0; j < 2; ++j)
@@ -450,8 +460,39 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   if (c->pv.n > 0) {
     rc = timer_begin(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
+    // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
+    // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
+    // wave owns a slot of it, so waves are persistent and stride over the task list; the grid is 8x what the
+    // chip holds at once (slots: a few hundred MB at n = 50 000).
+    int per_cu = 0;
+    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.wpb, pl.lds_bytes, &per_cu));
+    if (per_cu < 1) per_cu = 1;
+    per_cu = pl.pend_global ? per_cu * 8 : (1 << 20);
+    const int want = (c->n_units + pl.wpb - 1) / pl.wpb;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)per_cu * c->prop.multiProcessorCount));
+    {  // even rounds: shrink the grid so that every wave walks the same number of tasks
+      const int64_t waves = (int64_t)blocks * pl.wpb;
+      const int64_t rounds = (c->n_units + waves - 1) / waves;
+      blocks = (int)std::max<int64_t>(1, (c->n_units + rounds * pl.wpb - 1) / (rounds * pl.wpb));
+    }
+    if (getenv("ICIKT_DEBUG_PLAN"))
+      fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
+              pl.np, pl.pend_global ? "global" : "lds", pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
+              blocks, c->n_units);
+    if (pl.pend_global) {
+      const int Wp4 = (c->pv.Wp + 3) & ~3;
+      const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * Wp4;
+      if (pend_elems > c->d_pend_bits.cap) {
+        HIPCHK(c, c->d_pend_bits.reserve(pend_elems));
+        HIPCHK(c, c->d_pend_pre.reserve(pend_elems));
+        // slots start (and are left by every task) all zero
+        HIPCHK(c, hipMemsetAsync(c->d_pend_bits.p, 0, c->d_pend_bits.cap * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pend_pre.p, 0, c->d_pend_pre.cap * sizeof(uint32_t), c->stream));
+      }
+    }
     HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
-                               pl.wpb, pl.lds_bytes, pl.perpair_bytes, c->stream));
+                               pl.pend_global, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
+                               c->d_pend_pre.p, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
   }

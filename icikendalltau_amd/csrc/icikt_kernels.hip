@@ -377,10 +377,58 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 // closes; pend also yields the joint ties (compare_both, kendallc.cpp:33-51) of groups spanning steps.
 struct WaveLds {
   unsigned long long* seen;
-  unsigned long long* pend;
   uint16_t* spre;
-  uint16_t* ppre;
 };
+
+// `pend` and its prefix live in LDS beside seen/spre for short columns; for long ones (PG = true) they
+// live in GLOBAL memory, one private slot per launched wave and pair: only steps that meet a tie group of
+// the streamed column touch them (on continuous data: the missing-value group), and keeping them out of
+// LDS halves the per-pair LDS state when that state is what limits the waves per CU.  A global slot is
+// all zero between tasks (every open group is merged at the latest in the last step).  Lanes of the wave
+// hand data to each other through it, so reads bypass the CU's L1 (agent-scope relaxed atomics = sc1) and
+// phases are separated by s_waitcnt vmcnt(0).  Measured: global pend costs c4 (10 % missing, n = 10 000)
+// +50 % and gains c5 (n = 50 000) 15 %.
+struct PendG {
+  unsigned long long* bits;
+  uint32_t* pre;     // PG = true : u32 prefix in global memory
+  uint16_t* pre16;   // PG = false: u16 prefix in LDS
+};
+
+__device__ __forceinline__ unsigned long long g_ld64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t g_ld32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_st64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_st32(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_or64(unsigned long long* p, unsigned long long v) {
+  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// pend accessors: PG selects global (L1-bypassing) or LDS
+template <bool PG> __device__ __forceinline__ unsigned long long p_ld(const PendG& P, int w) {
+  return PG ? g_ld64(&P.bits[w]) : P.bits[w];
+}
+template <bool PG> __device__ __forceinline__ void p_st(const PendG& P, int w, unsigned long long v) {
+  if (PG) g_st64(&P.bits[w], v); else P.bits[w] = v;
+}
+template <bool PG> __device__ __forceinline__ void p_or(const PendG& P, int w, unsigned long long v) {
+  if (PG) g_or64(&P.bits[w], v); else atomicOr(&P.bits[w], v);
+}
+template <bool PG> __device__ __forceinline__ uint32_t p_ldpre(const PendG& P, int w) {
+  return PG ? g_ld32(&P.pre[w]) : (uint32_t)P.pre16[w];
+}
+template <bool PG> __device__ __forceinline__ void p_stpre(const PendG& P, int w, uint32_t v) {
+  if (PG) g_st32(&P.pre[w], v); else P.pre16[w] = (uint16_t)v;
+}
+template <bool PG> __device__ __forceinline__ void wave_pend_fence() {
+  if (PG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // In-step all-pairs loop for TWO pairs packed as u16 halves of one register.  One step is
 //   qs  = whole-wave shift right by one lane of qs (lane 0 keeps its value)
@@ -474,10 +522,12 @@ __device__ __forceinline__ void rebuild_prefix_hot(const WaveLds* L, int Wp, int
     }
 }
 
-// prefix popcounts of bits[0..Wp); optionally first merges merge_from into bits and clears merge_from.
+// prefix popcounts of bits[0..Wp) (LDS); optionally first merges the pend bitset merge_from into bits
+// and clears it.
 // Lane l owns words [l*items, (l+1)*items).
+template <bool PG>
 __device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_t* pre,
-                                               unsigned long long* merge_from, int Wp, int items,
+                                               const PendG* merge_from, int Wp, int items,
                                                uint32_t lane) {
   const int base = (int)lane * items;
   if (items <= 4) {
@@ -490,9 +540,9 @@ __device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_
       if (i < items && w < Wp) {
         unsigned long long v = bits[w];
         if (merge_from) {
-          v |= merge_from[w];
+          v |= p_ld<PG>(*merge_from, w);
           bits[w] = v;
-          merge_from[w] = 0ull;
+          p_st<PG>(*merge_from, w, 0ull);
         }
         pc[i] = (uint32_t)__popcll(v);
       }
@@ -513,9 +563,9 @@ __device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_
     if (w < Wp) {
       unsigned long long v = bits[w];
       if (merge_from) {
-        v |= merge_from[w];
+        v |= p_ld<PG>(*merge_from, w);
         bits[w] = v;
-        merge_from[w] = 0ull;
+        p_st<PG>(*merge_from, w, 0ull);
       }
       local += (uint32_t)__popcll(v);
     }
@@ -535,6 +585,30 @@ __device__ __forceinline__ uint32_t prefix_query(const unsigned long long* bits,
   return (uint32_t)pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
 }
 
+template <bool PG>
+__device__ __forceinline__ uint32_t pend_query(const PendG& P, uint32_t pos) {
+  const int w = (int)(pos >> 6);
+  return p_ldpre<PG>(P, w) + (uint32_t)__popcll(p_ld<PG>(P, w) & low_mask64(pos & 63u));
+}
+
+template <bool PG>
+__device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, uint32_t lane) {
+  const int base = (int)lane * items;
+  uint32_t local = 0;
+  for (int i = 0; i < items; ++i) {
+    const int w = base + i;
+    if (w < Wp) local += (uint32_t)__popcll(p_ld<PG>(P, w));
+  }
+  uint32_t run = wave_incl_scan(local) - local;
+  for (int i = 0; i < items; ++i) {
+    const int w = base + i;
+    if (w < Wp) {
+      p_stpre<PG>(P, w, run);
+      run += (uint32_t)__popcll(p_ld<PG>(P, w));
+    }
+  }
+}
+
 // state of one pair inside a wave
 struct PairState {
   WaveLds L;
@@ -551,7 +625,9 @@ struct PairState {
 struct StepCounts { uint32_t dis, tie, tie2; };
 struct StepAcc { WaveLds L; uint32_t dis, tie, tie2; };
 
-__device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const unsigned long long F,
+template <bool PG>
+__device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
+                                                               const unsigned long long F,
                                                                const bool Fn, const bool valid, const uint32_t row,
                                                                const uint32_t q, const uint32_t lo,
                                                                const uint16_t* hiG, const int Wp, const int items,
@@ -597,58 +673,61 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     if (olane) {
       // joint ties with the group's rows of earlier steps
       ph = (uint32_t)hiG[row] + 1u;
-      ebefore = prefix_query(S.L.pend, S.L.ppre, ph) - prefix_query(S.L.pend, S.L.ppre, lo);
+      ebefore = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
       S.tie += ebefore;
     } else if (valid) {
       // rows of later groups of this step also see the open group's earlier rows, still in pend
-      S.dis += prefix_query(S.L.pend, S.L.ppre, lo);
+      S.dis += pend_query<PG>(Pg, lo);
     }
   }
 
   // (4) insert this step's rows
   wave_lds_fence();
+  wave_pend_fence<PG>();
   const unsigned long long bit = 1ull << (q & 63u);
   const uint32_t qw = (q & 0xFFFFu) >> 6;
   if (F == 0ull) {
-    if (valid) atomicOr(&S.L.pend[qw], bit);
-    wave_lds_fence();
-    rebuild_prefix(S.L.pend, S.L.ppre, nullptr, Wp, items, lane);
-    wave_lds_fence();
+    if (valid) p_or<PG>(Pg, (int)qw, bit);
+    wave_pend_fence<PG>();
+    pend_rebuild<PG>(Pg, Wp, items, lane);
+    wave_pend_fence<PG>();
     // in-step joint ties: sum over rows of (#rows of this step in the same tie group of the gathered
     // column, itself included) = after - before; twice the tie count is that sum minus the rows
     if (valid) {
-      const uint32_t after = prefix_query(S.L.pend, S.L.ppre, ph) - prefix_query(S.L.pend, S.L.ppre, lo);
+      const uint32_t after = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
       S.tie2 += after - ebefore - 1u;
     }
     if (Fn) {
-      wave_lds_fence();
-      rebuild_prefix(S.L.seen, S.L.spre, S.L.pend, Wp, items, lane);
+      wave_pend_fence<PG>();
+      rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
     }
   } else {
     const int last_start = 63 - (int)__builtin_clzll(F);
     const bool tlane = valid && ((int)lane >= last_start);
-    if (olane) atomicOr(&S.L.pend[qw], bit);
+    if (olane) p_or<PG>(Pg, (int)qw, bit);
     else if (valid && (Fn || !tlane)) atomicOr(&S.L.seen[qw], bit);
     wave_lds_fence();
-    rebuild_prefix(S.L.seen, S.L.spre, ((F & 1ull) == 0ull) ? S.L.pend : nullptr, Wp, items, lane);
+    wave_pend_fence<PG>();
+    rebuild_prefix<PG>(S.L.seen, S.L.spre, ((F & 1ull) == 0ull) ? &Pg : nullptr, Wp, items, lane);
     if (!Fn) {
-      wave_lds_fence();
-      if (tlane) atomicOr(&S.L.pend[qw], bit);
-      wave_lds_fence();
-      rebuild_prefix(S.L.pend, S.L.ppre, nullptr, Wp, items, lane);
+      wave_pend_fence<PG>();
+      if (tlane) p_or<PG>(Pg, (int)qw, bit);
+      wave_pend_fence<PG>();
+      pend_rebuild<PG>(Pg, Wp, items, lane);
     }
   }
   wave_lds_fence();
+  wave_pend_fence<PG>();
   StepCounts out;
   out.dis = S.dis; out.tie = S.tie; out.tie2 = S.tie2;
   return out;
 }
 
-template <int NP>
-__global__ void __launch_bounds__(512)
+template <int NP, bool PG>
+__global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
-         int perpair_bytes) {
+         int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   // XCD-aware mapping: consecutive tasks share their gathered column, so keep them on one XCD
@@ -661,11 +740,20 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // SGPR: keeps every per-wave pointer scalar
   const int wpb = blockDim.x >> 6;
-  const int task = blk * wpb + wave;
-  if (task >= n_tasks) return;  // the kernel has no workgroup barrier
+  const int gwave = blk * wpb + wave;             // this wave's slot among the launched waves
+  const int nwaves = (int)gridDim.x * wpb;
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const uint32_t lane = lane_id();
+  const int Wp4 = (Wp + 3) & ~3;
+  const int items = (Wp + 63) >> 6;
+  const int nb = (n + 63) >> 6;
+  uint32_t pk_ones = 0x00010001u;
+  asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
+
+  // persistent waves: the grid is sized to the chip and each wave walks the task list with stride nwaves;
+  // the kernel has no workgroup barrier, so the waves of a workgroup run independently
+  for (int task = gwave; task < n_tasks; task += nwaves) {
   const int p0 = __builtin_amdgcn_readfirstlane(task_start[task]);
   const int np = __builtin_amdgcn_readfirstlane(task_start[task + 1]) - p0;  // 1..NP pairs, same pi
   // the gathered (random-access) column is the pairs' common pi: the waves of a workgroup, and the
@@ -676,8 +764,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
   const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
 
-  const int Wp4 = (Wp + 3) & ~3;
   PairState S[NP];
+  PendG Pg[NP];
   uint32_t cb[NP], gg[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -685,11 +773,20 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     const int acol = __builtin_amdgcn_readfirstlane(pj[p0 + (k < np ? k : np - 1)]);
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
     S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
-    S[k].L.pend = S[k].L.seen + Wp4;
-    S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.pend + Wp4);
-    S[k].L.ppre = S[k].L.spre + Wp4;
-    for (int w = lane; w < Wp4; w += 64) {
-      S[k].L.seen[w] = 0ull; S[k].L.pend[w] = 0ull; S[k].L.spre[w] = 0; S[k].L.ppre[w] = 0;
+    if (PG) {
+      S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
+      for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; S[k].L.spre[w] = 0; }
+      Pg[k].bits = pend_bits + ((size_t)gwave * NP + k) * (size_t)Wp4;
+      Pg[k].pre = pend_pre + ((size_t)gwave * NP + k) * (size_t)Wp4;
+      Pg[k].pre16 = nullptr;
+    } else {
+      Pg[k].bits = S[k].L.seen + Wp4;
+      S[k].L.spre = reinterpret_cast<uint16_t*>(Pg[k].bits + Wp4);
+      Pg[k].pre16 = S[k].L.spre + Wp4;
+      Pg[k].pre = nullptr;
+      for (int w = lane; w < Wp4; w += 64) {
+        S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; S[k].L.spre[w] = 0; Pg[k].pre16[w] = 0;
+      }
     }
     S[k].ord = pv.order + (int64_t)acol * pv.n_ord;
     S[k].gf = pv.gflag + (int64_t)acol * Wp;
@@ -705,10 +802,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   }
   wave_lds_fence();
 
-  const int items = (Wp + 63) >> 6;
-  const int nb = (n + 63) >> 6;
-  uint32_t pk_ones = 0x00010001u;
-  asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     S[k].Fnext = (nb > 0) ? S[k].gf[0] : 0ull;
@@ -778,7 +871,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
         rebuild_prefix_hot<NP>(Ls, Wp, items, lane);
       } else {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) rebuild_prefix(S[k].L.seen, S[k].L.spre, nullptr, Wp, items, lane);
+        for (int k = 0; k < NP; ++k) rebuild_prefix<PG>(S[k].L.seen, S[k].L.spre, nullptr, Wp, items, lane);
       }
       wave_lds_fence();
       continue;
@@ -797,7 +890,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest(S[k].L, F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, Wp, items, lane);
+      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
   }
@@ -817,11 +910,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       raw[p0 + k] = o;
     }
   }
+  wave_lds_fence();
+  }  // task loop
 }
 
-template __global__ void k1_pairs<1>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
-template __global__ void k1_pairs<2>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
-template __global__ void k1_pairs<4>(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int);
 
 // ------------------------------------------------------------------------------------------------
 // K2: epilogue, one pair per lane
@@ -1041,23 +1133,35 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
   return hipGetLastError();
 }
 
+typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
+                        unsigned long long*, uint32_t*);
+
+static k1_fn_t k1_select(int np, bool pend_global) {
+  if (pend_global) return (np == 1) ? &k1_pairs<1, true> : (np == 2) ? &k1_pairs<2, true> : &k1_pairs<4, true>;
+  return (np == 1) ? &k1_pairs<1, false> : (np == 2) ? &k1_pairs<2, false> : &k1_pairs<4, false>;
+}
+
 hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
-                     const int32_t* pj, PairRaw* raw, int np, int wpb, size_t lds_bytes, int perpair_bytes,
+                     const int32_t* pj, PairRaw* raw, int np, bool pend_global, int wpb, int blocks,
+                     size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
                      hipStream_t s) {
-  if (n_tasks <= 0) return hipSuccess;
-  const int blocks = (n_tasks + wpb - 1) / wpb;
-  const void* fn = (np == 1) ? reinterpret_cast<const void*>(&k1_pairs<1>)
-                 : (np == 2) ? reinterpret_cast<const void*>(&k1_pairs<2>)
-                             : reinterpret_cast<const void*>(&k1_pairs<4>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
+  k1_fn_t fn = k1_select(np, pend_global);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
   if (e != hipSuccess) return e;
-  if (np == 1)
-    hipLaunchKernelGGL(k1_pairs<1>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
-  else if (np == 2)
-    hipLaunchKernelGGL(k1_pairs<2>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
-  else
-    hipLaunchKernelGGL(k1_pairs<4>, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw, perpair_bytes);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw,
+                     perpair_bytes, pend_bits, pend_pre);
   return hipGetLastError();
+}
+
+// resident workgroups per CU of the pair kernel for a launch shape (occupancy query)
+hipError_t k1_blocks_per_cu(int np, bool pend_global, int wpb, size_t lds_bytes, int* out) {
+  k1_fn_t fn = k1_select(np, pend_global);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, reinterpret_cast<const void*>(fn), wpb * 64, lds_bytes);
 }
 
 hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, const PairRaw* raw,

@@ -360,3 +360,44 @@ def test_kt_fast_through_hip_engine(hip_ctx, golden_dir, expected):
     o = api.kt_fast(Y, use="pairwise.complete.obs", colnames=nm, engine=OracleEngine())
     assert np.nanmax(np.abs(g["tau"].to_numpy() - o["tau"].to_numpy())) <= ATOL
     assert np.nanmax(np.abs(g["pvalue"].to_numpy() - o["pvalue"].to_numpy())) <= ATOL
+
+
+def test_c_abi_error_contract(hip_ctx):
+    """Status codes + messages instead of exceptions across the boundary (include/icikt.h)."""
+    import ctypes
+    import torch
+    from icikendalltau_amd import _lib
+    L = _lib.lib()
+    h = hip_ctx._h
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((50, 4)))
+    out = np.empty((1, 4))
+    bad = np.array([9], dtype=np.int32)
+    ok = np.array([0], dtype=np.int32)
+    rc = L.icikt_pairs_f64(h, X.ctypes.data, 50, 4, 50, bad.ctypes.data, ok.ctypes.data, 1, 1, 0, 0, 0,
+                           out.ctypes.data, None, None)
+    assert rc == -1 and b"out of range" in L.icikt_last_error(h)
+    rc = L.icikt_pairs_f64(h, X.ctypes.data, 50, 4, 10, ok.ctypes.data, ok.ctypes.data, 1, 1, 0, 0, 0,
+                           out.ctypes.data, None, None)
+    assert rc == -1                                    # ld < n_feat
+    rc = L.icikt_pairs_f64(h, X.ctypes.data, 50, 4, 50, ok.ctypes.data, ok.ctypes.data, 1, 7, 0, 0, 0,
+                           out.ctypes.data, None, None)
+    assert rc == -1 and b"perspective" in L.icikt_last_error(h)
+    c2 = _lib.Context(0)
+    d = torch.empty(4, dtype=torch.float64, device="cuda")
+    with pytest.raises(_lib.IciktError, match="prepare"):
+        c2.run_dev(1, 0, False, 0, d.data_ptr())       # run before prepare
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    c2.prepare_dev(dX.data_ptr(), 50, 4, 50)
+    with pytest.raises(_lib.IciktError, match="pair list"):
+        c2.run_dev(1, 0, False, 0, d.data_ptr())       # run before set_pairs
+    c2.set_pairs(np.array([0, 5], np.int32), np.array([1, 2], np.int32))
+    with pytest.raises(_lib.IciktError, match="column"):
+        c2.run_dev(1, 0, False, 0, d.data_ptr())       # pair list refers to column 5 of 4
+    with pytest.raises(_lib.IciktError, match="range"):
+        c2.set_pairs_combn(4, 0, 7)                    # C(4,2) = 6
+    c2.close()
+    # zero pairs / zero rows are not errors
+    o, c, r = hip_ctx.pairs(X, np.array([], np.int32), np.array([], np.int32))
+    assert o.shape == (0, 4)
+    o, c, r = hip_ctx.pairs(np.empty((0, 3)), perspective="global")
+    assert o.shape == (3, 4) and np.all(r == 1) and np.all(np.isnan(o))

@@ -142,6 +142,7 @@ struct K1Plan {
   int wpb;           // waves per workgroup
   size_t lds_bytes;
   int perpair_bytes;
+  int opts;          // bit 0: half-wave hot step (one pair per 32-lane half, 32-row sub-steps)
 };
 
 K1Plan plan_k1(const PrepView& pv) {
@@ -166,6 +167,8 @@ K1Plan plan_k1(const PrepView& pv) {
   int wpb = 4;
   if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
+  pl.opts = 1;
+  if (const char* e = getenv("ICIKT_K1_HALF")) pl.opts = (e[0] == '1') ? 1 : 0;
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
   pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
@@ -492,7 +495,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     }
     HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                                pl.pend_global, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
-                               c->d_pend_pre.p, c->stream));
+                               c->d_pend_pre.p, pl.opts, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
   }
@@ -626,15 +629,34 @@ int icikt_selftest(icikt_ctx* c) {
   if (!c) return ICIKT_E_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
-  HIPCHK(c, c->d_self.reserve(192));
+  HIPCHK(c, c->d_self.reserve(448));
   HIPCHK(c, icikt::launch_selftest(c->d_self.p, c->stream));
-  uint32_t h[192];
+  uint32_t h[448];
   HIPCHK(c, hipMemcpyAsync(h, c->d_self.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (uint32_t l = 0; l < 64; ++l) {
     if (h[l] != (l + 1) * (l + 2) / 2) return fail(c, ICIKT_E_HIP, "selftest: wave_incl_scan mismatch");
     if (h[64 + l] != (l == 0 ? 0xABCDu : 3u * (l - 1))) return fail(c, ICIKT_E_HIP, "selftest: wave_shr1 mismatch");
     if (h[128 + l] != (l < 41 ? 0xFFFFFFFFu : l - 41)) return fail(c, ICIKT_E_HIP, "selftest: repeated wave_shr1 mismatch");
+    // half-wave all-pairs: rows below me inside my 32-lane half with q < my lo
+    uint32_t want = 0;
+    const uint32_t lo = ((l * 40503u + 977u) >> 3) & 0xFFFu;
+    for (uint32_t j = (l & 32u); j < l; ++j) want += (((j * 2654435761u >> 20) & 0xFFFu) < lo) ? 1u : 0u;
+    if (h[192 + l] != want) {
+      if (getenv("ICIKT_DEBUG_PLAN")) {
+        for (uint32_t m = 0; m < 64; ++m) {
+          uint32_t w2 = 0;
+          const uint32_t lo2 = ((m * 40503u + 977u) >> 3) & 0xFFFu;
+          for (uint32_t j = (m & 32u); j < m; ++j) w2 += (((j * 2654435761u >> 20) & 0xFFFu) < lo2) ? 1u : 0u;
+          fprintf(stderr, "lane %2u q=%4u lo=%4u got=%2u want=%2u\n", m, (m * 2654435761u >> 20) & 0xFFFu, lo2, h[192 + m], w2);
+        }
+      }
+      return fail(c, ICIKT_E_HIP, "selftest: half_allpairs mismatch");
+    }
+    if (h[256 + l] != (l < 32 ? l : 100u + (l - 32))) return fail(c, ICIKT_E_HIP, "selftest: permlane32_swap[0] mismatch");
+    if (h[320 + l] != (l < 32 ? 32u + l : 100u + l)) return fail(c, ICIKT_E_HIP, "selftest: permlane32_swap[1] mismatch");
+    const uint32_t k = (l & 31u) + 1, b = (l & 32u) + 1;  // sum of (lane+1) over my half up to me
+    if (h[384 + l] != k * (2 * b + k - 1) / 2) return fail(c, ICIKT_E_HIP, "selftest: half_incl_scan mismatch");
   }
   return ICIKT_SUCCESS;
 }

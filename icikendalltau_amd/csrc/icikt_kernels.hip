@@ -609,6 +609,71 @@ __device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, 
   }
 }
 
+// ---- half-wave hot step: one pair per 32-lane half, 32 rows per sub-step --------------------------
+// In-step all-pairs without a shift chain: VOP2 instructions take a DPP control on src0, and inside a
+// 16-lane row DPP shifts by any immediate 1..15, so "is the q of the lane b below me less than my lo" is ONE
+// instruction: v_sub_co_u32_dpp computes q_src - lo and leaves the borrow (lo > q_src) in VCC.  (VOPC has no
+// DPP form on gfx9, and v_subrev_co_u32_dpp ignores the DPP control: tools/ubench/dpp_sem.hip.)  A lane
+// without a source reads 0 (bound_ctrl:0) and would count whenever lo > 0: that is a known number per lane
+// (15 - position in the row) and is subtracted afterwards.  The 16 lanes of the half's lower row are reached
+// through q16 (the lower row's q copied to the upper row's lanes, ~0 = "never below" elsewhere) rotated by
+// 0..15.  31 subtract-with-borrow + 31 add-with-carry per 32 rows of a pair, against 63 x 2 per 64 rows in
+// the packed loop.
+#define ICIKT_HSHR(b) "v_sub_co_u32_dpp %1, vcc, %2, %4 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+                      "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+#define ICIKT_HROR(b) "v_sub_co_u32_dpp %1, vcc, %3, %4 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
+                      "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+// q16: for lanes 16..31 of a half the q of the lane 16 below, 0xFFFFFFFF for lanes 0..15
+__device__ __forceinline__ uint32_t half_allpairs(uint32_t q, uint32_t q16, uint32_t lo, uint32_t lane) {
+  uint32_t acc = 0, junk;
+  // s_nop 1: a DPP read needs two wait states after a VALU write of its source, and hipcc pads nothing
+  // inside an asm statement (q is typically produced by the instruction just before it)
+  asm volatile("s_nop 1\n\t"
+               ICIKT_HSHR(1) ICIKT_HSHR(2) ICIKT_HSHR(3) ICIKT_HSHR(4) ICIKT_HSHR(5) ICIKT_HSHR(6) ICIKT_HSHR(7)
+               ICIKT_HSHR(8) ICIKT_HSHR(9) ICIKT_HSHR(10) ICIKT_HSHR(11) ICIKT_HSHR(12) ICIKT_HSHR(13)
+               ICIKT_HSHR(14) ICIKT_HSHR(15)
+               "v_cmp_lt_u32_e32 vcc, %3, %4\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+               ICIKT_HROR(1) ICIKT_HROR(2) ICIKT_HROR(3) ICIKT_HROR(4) ICIKT_HROR(5) ICIKT_HROR(6) ICIKT_HROR(7)
+               ICIKT_HROR(8) ICIKT_HROR(9) ICIKT_HROR(10) ICIKT_HROR(11) ICIKT_HROR(12) ICIKT_HROR(13)
+               ICIKT_HROR(14) ICIKT_HROR(15)
+               : "+v"(acc), "=&v"(junk)
+               : "v"(q), "v"(q16), "v"(lo)
+               : "vcc");
+  // shifts 1..15 ran past the row start for 15 - p of the steps (p = position in the row) and read 0
+  return acc - ((lo != 0u) ? (15u - (lane & 15u)) : 0u);
+}
+
+// inclusive prefix sum inside each 32-lane half
+__device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  return v;
+}
+
+// prefix rebuild of one bitset per half: lane l (0..31) of a half owns words [l*items, (l+1)*items), items <= 8
+__device__ __forceinline__ void rebuild_prefix_half(unsigned long long* bits, uint16_t* pre, int Wp, int items,
+                                                    uint32_t l) {
+  const int base = (int)l * items;
+  uint32_t pc[8], local = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int w = base + i;
+    const unsigned long long v = (i < items && w < Wp) ? bits[w] : 0ull;
+    pc[i] = (uint32_t)__popcll(v);
+    local += pc[i];
+  }
+  uint32_t run = half_incl_scan(local) - local;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int w = base + i;
+    if (i < items && w < Wp) pre[w] = (uint16_t)run;
+    run += pc[i];
+  }
+}
+
 // state of one pair inside a wave
 struct PairState {
   WaveLds L;
@@ -727,7 +792,8 @@ template <int NP, bool PG>
 __global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
-         int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre) {
+         int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
+         int opts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   // XCD-aware mapping: consecutive tasks share their gathered column, so keep them on one XCD
@@ -748,6 +814,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const int Wp4 = (Wp + 3) & ~3;
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
+  const int items_h = (Wp + 31) >> 5;                       // words per lane when a half rebuilds a prefix
+  const bool half_mode = (NP == 2) && (opts & 1) && items_h <= 8;
   uint32_t pk_ones = 0x00010001u;
   asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
 
@@ -808,6 +876,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     S[k].row_next = gload_u16(S[k].ord, lane);
   }
 
+  uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
   for (int t = 0; t < nb; ++t) {
     const int kpos = t * 64 + (int)lane;
     const bool valid = kpos < n;
@@ -822,6 +891,36 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       Fn[k] = (uniform_u64(S[k].Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
       all_fast = all_fast && (F[k] == ~0ull) && Fn[k];
       row[k] = S[k].row_next;
+    }
+
+    if (NP == 2 && all_fast && half_mode) {
+      // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.
+      //      permlane32_swap turns the two 64-lane row registers into the two sub-steps' rows. --------
+      const auto sw = __builtin_amdgcn_permlane32_swap(row[0], row[NP - 1], false, false);
+      const uint32_t rr0 = gload_u32(recG, sw[0]);
+      const uint32_t rr1 = gload_u32(recG, sw[1]);
+      // prefetch the next step's rows behind the gathers (order[] is zero-padded by one step)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
+      const bool hi = lane >= 32u;
+      unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
+      uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
+      const uint32_t l32 = lane & 31u;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const uint32_t r = sub ? rr1 : rr0;
+        const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
+        const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
+        const uint32_t up = (uint32_t)__shfl_up((int)qh, 16, 64);
+        const uint32_t q16 = (lane & 16u) ? up : 0xFFFFFFFFu;   // lower row of the half: nothing 16 lanes below
+        dis_half += cnt + half_allpairs(qh, q16, loh, lane);
+        wave_lds_fence();
+        atomicOr(&seenH[qh >> 6], 1ull << (qh & 63u));
+        wave_lds_fence();
+        rebuild_prefix_half(seenH, spreH, Wp, items_h, l32);
+        wave_lds_fence();
+      }
+      continue;
     }
 
     if (all_fast) {
@@ -897,7 +996,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
 
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const unsigned long long dis = wave_sum_u64(S[k].dis);
+    const unsigned long long dis = wave_sum_u64(S[k].dis + (((lane >= 32u) == (k == NP - 1 && NP == 2)) ? dis_half : 0u));
     const unsigned long long ntie = wave_sum_u64(S[k].tie) + (wave_sum_u64(S[k].tie2) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);
     const unsigned long long ggs = wave_sum_u64(gg[k]);
@@ -1123,6 +1222,14 @@ __global__ void k_selftest(uint32_t* out) {
   uint32_t v = dpp_wave_shr1(0xFFFFFFFFu, lane);
   for (int s = 1; s < 41; ++s) v = dpp_wave_shr1(v, v);        // in-place chain, crosses DPP rows
   out[128 + lane] = v;                                         // lanes < 41: ~0, else lane-41
+  // half-wave pieces: q, lo from a fixed pseudo-random table; the host recomputes the counts
+  const uint32_t q = (lane * 2654435761u >> 20) & 0xFFFu, lo = ((lane * 40503u + 977u) >> 3) & 0xFFFu;
+  const uint32_t up = (uint32_t)__shfl_up((int)q, 16, 64);
+  out[192 + lane] = half_allpairs(q, (lane & 16u) ? up : 0xFFFFFFFFu, lo, lane);
+  const auto sw = __builtin_amdgcn_permlane32_swap(lane, 100u + lane, false, false);
+  out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)
+  out[320 + lane] = sw[1];                                     // lanes < 32: 32 + lane, else 100 + lane
+  out[384 + lane] = half_incl_scan(lane + 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1134,7 +1241,7 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
 }
 
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
-                        unsigned long long*, uint32_t*);
+                        unsigned long long*, uint32_t*, int);
 
 static k1_fn_t k1_select(int np, bool pend_global) {
   if (pend_global) return (np == 1) ? &k1_pairs<1, true> : (np == 2) ? &k1_pairs<2, true> : &k1_pairs<4, true>;
@@ -1144,14 +1251,14 @@ static k1_fn_t k1_select(int np, bool pend_global) {
 hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
-                     hipStream_t s) {
+                     int opts, hipStream_t s) {
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
   k1_fn_t fn = k1_select(np, pend_global);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw,
-                     perpair_bytes, pend_bits, pend_pre);
+                     perpair_bytes, pend_bits, pend_pre, opts);
   return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ FLAG_TIMING = 2
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
 MAX_FEATURES = 65535
-PREP_ARRAYS = 7
+PREP_ARRAYS = 8
 
 REASON_OK, REASON_ALL_MISSING, REASON_SHORT, REASON_SINGLE_UNIQUE, REASON_TIES_EQ_TOTAL = range(5)
 REASON_WARNINGS = {

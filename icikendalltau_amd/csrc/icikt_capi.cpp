@@ -58,7 +58,7 @@ struct icikt_ctx {
   bool prepared = false;
   PrepView pv{};
   DevBuf<uint16_t> order, hirow;
-  DevBuf<uint32_t> rec;
+  DevBuf<uint32_t> rec, tgroups;
   DevBuf<unsigned long long> mask, fillmask, gflag, sort_keys;
   DevBuf<uint32_t> sort_idx;
   DevBuf<ColStats> stats;
@@ -169,6 +169,10 @@ K1Plan plan_k1(const PrepView& pv) {
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.opts = 1;
   if (const char* e = getenv("ICIKT_K1_HALF")) pl.opts = (e[0] == '1') ? 1 : 0;
+  int tg_max = 256;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
+  if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
+  pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
+  if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
   pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
@@ -258,7 +262,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->mask.release(); c->fillmask.release();
-  c->gflag.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
+  c->gflag.release(); c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release();
   c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -329,6 +333,8 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   HIPCHK(c, c->fillmask.reserve(S * pv.Wp));
   HIPCHK(c, c->gflag.reserve(S * pv.Wp));
   HIPCHK(c, c->stats.reserve(S));
+  pv.tg_stride = pv.n_pad / 2 + 1;
+  HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
   // sort scratch: bounded to ~1 GiB
   size_t chunk = std::min<size_t>(ncols, std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)np2 * 12)));
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
@@ -338,6 +344,7 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   pv.order = c->order.p; pv.hirow = c->hirow.p; pv.rec = c->rec.p;
   pv.mask = c->mask.p; pv.fillmask = c->fillmask.p; pv.gflag = c->gflag.p;
   pv.stats = c->stats.p; pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
+  pv.tgroups = c->tgroups.p;
   c->pv = pv;
   c->alloc_cols = (int64_t)S;
 
@@ -377,6 +384,7 @@ int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
   ptrs[4] = pv.fillmask; bytes_per_col[4] = (int64_t)pv.Wp * 8;
   ptrs[5] = pv.gflag;    bytes_per_col[5] = (int64_t)pv.Wp * 8;
   ptrs[6] = pv.stats;    bytes_per_col[6] = (int64_t)sizeof(ColStats);
+  ptrs[7] = pv.tgroups;  bytes_per_col[7] = (int64_t)pv.tg_stride * 4;
   return ICIKT_SUCCESS;
 }
 

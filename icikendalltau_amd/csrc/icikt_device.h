@@ -18,7 +18,7 @@ struct ColStats {
   int32_t tfill;     // size of the fill group (missing rows + rows equal to min-0.1); 0 if nna == 0
   int32_t maxgroup;  // largest tie group
   uint32_t s0, s1, s2;  // count_rank_tie sums in wrapping int32: t(t-1), t(t-1)(t-2), t(t-1)(2t+5)
-  uint32_t pad;
+  uint32_t ntg;      // tie groups of size >= 2 (length of the column's tgroups list)
   long long e0, e1, e2;  // the same sums exactly
   double fill;           // min - 0.1
 };
@@ -49,6 +49,8 @@ struct PrepView {
   unsigned long long* fillmask;  // [S][Wp] rows in the fill group
   unsigned long long* gflag;     // [S][Wp] bit k: processing position k starts a tie group
   ColStats* stats;               // [S]
+  uint32_t* tgroups;             // [S][tg_stride] tie groups (size >= 2), ascending: lo | hi << 16
+  int tg_stride;                 // n_pad / 2 + 1
   // sort scratch (per column of the current chunk)
   unsigned long long* sort_keys;  // [chunk][npow2]
   uint32_t* sort_idx;             // [chunk][npow2]

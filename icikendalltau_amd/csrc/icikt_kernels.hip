@@ -127,6 +127,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   uint16_t* order = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + (int64_t)c * pv.n_pad;
   uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
+  uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
 
   // ---- phase 1: NA bitset, NA count, min of the non-missing values (kendallc.cpp:187-218) --------
   double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
@@ -281,7 +282,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   __syncthreads();
 
   // per-thread tie statistics over the groups that START in my chunk
-  int ngroups = 0, maxgroup = 0, tfill = 0;
+  int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
   long long e0 = 0, e1 = 0, e2 = 0;     // exact
   {  // backward sweep: last position of each row's tie group
@@ -304,6 +305,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     if (st) {
       const int t = hi - lo + 1;
       ++ngroups;
+      if (t >= 2) ++ntg_local;
       maxgroup = max(maxgroup, t);
       if (lo == 0) tfill = t;
       if (t >= 2) {
@@ -335,6 +337,29 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   if (tid == 0) { gflag[W] = 0ull; }
   for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
 
+  // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
+  // tie group of the OTHER column that spans several steps once, when that group closes
+  {
+    sh_i[tid] = ntg_local;
+    __syncthreads();
+    for (int sft = 1; sft < K0_THREADS; sft <<= 1) {
+      const int v = sh_i[tid];
+      const int o = (tid >= sft) ? sh_i[tid - sft] : 0;
+      __syncthreads();
+      sh_i[tid] = v + o;
+      __syncthreads();
+    }
+    int off = sh_i[tid] - ntg_local;
+    __syncthreads();
+    for (int k = k0; k < k1; ++k) {
+      const bool st = (k == 0) || (keys[k - 1] != keys[k]);
+      if (st) {
+        const int hi = (int)hirow[idx[k]];
+        if (hi > k) tgl[off++] = (uint32_t)k | ((uint32_t)hi << 16);
+      }
+    }
+  }
+  const int ntg = block_reduce<int>(ntg_local, sh_i, [](int a, int b) { return a + b; });
   ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });
   maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return a > b ? a : b; });
   tfill = block_reduce<int>(tfill, sh_i, [](int a, int b) { return a > b ? a : b; });
@@ -351,7 +376,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     st.ngroups = ngroups;
     st.tfill = (nna > 0) ? tfill : 0;
     st.maxgroup = maxgroup;
-    st.s0 = s0; st.s1 = s1; st.s2 = s2; st.pad = 0;
+    st.s0 = s0; st.s1 = s1; st.s2 = s2; st.ntg = (uint32_t)ntg;
     st.e0 = e0; st.e1 = e1; st.e2 = e2;
     st.fill = fill;
     pv.stats[c] = st;
@@ -690,26 +715,53 @@ struct PairState {
 struct StepCounts { uint32_t dis, tie, tie2; };
 struct StepAcc { WaveLds L; uint32_t dis, tie, tie2; };
 
+// Joint ties of an A tie group that is complete in pend (its rows' B-positions): for every tie group of B
+// (list tg, ntg entries) the rows in it contribute C(c, 2).  Rebuilds pend's prefix first.
+template <bool PG>
+__device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint32_t* tg, int ntg, int Wp, int items,
+                                                     uint32_t lane) {
+  wave_pend_fence<PG>();
+  wave_lds_fence();
+  pend_rebuild<PG>(Pg, Wp, items, lane);
+  wave_pend_fence<PG>();
+  wave_lds_fence();
+  uint32_t t = 0;
+  for (int g = (int)lane; g < ntg; g += 64) {
+    const uint32_t r = tg[g];
+    const uint32_t c = pend_query<PG>(Pg, (r >> 16) + 1u) - pend_query<PG>(Pg, r & 0xFFFFu);
+    t += c * (c - 1u) / 2u;
+  }
+  return t;
+}
+
 template <bool PG>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
                                                                const bool Fn, const bool valid, const uint32_t row,
                                                                const uint32_t q, const uint32_t lo,
-                                                               const uint16_t* hiG, const int Wp, const int items,
+                                                               const uint16_t* hiG, const uint32_t* tg, const int ntg,
+                                                               const int Wp, const int items,
                                                                const uint32_t lane) {
+  // Two ways to count the joint ties (compare_both, kendallc.cpp:33-51) of an A tie group that spans steps:
+  //   list mode (ntg >= 0): B has few tie groups; the group's rows just collect in pend and, when the group
+  //     closes, each tie group of B contributes C(rows of the group inside it, 2).  A step inside the
+  //     missing-value group of A then costs one query and one atomic OR.
+  //   row mode (ntg < 0): every row asks pend how many earlier rows of its A group share its B group.
+  const bool list = ntg >= 0;
   StepAcc S;
   S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
-  const bool allpairs_done = false;
+  const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
+  const int last_start = (F != 0ull) ? 63 - (int)__builtin_clzll(F) : 0;
+  const bool olane = valid && ((int)lane < first_start);          // rows of the group open from earlier steps
+  const bool tlane = valid && (F != 0ull) && ((int)lane >= last_start);  // rows of the step's last group
   // (2) pairs inside this step
   if (F == ~0ull) {
-    if (!allpairs_done) {
-      // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
-      const uint32_t c2 = s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q), lo);
-      S.dis += c2;
-    }
+    // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
+    const uint32_t c2 = s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q), lo);
+    S.dis += c2;
   } else if (F != 0ull) {
     // mixed step: xg = group ordinal inside the step; rows tied in the streamed column are not
-    // discordant, and rows tied in both columns are joint ties (compare_both, kendallc.cpp:33-51)
+    // discordant, and rows tied in both columns are joint ties
     const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
     const uint32_t lot = valid ? lo : 0xFFFFFFFFu;
     uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
@@ -725,17 +777,25 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
       ls = dpp_wave_shr1(ls, ls);
     }
     S.dis += valid ? c2 : 0u;
-    S.tie += valid ? c3 : 0u;
+    // list mode: groups that pass through pend are counted when they close, not here
+    const bool counted_here = list ? (valid && !olane && (Fn || !tlane)) : valid;
+    S.tie += counted_here ? c3 : 0u;
   }
-  // F == 0: the whole step lies inside one open group: nothing is discordant in-step; its joint ties
-  // are counted below from pend (before / after inserting the step)
+  // F == 0: the whole step lies inside one open group: nothing is discordant in-step
 
   // (3) rows of a group that is still open from earlier steps
-  const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
-  const bool olane = valid && ((int)lane < first_start);
   uint32_t ph = 0, ebefore = 0;
   if ((F & 1ull) == 0ull) {
-    if (olane) {
+    if (list) {
+      if (F != 0ull) {
+        // the open group closes in this step: rows of the later groups also see its earlier rows (in pend)
+        wave_pend_fence<PG>();
+        pend_rebuild<PG>(Pg, Wp, items, lane);
+        wave_pend_fence<PG>();
+        wave_lds_fence();
+        if (valid && !olane) S.dis += pend_query<PG>(Pg, lo);
+      }
+    } else if (olane) {
       // joint ties with the group's rows of earlier steps
       ph = (uint32_t)hiG[row] + 1u;
       ebefore = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
@@ -753,32 +813,41 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   const uint32_t qw = (q & 0xFFFFu) >> 6;
   if (F == 0ull) {
     if (valid) p_or<PG>(Pg, (int)qw, bit);
-    wave_pend_fence<PG>();
-    pend_rebuild<PG>(Pg, Wp, items, lane);
-    wave_pend_fence<PG>();
-    // in-step joint ties: sum over rows of (#rows of this step in the same tie group of the gathered
-    // column, itself included) = after - before; twice the tie count is that sum minus the rows
-    if (valid) {
-      const uint32_t after = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
-      S.tie2 += after - ebefore - 1u;
-    }
-    if (Fn) {
+    if (list) {
+      if (Fn) {
+        S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
+        wave_pend_fence<PG>();
+        rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+      }
+    } else {
       wave_pend_fence<PG>();
-      rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+      pend_rebuild<PG>(Pg, Wp, items, lane);
+      wave_pend_fence<PG>();
+      // in-step joint ties: sum over rows of (#rows of this step in the same tie group of the gathered
+      // column, itself included) = after - before; twice the tie count is that sum minus the rows
+      if (valid) {
+        const uint32_t after = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
+        S.tie2 += after - ebefore - 1u;
+      }
+      if (Fn) {
+        wave_pend_fence<PG>();
+        rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+      }
     }
   } else {
-    const int last_start = 63 - (int)__builtin_clzll(F);
-    const bool tlane = valid && ((int)lane >= last_start);
     if (olane) p_or<PG>(Pg, (int)qw, bit);
     else if (valid && (Fn || !tlane)) atomicOr(&S.L.seen[qw], bit);
+    if (list && (F & 1ull) == 0ull) S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
     wave_lds_fence();
     wave_pend_fence<PG>();
     rebuild_prefix<PG>(S.L.seen, S.L.spre, ((F & 1ull) == 0ull) ? &Pg : nullptr, Wp, items, lane);
     if (!Fn) {
       wave_pend_fence<PG>();
       if (tlane) p_or<PG>(Pg, (int)qw, bit);
-      wave_pend_fence<PG>();
-      pend_rebuild<PG>(Pg, Wp, items, lane);
+      if (!list) {
+        wave_pend_fence<PG>();
+        pend_rebuild<PG>(Pg, Wp, items, lane);
+      }
     }
   }
   wave_lds_fence();
@@ -816,6 +885,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const int nb = (n + 63) >> 6;
   const int items_h = (Wp + 31) >> 5;                       // words per lane when a half rebuilds a prefix
   const bool half_mode = (NP == 2) && (opts & 1) && items_h <= 8;
+  const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
   uint32_t pk_ones = 0x00010001u;
   asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
 
@@ -831,6 +901,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const uint16_t* hiG = pv.hirow + (int64_t)bcol * pv.n_pad;
   const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
   const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
+  // few tie groups in the gathered column: joint ties of multi-step groups are counted at group close
+  const uint32_t* tgB = pv.tgroups + (int64_t)bcol * pv.tg_stride;
+  const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.stats[bcol].ntg);
+  const int ntgB = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
 
   PairState S[NP];
   PendG Pg[NP];
@@ -989,7 +1063,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, Wp, items, lane);
+      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, tgB, ntgB, Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
   }

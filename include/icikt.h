@@ -117,7 +117,7 @@ int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t 
  * The caller then all-gathers the column slices of the ICIKT_PREP_ARRAYS arrays returned by
  * icikt_prep_arrays() across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
  * [alloc_cols][bytes_per_col[i]] bytes, column-contiguous. */
-#define ICIKT_PREP_ARRAYS 7
+#define ICIKT_PREP_ARRAYS 8
 int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
                            int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);
 int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);

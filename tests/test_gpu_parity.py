@@ -322,7 +322,7 @@ def test_sharded_prepass_matches_full(hip_ctx):
         c0, c1 = min(S, r * cols_per), min(S, (r + 1) * cols_per)
         hip_ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc)
     arrays = hip_ctx.prep_arrays()
-    assert len(arrays) == 7 and all(ptr and bpc > 0 for ptr, bpc in arrays)
+    assert len(arrays) == 8 and all(ptr and bpc > 0 for ptr, bpc in arrays)
     P = S * (S - 1) // 2
     hip_ctx.set_pairs_combn(S, 0, P)
     out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
@@ -401,3 +401,24 @@ def test_c_abi_error_contract(hip_ctx):
     assert o.shape == (0, 4)
     o, c, r = hip_ctx.pairs(np.empty((0, 3)), perspective="global")
     assert o.shape == (3, 4) and np.all(r == 1) and np.all(np.isnan(o))
+
+
+@pytest.mark.parametrize("tgmax", ["-1", "3", "1000000"])
+def test_joint_tie_counting_modes(hip_ctx, tgmax, monkeypatch):
+    """Joint ties of tie groups that span steps: by tie-group list (few groups in the gathered column) or row
+    by row; forced both ways on columns with 2 ... 1 500 tie groups, long and short."""
+    monkeypatch.setenv("ICIKT_K1_TGMAX", tgmax)
+    rng = np.random.default_rng(71)
+    n = 4000
+    X = np.empty((n, 8))
+    X[:, 0] = rng.standard_normal(n)                         # one tie group after masking (missing only)
+    X[:, 1] = np.round(rng.standard_normal(n) * 400)         # ~1 500 small tie groups
+    X[:, 2] = rng.integers(0, 3, n)                          # three huge groups
+    X[:, 3] = np.round(rng.standard_normal(n) * 5)           # ~30 groups of ~100+
+    X[:, 4] = np.sort(X[:, 3])                               # the same values, sorted: groups contiguous in row order
+    X[:, 5] = np.where(rng.random(n) < 0.6, np.nan, rng.standard_normal(n))
+    X[:, 6] = np.repeat(np.arange(n // 80), 80)              # groups of 80: every group spans two steps
+    X[:, 7] = -X[:, 6]
+    X[rng.random(X.shape) < 0.07] = np.nan
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)

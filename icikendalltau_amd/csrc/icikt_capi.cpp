@@ -173,6 +173,7 @@ K1Plan plan_k1(const PrepView& pv) {
   if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
+  if (np != 2 || pl.pend_global || ((pv.Wp + 31) >> 5) > 8) pl.opts &= ~1;  // half-wave step needs <= 8 words per lane
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
   pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
@@ -476,7 +477,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     // wave owns a slot of it, so waves are persistent and stride over the task list; the grid is 8x what the
     // chip holds at once (slots: a few hundred MB at n = 50 000).
     int per_cu = 0;
-    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.wpb, pl.lds_bytes, &per_cu));
+    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, (pl.opts & 1) != 0, pl.wpb, pl.lds_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
     per_cu = pl.pend_global ? per_cu * 8 : (1 << 20);
     const int want = (c->n_units + pl.wpb - 1) / pl.wpb;

@@ -857,7 +857,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   return out;
 }
 
-template <int NP, bool PG>
+template <int NP, bool PG, bool HALF>
 __global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
@@ -884,7 +884,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
   const int items_h = (Wp + 31) >> 5;                       // words per lane when a half rebuilds a prefix
-  const bool half_mode = (NP == 2) && (opts & 1) && items_h <= 8;
+  constexpr bool half_mode = HALF && (NP == 2);              // host guarantees items_h <= 8 for HALF kernels
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
   uint32_t pk_ones = 0x00010001u;
   asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
@@ -967,7 +967,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       row[k] = S[k].row_next;
     }
 
-    if (NP == 2 && all_fast && half_mode) {
+    if (half_mode && all_fast) {
       // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.
       //      permlane32_swap turns the two 64-lane row registers into the two sub-steps' rows. --------
       const auto sw = __builtin_amdgcn_permlane32_swap(row[0], row[NP - 1], false, false);
@@ -997,7 +997,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       continue;
     }
 
-    if (all_fast) {
+    if (!half_mode && all_fast) {
       // ---- hot step: in every pair of the wave all 64 rows are valid, each row is its own tie group
       //      of the streamed column, and no group stays open: gather, count, insert into `seen`.
       //      Loads of all pairs are issued before the first use. ------------------------------------
@@ -1317,9 +1317,12 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
                         unsigned long long*, uint32_t*, int);
 
-static k1_fn_t k1_select(int np, bool pend_global) {
-  if (pend_global) return (np == 1) ? &k1_pairs<1, true> : (np == 2) ? &k1_pairs<2, true> : &k1_pairs<4, true>;
-  return (np == 1) ? &k1_pairs<1, false> : (np == 2) ? &k1_pairs<2, false> : &k1_pairs<4, false>;
+// HALF (half-wave hot step) exists for two pairs per wave with pend in LDS; the host only asks for it when a
+// half can rebuild a prefix with <= 8 words per lane (n <= 16 320)
+static k1_fn_t k1_select(int np, bool pend_global, bool half) {
+  if (pend_global) return (np == 1) ? &k1_pairs<1, true, false> : (np == 2) ? &k1_pairs<2, true, false> : &k1_pairs<4, true, false>;
+  if (np == 2 && half) return &k1_pairs<2, false, true>;
+  return (np == 1) ? &k1_pairs<1, false, false> : (np == 2) ? &k1_pairs<2, false, false> : &k1_pairs<4, false, false>;
 }
 
 hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
@@ -1327,7 +1330,7 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
                      int opts, hipStream_t s) {
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
-  k1_fn_t fn = k1_select(np, pend_global);
+  k1_fn_t fn = k1_select(np, pend_global, (opts & 1) != 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -1337,8 +1340,8 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
 }
 
 // resident workgroups per CU of the pair kernel for a launch shape (occupancy query)
-hipError_t k1_blocks_per_cu(int np, bool pend_global, int wpb, size_t lds_bytes, int* out) {
-  k1_fn_t fn = k1_select(np, pend_global);
+hipError_t k1_blocks_per_cu(int np, bool pend_global, bool half, int wpb, size_t lds_bytes, int* out) {
+  k1_fn_t fn = k1_select(np, pend_global, half);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;

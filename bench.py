@@ -167,15 +167,24 @@ def main():
                 full.copy_(torch.cat(parts))
 
     if world > 1 and os.environ.get("ICIKT_BENCH_PREP", "sharded") == "sharded":
+        # local part first (no collective inside), then the ranks agree: either all of them run the sharded
+        # pre-pass or none does -- a rank that falls back alone would leave the others inside a collective
+        err = None
         try:
             ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, 0)
             shards = [(torch.as_tensor(_DevBytes(ptr, bpc * alloc_cols), device=dev), bpc * cols_per)
                       for ptr, bpc in ctx.prep_arrays()]
-            prepare_sharded()  # one trial pass, so that a collective that cannot run shows up here
+        except Exception as e:  # noqa: BLE001
+            err, shards = e, None
+        ok = torch.tensor([0 if shards is None else 1], dtype=torch.int32, device=comm_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            prepare_sharded()  # one trial pass before the timed region
             torch.cuda.synchronize()
             prep_mode = "sharded+allgather"
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] sharded pre-pass unavailable ({e!r}); every rank runs the whole pre-pass", file=sys.stderr)
+        else:
+            print(f"[bench] rank {rank}: sharded pre-pass unavailable ({err!r}); every rank runs the whole pre-pass",
+                  file=sys.stderr)
             shards = None
     if world > 1 and shards is None:
         prep_mode = "replicated"

@@ -143,6 +143,7 @@ struct K1Plan {
   size_t lds_bytes;
   int perpair_bytes;
   int opts;          // bit 0: half-wave hot step (one pair per 32-lane half, 32-row sub-steps)
+  int half_items;    // words per lane of a half-wave prefix rebuild (0: no half-wave step)
 };
 
 K1Plan plan_k1(const PrepView& pv) {
@@ -166,14 +167,18 @@ K1Plan plan_k1(const PrepView& pv) {
   while (np > 1 && (size_t)pl.perpair_bytes * np > lds_cap) np >>= 1;
   int wpb = 4;
   if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
-  const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.opts = 1;
   if (const char* e = getenv("ICIKT_K1_HALF")) pl.opts = (e[0] == '1') ? 1 : 0;
   int tg_max = 256;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
   if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
-  if (np != 2 || pl.pend_global || ((pv.Wp + 31) >> 5) > 8) pl.opts &= ~1;  // half-wave step needs <= 8 words per lane
+  // half-wave hot step: a half rebuilds a prefix with half_items <= 8 words per lane, unpredicated, so the
+  // LDS arrays of such a kernel are padded to 32 * half_items words
+  pl.half_items = (pv.Wp + 31) >> 5;
+  if (np != 2 || pl.pend_global || pl.half_items > 8 || !(pl.opts & 1)) { pl.opts &= ~1; pl.half_items = 0; }
+  if (pl.half_items) pl.perpair_bytes = 32 * pl.half_items * (8 + 8 + 2 + 2);
+  const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
   pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
@@ -477,7 +482,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     // wave owns a slot of it, so waves are persistent and stride over the task list; the grid is 8x what the
     // chip holds at once (slots: a few hundred MB at n = 50 000).
     int per_cu = 0;
-    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, (pl.opts & 1) != 0, pl.wpb, pl.lds_bytes, &per_cu));
+    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
     per_cu = pl.pend_global ? per_cu * 8 : (1 << 20);
     const int want = (c->n_units + pl.wpb - 1) / pl.wpb;
@@ -488,8 +493,8 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
       blocks = (int)std::max<int64_t>(1, (c->n_units + rounds * pl.wpb - 1) / (rounds * pl.wpb));
     }
     if (getenv("ICIKT_DEBUG_PLAN"))
-      fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
-              pl.np, pl.pend_global ? "global" : "lds", pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
+      fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
+              pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
               blocks, c->n_units);
     if (pl.pend_global) {
       const int Wp4 = (c->pv.Wp + 3) & ~3;
@@ -503,7 +508,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
       }
     }
     HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
-                               pl.pend_global, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
+                               pl.pend_global, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
                                c->d_pend_pre.p, pl.opts, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
@@ -647,25 +652,23 @@ int icikt_selftest(icikt_ctx* c) {
     if (h[l] != (l + 1) * (l + 2) / 2) return fail(c, ICIKT_E_HIP, "selftest: wave_incl_scan mismatch");
     if (h[64 + l] != (l == 0 ? 0xABCDu : 3u * (l - 1))) return fail(c, ICIKT_E_HIP, "selftest: wave_shr1 mismatch");
     if (h[128 + l] != (l < 41 ? 0xFFFFFFFFu : l - 41)) return fail(c, ICIKT_E_HIP, "selftest: repeated wave_shr1 mismatch");
-    // half-wave all-pairs: rows below me inside my 32-lane half with q < my lo
-    uint32_t want = 0;
-    const uint32_t lo = ((l * 40503u + 977u) >> 3) & 0xFFFu;
-    for (uint32_t j = (l & 32u); j < l; ++j) want += (((j * 2654435761u >> 20) & 0xFFFu) < lo) ? 1u : 0u;
-    if (h[192 + l] != want) {
-      if (getenv("ICIKT_DEBUG_PLAN")) {
-        for (uint32_t m = 0; m < 64; ++m) {
-          uint32_t w2 = 0;
-          const uint32_t lo2 = ((m * 40503u + 977u) >> 3) & 0xFFFu;
-          for (uint32_t j = (m & 32u); j < m; ++j) w2 += (((j * 2654435761u >> 20) & 0xFFFu) < lo2) ? 1u : 0u;
-          fprintf(stderr, "lane %2u q=%4u lo=%4u got=%2u want=%2u\n", m, (m * 2654435761u >> 20) & 0xFFFu, lo2, h[192 + m], w2);
-        }
-      }
-      return fail(c, ICIKT_E_HIP, "selftest: half_allpairs mismatch");
-    }
     if (h[256 + l] != (l < 32 ? l : 100u + (l - 32))) return fail(c, ICIKT_E_HIP, "selftest: permlane32_swap[0] mismatch");
     if (h[320 + l] != (l < 32 ? 32u + l : 100u + l)) return fail(c, ICIKT_E_HIP, "selftest: permlane32_swap[1] mismatch");
     const uint32_t k = (l & 31u) + 1, b = (l & 32u) + 1;  // sum of (lane+1) over my half up to me
     if (h[384 + l] != k * (2 * b + k - 1) / 2) return fail(c, ICIKT_E_HIP, "selftest: half_incl_scan mismatch");
+  }
+  // half-wave all-pairs: per 32-lane half, #{(a, j): a before j, q_a < lo_j}; the lanes' shares are summed
+  for (uint32_t half = 0; half < 2; ++half) {
+    uint32_t want = 0, got = 0;
+    for (uint32_t l = half * 32; l < half * 32 + 32; ++l) {
+      const uint32_t lo = ((l * 40503u + 977u) >> 3) & 0xFFFu;
+      for (uint32_t j = half * 32; j < l; ++j) want += (((j * 2654435761u >> 20) & 0xFFFu) < lo) ? 1u : 0u;
+      got += h[192 + l];
+    }
+    if (got != want) {
+      if (getenv("ICIKT_DEBUG_PLAN")) fprintf(stderr, "[icikt] selftest half %u: got %u want %u\n", half, got, want);
+      return fail(c, ICIKT_E_HIP, "selftest: half_allpairs mismatch");
+    }
   }
   return ICIKT_SUCCESS;
 }

@@ -637,19 +637,23 @@ __device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, 
 // ---- half-wave hot step: one pair per 32-lane half, 32 rows per sub-step --------------------------
 // In-step all-pairs without a shift chain: VOP2 instructions take a DPP control on src0, and inside a
 // 16-lane row DPP shifts by any immediate 1..15, so "is the q of the lane b below me less than my lo" is ONE
-// instruction: v_sub_co_u32_dpp computes q_src - lo and leaves the borrow (lo > q_src) in VCC.  (VOPC has no
-// DPP form on gfx9, and v_subrev_co_u32_dpp ignores the DPP control: tools/ubench/dpp_sem.hip.)  A lane
-// without a source reads 0 (bound_ctrl:0) and would count whenever lo > 0: that is a known number per lane
-// (15 - position in the row) and is subtracted afterwards.  The 16 lanes of the half's lower row are reached
-// through q16 (the lower row's q copied to the upper row's lanes, ~0 = "never below" elsewhere) rotated by
-// 0..15.  31 subtract-with-borrow + 31 add-with-carry per 32 rows of a pair, against 63 x 2 per 64 rows in
-// the packed loop.
-#define ICIKT_HSHR(b) "v_sub_co_u32_dpp %1, vcc, %2, %4 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+// instruction: v_sub_co_u32_dpp computes src0_dpp - src1 and leaves the borrow (src1 > src0_dpp) in VCC.
+// (VOPC has no DPP form on gfx9, and v_subrev_co_u32_dpp ignores the DPP control: tools/ubench/dpp_sem.hip.)
+//  * inside a DPP row (15 compares, row_shr:1..15): a lane without a source reads 0 (bound_ctrl:0) and would
+//    count whenever lo > 0: that is a known number per lane (15 - position in the row), subtracted afterwards.
+//  * between the half's two rows (256 pairs, all "lower row earlier"): BOTH rows work, 8 compares instead of
+//    16.  An upper lane asks "lo_me > q_l" of 8 lower lanes; a lower lane asks the same question about
+//    itself, "lo_u > q_me", of the other 8 upper lanes, as "~q_me > ~lo_u" so that the same instruction
+//    serves both.  xa holds what a lane's DPP sources offer (upper lanes: the lower row's q; lower lanes: the
+//    upper row's ~lo rotated by one position), xb = what the lane compares with (upper: lo, lower: ~q); with
+//    row_ror:0..7 (lane p reads p - r) the upper lanes cover (lower - upper) mod 16 in {0, 15, .., 9} and
+//    the lower lanes {1, .., 8}.
+// 23 subtract-with-borrow + 23 add-with-carry per 32 rows of a pair, against 63 x 2 per 64 rows in the packed loop.
+#define ICIKT_HSHR(b) "v_sub_co_u32_dpp %1, vcc, %2, %3 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
                       "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
-#define ICIKT_HROR(b) "v_sub_co_u32_dpp %1, vcc, %3, %4 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
+#define ICIKT_HROR(b) "v_sub_co_u32_dpp %1, vcc, %4, %5 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
                       "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
-// q16: for lanes 16..31 of a half the q of the lane 16 below, 0xFFFFFFFF for lanes 0..15
-__device__ __forceinline__ uint32_t half_allpairs(uint32_t q, uint32_t q16, uint32_t lo, uint32_t lane) {
+__device__ __forceinline__ uint32_t half_allpairs(uint32_t q, uint32_t lo, uint32_t xa, uint32_t xb, uint32_t lane) {
   uint32_t acc = 0, junk;
   // s_nop 1: a DPP read needs two wait states after a VALU write of its source, and hipcc pads nothing
   // inside an asm statement (q is typically produced by the instruction just before it)
@@ -657,15 +661,26 @@ __device__ __forceinline__ uint32_t half_allpairs(uint32_t q, uint32_t q16, uint
                ICIKT_HSHR(1) ICIKT_HSHR(2) ICIKT_HSHR(3) ICIKT_HSHR(4) ICIKT_HSHR(5) ICIKT_HSHR(6) ICIKT_HSHR(7)
                ICIKT_HSHR(8) ICIKT_HSHR(9) ICIKT_HSHR(10) ICIKT_HSHR(11) ICIKT_HSHR(12) ICIKT_HSHR(13)
                ICIKT_HSHR(14) ICIKT_HSHR(15)
-               "v_cmp_lt_u32_e32 vcc, %3, %4\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+               "v_cmp_lt_u32_e32 vcc, %4, %5\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
                ICIKT_HROR(1) ICIKT_HROR(2) ICIKT_HROR(3) ICIKT_HROR(4) ICIKT_HROR(5) ICIKT_HROR(6) ICIKT_HROR(7)
-               ICIKT_HROR(8) ICIKT_HROR(9) ICIKT_HROR(10) ICIKT_HROR(11) ICIKT_HROR(12) ICIKT_HROR(13)
-               ICIKT_HROR(14) ICIKT_HROR(15)
                : "+v"(acc), "=&v"(junk)
-               : "v"(q), "v"(q16), "v"(lo)
+               : "v"(q), "v"(lo), "v"(xa), "v"(xb)
                : "vcc");
   // shifts 1..15 ran past the row start for 15 - p of the steps (p = position in the row) and read 0
   return acc - ((lo != 0u) ? (15u - (lane & 15u)) : 0u);
+}
+
+// ds_bpermute byte index of the lane whose `offer` a lane reads for the cross-row compares: upper row <- same
+// position of the lower row, lower row <- the upper row rotated by one
+__device__ __forceinline__ uint32_t half_cross_idx(uint32_t lane) {
+  return ((lane & 16u) ? lane - 16u : ((lane & 32u) | 16u | ((lane - 1u) & 15u))) << 2;
+}
+// per-lane share of #{rows a before row j in the same 32-lane half : q_a < lo_j}; only the sum over the half
+// is meaningful (lower-row lanes carry part of the upper row's counts)
+__device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t lane, uint32_t cross_idx) {
+  const uint32_t offer = (lane & 16u) ? ~lo : q;
+  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)cross_idx, (int)offer);
+  return half_allpairs(q, lo, xa, ~offer, lane);
 }
 
 // inclusive prefix sum inside each 32-lane half
@@ -678,25 +693,24 @@ __device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
   return v;
 }
 
-// prefix rebuild of one bitset per half: lane l (0..31) of a half owns words [l*items, (l+1)*items), items <= 8
-__device__ __forceinline__ void rebuild_prefix_half(unsigned long long* bits, uint16_t* pre, int Wp, int items,
-                                                    uint32_t l) {
-  const int base = (int)l * items;
-  uint32_t pc[8], local = 0;
+// prefix rebuild of one bitset per half: lane l (0..31) of a half owns words [l*HI, (l+1)*HI).  The arrays
+// of a half-wave kernel are padded to 32*HI words, so nothing is predicated; v_bcnt accumulates the running
+// count on its own.
+template <int HI>
+__device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bits, uint16_t* pre, uint32_t l) {
+  const uint32_t base = l * (uint32_t)HI;
+  uint32_t c[HI], run = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int w = base + i;
-    const unsigned long long v = (i < items && w < Wp) ? bits[w] : 0ull;
-    pc[i] = (uint32_t)__popcll(v);
-    local += pc[i];
+  for (int i = 0; i < HI; ++i) {
+    const unsigned long long v = bits[base + i];
+    run = (uint32_t)__builtin_popcount((uint32_t)v) + run;
+    run = (uint32_t)__builtin_popcount((uint32_t)(v >> 32)) + run;
+    c[i] = run;
   }
-  uint32_t run = half_incl_scan(local) - local;
+  const uint32_t excl = half_incl_scan(run) - run;
+  pre[base] = (uint16_t)excl;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int w = base + i;
-    if (i < items && w < Wp) pre[w] = (uint16_t)run;
-    run += pc[i];
-  }
+  for (int i = 1; i < HI; ++i) pre[base + i] = (uint16_t)(excl + c[i - 1]);
 }
 
 // state of one pair inside a wave
@@ -857,7 +871,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   return out;
 }
 
-template <int NP, bool PG, bool HALF>
+template <int NP, bool PG, int HI>
 __global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
@@ -880,11 +894,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const uint32_t lane = lane_id();
-  const int Wp4 = (Wp + 3) & ~3;
+  const int Wp4 = HI ? 32 * HI : ((Wp + 3) & ~3);             // LDS stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
-  const int items_h = (Wp + 31) >> 5;                       // words per lane when a half rebuilds a prefix
-  constexpr bool half_mode = HALF && (NP == 2);              // host guarantees items_h <= 8 for HALF kernels
+  constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
   uint32_t pk_ones = 0x00010001u;
   asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
@@ -980,18 +993,17 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
       uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
       const uint32_t l32 = lane & 31u;
+      const uint32_t cross_idx = half_cross_idx(lane);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const uint32_t r = sub ? rr1 : rr0;
         const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
         const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
-        const uint32_t up = (uint32_t)__shfl_up((int)qh, 16, 64);
-        const uint32_t q16 = (lane & 16u) ? up : 0xFFFFFFFFu;   // lower row of the half: nothing 16 lanes below
-        dis_half += cnt + half_allpairs(qh, q16, loh, lane);
+        dis_half += cnt + half_count(qh, loh, lane, cross_idx);
         wave_lds_fence();
         atomicOr(&seenH[qh >> 6], 1ull << (qh & 63u));
         wave_lds_fence();
-        rebuild_prefix_half(seenH, spreH, Wp, items_h, l32);
+        rebuild_prefix_half<(HI > 0 ? HI : 1)>(seenH, spreH, l32);
         wave_lds_fence();
       }
       continue;
@@ -1298,8 +1310,7 @@ __global__ void k_selftest(uint32_t* out) {
   out[128 + lane] = v;                                         // lanes < 41: ~0, else lane-41
   // half-wave pieces: q, lo from a fixed pseudo-random table; the host recomputes the counts
   const uint32_t q = (lane * 2654435761u >> 20) & 0xFFFu, lo = ((lane * 40503u + 977u) >> 3) & 0xFFFu;
-  const uint32_t up = (uint32_t)__shfl_up((int)q, 16, 64);
-  out[192 + lane] = half_allpairs(q, (lane & 16u) ? up : 0xFFFFFFFFu, lo, lane);
+  out[192 + lane] = half_count(q, lo, lane, half_cross_idx(lane));  // summed per half by the host
   const auto sw = __builtin_amdgcn_permlane32_swap(lane, 100u + lane, false, false);
   out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)
   out[320 + lane] = sw[1];                                     // lanes < 32: 32 + lane, else 100 + lane
@@ -1317,20 +1328,32 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
                         unsigned long long*, uint32_t*, int);
 
-// HALF (half-wave hot step) exists for two pairs per wave with pend in LDS; the host only asks for it when a
-// half can rebuild a prefix with <= 8 words per lane (n <= 16 320)
-static k1_fn_t k1_select(int np, bool pend_global, bool half) {
-  if (pend_global) return (np == 1) ? &k1_pairs<1, true, false> : (np == 2) ? &k1_pairs<2, true, false> : &k1_pairs<4, true, false>;
-  if (np == 2 && half) return &k1_pairs<2, false, true>;
-  return (np == 1) ? &k1_pairs<1, false, false> : (np == 2) ? &k1_pairs<2, false, false> : &k1_pairs<4, false, false>;
+// The half-wave hot step exists for two pairs per wave with pend in LDS, one kernel per half_items (1..8
+// words per lane in a half's prefix rebuild: n <= 2 040 * half_items)
+static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
+  if (pend_global) return (np == 1) ? &k1_pairs<1, true, 0> : (np == 2) ? &k1_pairs<2, true, 0> : &k1_pairs<4, true, 0>;
+  if (np == 2) {
+    switch (half_items) {
+      case 1: return &k1_pairs<2, false, 1>;
+      case 2: return &k1_pairs<2, false, 2>;
+      case 3: return &k1_pairs<2, false, 3>;
+      case 4: return &k1_pairs<2, false, 4>;
+      case 5: return &k1_pairs<2, false, 5>;
+      case 6: return &k1_pairs<2, false, 6>;
+      case 7: return &k1_pairs<2, false, 7>;
+      case 8: return &k1_pairs<2, false, 8>;
+      default: break;
+    }
+  }
+  return (np == 1) ? &k1_pairs<1, false, 0> : (np == 2) ? &k1_pairs<2, false, 0> : &k1_pairs<4, false, 0>;
 }
 
 hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
-                     const int32_t* pj, PairRaw* raw, int np, bool pend_global, int wpb, int blocks,
+                     const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
                      int opts, hipStream_t s) {
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
-  k1_fn_t fn = k1_select(np, pend_global, (opts & 1) != 0);
+  k1_fn_t fn = k1_select(np, pend_global, half_items);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -1340,8 +1363,8 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
 }
 
 // resident workgroups per CU of the pair kernel for a launch shape (occupancy query)
-hipError_t k1_blocks_per_cu(int np, bool pend_global, bool half, int wpb, size_t lds_bytes, int* out) {
-  k1_fn_t fn = k1_select(np, pend_global, half);
+hipError_t k1_blocks_per_cu(int np, bool pend_global, int half_items, int wpb, size_t lds_bytes, int* out) {
+  k1_fn_t fn = k1_select(np, pend_global, half_items);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;

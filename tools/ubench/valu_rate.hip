@@ -28,6 +28,14 @@
 #define G_MIX1  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_cmp_lt_u32_e32 vcc, %0, %4\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_add_u32 %3, %3, %2\n\t"
 #define G_MIXF  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_sub_f32_e64 %1, %4, %0 clamp\n\tv_add_f32 %2, %2, %1\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
 
+#define DPPR " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define G_ALIGN "v_alignbit_b32 %0, %0, %4, 31\n\tv_alignbit_b32 %1, %1, %4, 31\n\tv_alignbit_b32 %2, %2, %4, 31\n\tv_alignbit_b32 %3, %3, %4, 31\n\t"
+#define G_SUBDPP "v_sub_u32_dpp %0, %4, %5" DPPR "v_sub_u32_dpp %1, %4, %5" DPPR "v_sub_u32_dpp %2, %4, %5" DPPR "v_sub_u32_dpp %3, %4, %5" DPPR
+#define G_SUBCODPP "v_sub_co_u32_dpp %0, vcc, %4, %5" DPPR "v_sub_co_u32_dpp %1, vcc, %4, %5" DPPR "v_sub_co_u32_dpp %2, vcc, %4, %5" DPPR "v_sub_co_u32_dpp %3, vcc, %4, %5" DPPR
+#define G_MIXA "v_sub_co_u32_dpp %1, vcc, %4, %5" DPPR "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\tv_sub_co_u32_dpp %1, vcc, %4, %5" DPPR "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+#define G_MIXB "v_sub_u32_dpp %1, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\tv_sub_u32_dpp %1, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\t"
+#define G_MIXC "v_sub_u32_dpp %1, %4, %5" DPPR "v_sub_u32_dpp %2, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\tv_alignbit_b32 %3, %3, %2, 31\n\t"
+
 template <int V>
 __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
   uint32_t a = threadIdx.x, b = threadIdx.x * 3, c = threadIdx.x * 5, d = threadIdx.x * 7, e = 0x00010001u, f = 3;
@@ -37,6 +45,8 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
     else if (V == 4) RUN(G_MOV); else if (V == 5) RUN(G_CMP); else if (V == 6) RUN(G_ADDC); else if (V == 7) RUN(G_PKSUB);
     else if (V == 8) RUN(G_PKADD); else if (V == 9) RUN(G_CNDM); else if (V == 10) RUN(G_BCNT); else if (V == 11) RUN(G_SUBF);
     else if (V == 12) RUN(G_ADDF); else if (V == 13) RUN(G_ADDFDPP); else if (V == 14) RUN(G_MIX1); else if (V == 15) RUN(G_MIXF);
+    else if (V == 16) RUN(G_ALIGN); else if (V == 17) RUN(G_SUBDPP); else if (V == 18) RUN(G_SUBCODPP);
+    else if (V == 19) RUN(G_MIXA); else if (V == 20) RUN(G_MIXB); else if (V == 21) RUN(G_MIXC);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
 }
@@ -77,6 +87,12 @@ int main() {
   if (run<13>("v_add_f32_dpp", d)) return 1;
   if (run<14>("mix dpp/cmp/cndm/add", d)) return 1;
   if (run<15>("mix dpp/subf/addf/dpp", d)) return 1;
+  if (run<16>("v_alignbit_b32", d)) return 1;
+  if (run<17>("v_sub_u32_dpp row_shr", d)) return 1;
+  if (run<18>("v_sub_co_u32_dpp", d)) return 1;
+  if (run<19>("mix sub_co_dpp/addc", d)) return 1;
+  if (run<20>("mix sub_dpp/alignbit", d)) return 1;
+  if (run<21>("mix 2sub_dpp/2alignbit", d)) return 1;
   if (run<0>("v_fma_f32 (again)", d)) return 1;
   return 0;
 }

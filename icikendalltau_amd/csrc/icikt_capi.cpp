@@ -144,27 +144,28 @@ struct K1Plan {
   int perpair_bytes;
   int opts;          // bit 0: half-wave hot step (one pair per 32-lane half, 32-row sub-steps)
   int half_items;    // words per lane of a half-wave prefix rebuild (0: no half-wave step)
+  int stride;        // 64-bit words between a pair's LDS / pend arrays (k1_lds_stride)
 };
 
 K1Plan plan_k1(const PrepView& pv) {
   K1Plan pl{};
-  const int Wp4 = (pv.Wp + 3) & ~3;
   const size_t lds_cap = 160 * 1024;
-  const size_t full = (size_t)Wp4 * (8 + 8 + 2 + 2);  // seen, pend (u64) + spre, ppre (u16)
-  const size_t slim = ((size_t)Wp4 * (8 + 2) + 15) & ~(size_t)15;  // seen + spre only
-  // pend stays in LDS while two pairs per wave still leave 16 waves per CU (n <~ 16 000); beyond that the
-  // LDS state is what limits occupancy and pend moves to global memory (slower general steps)
-  pl.pend_global = full * 2 * 16 > lds_cap;
+  // n <= 10 176 (a half wave rebuilds a prefix with <= 5 words per lane): two pairs per wave, one per half,
+  // pend in LDS.  Longer columns: one pair per wave on all 64 lanes (measured crossover between n = 10 000 and
+  // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 20 waves per CU (n <~ 25 000), beyond
+  // that the LDS state is what limits occupancy and pend moves to a per-wave slot in global memory (slower
+  // steps when the streamed column has tie groups).
+  const bool half_ok = ((pv.Wp + 31) >> 5) <= icikt::ICIKT_HALF_ITEMS_MAX;
+  int np = half_ok ? 2 : 1;
+  {
+    const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2 + 2);  // seen, pend + spre, ppre
+    pl.pend_global = !half_ok && full * 20 > lds_cap;
+  }
   if (const char* e = getenv("ICIKT_K1_PEND")) pl.pend_global = (e[0] == 'g');
-  pl.perpair_bytes = (int)(pl.pend_global ? slim : full);
-  // two pairs per wave ride the packed-u16 all-pairs loop; one when that leaves fewer than 8 waves per CU
-  int np = ((size_t)pl.perpair_bytes * 2 * 8 <= lds_cap) ? 2 : 1;
-  if (pl.pend_global && (size_t)pl.perpair_bytes * 2 * 16 > lds_cap) np = 1;  // long columns: waves over packing
   if (const char* e = getenv("ICIKT_K1_NP")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) np = v;
   }
-  while (np > 1 && (size_t)pl.perpair_bytes * np > lds_cap) np >>= 1;
   int wpb = 4;
   if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
   pl.opts = 1;
@@ -173,11 +174,15 @@ K1Plan plan_k1(const PrepView& pv) {
   if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
-  // half-wave hot step: a half rebuilds a prefix with half_items <= 8 words per lane, unpredicated, so the
+  // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
   // LDS arrays of such a kernel are padded to 32 * half_items words
   pl.half_items = (pv.Wp + 31) >> 5;
-  if (np != 2 || pl.pend_global || pl.half_items > 8 || !(pl.opts & 1)) { pl.opts &= ~1; pl.half_items = 0; }
-  if (pl.half_items) pl.perpair_bytes = 32 * pl.half_items * (8 + 8 + 2 + 2);
+  if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) { pl.opts &= ~1; pl.half_items = 0; }
+  // final layout: the kernel derives the same stride from (Wp, half_items)
+  pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
+  pl.perpair_bytes = (int)(pl.pend_global ? (((size_t)pl.stride * (8 + 2) + 15) & ~(size_t)15)
+                                          : (size_t)pl.stride * (8 + 8 + 2 + 2));
+  while (np > 1 && (size_t)pl.perpair_bytes * np > lds_cap) np >>= 1;  // only reachable through the overrides
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
@@ -497,8 +502,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
               pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
               blocks, c->n_units);
     if (pl.pend_global) {
-      const int Wp4 = (c->pv.Wp + 3) & ~3;
-      const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * Wp4;
+      const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * pl.stride;
       if (pend_elems > c->d_pend_bits.cap) {
         HIPCHK(c, c->d_pend_bits.reserve(pend_elems));
         HIPCHK(c, c->d_pend_pre.reserve(pend_elems));

@@ -683,6 +683,73 @@ __device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t
   return half_allpairs(q, lo, xa, ~offer, lane);
 }
 
+// ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
+// Same construction as the half-wave step, for four DPP rows: 15 in-row compares (row_shr) and, for the six
+// row pairs, three rounds in which every row has one partner row (1: 0-1 2-3, 2: 0-2 1-3, 3: 0-3 1-2) and both
+// partners work, 8 compares per round: 39 compare + carry pairs per 64 rows instead of a 63-step shift chain.
+// In round c a lane of the later row reads the earlier row's q at its own position, a lane of the earlier row
+// the later row's ~lo one position to the left (wave_cross_idx), through ds_bpermute.
+__device__ __forceinline__ uint32_t wave_cross_idx(uint32_t lane, uint32_t c) {
+  const uint32_t later = (c == 1u) ? (lane & 16u) : (lane & 32u);
+  const uint32_t prow = (lane ^ (c << 4)) & 48u;
+  return (prow | ((later ? lane : lane - 1u) & 15u)) << 2;
+}
+#define ICIKT_WROR(b, xa, xb) "v_sub_co_u32_dpp %1, vcc, " xa ", " xb " row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
+                              "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+#define ICIKT_WROUND(xa, xb)                                                                  \
+  "v_cmp_lt_u32_e32 vcc, " xa ", " xb "\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"        \
+  ICIKT_WROR(1, xa, xb) ICIKT_WROR(2, xa, xb) ICIKT_WROR(3, xa, xb) ICIKT_WROR(4, xa, xb)     \
+  ICIKT_WROR(5, xa, xb) ICIKT_WROR(6, xa, xb) ICIKT_WROR(7, xa, xb)
+// per-lane share of #{rows a before row j in the step : q_a < lo_j}; only the sum over the wave is meaningful
+__device__ __forceinline__ uint32_t wave_allpairs(uint32_t q, uint32_t lo, uint32_t lane) {
+  const uint32_t nlo = ~lo;
+  const uint32_t off1 = (lane & 16u) ? nlo : q;   // round 1: rows 1, 3 are the later ones
+  const uint32_t off2 = (lane & 32u) ? nlo : q;   // rounds 2, 3: rows 2, 3
+  const uint32_t xa1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 1u), (int)off1);
+  const uint32_t xa2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 2u), (int)off2);
+  const uint32_t xa3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 3u), (int)off2);
+  const uint32_t xb1 = ~off1, xb2 = ~off2;
+  uint32_t acc = 0, junk;
+  asm volatile("s_nop 1\n\t"
+               ICIKT_HSHR(1) ICIKT_HSHR(2) ICIKT_HSHR(3) ICIKT_HSHR(4) ICIKT_HSHR(5) ICIKT_HSHR(6) ICIKT_HSHR(7)
+               ICIKT_HSHR(8) ICIKT_HSHR(9) ICIKT_HSHR(10) ICIKT_HSHR(11) ICIKT_HSHR(12) ICIKT_HSHR(13)
+               ICIKT_HSHR(14) ICIKT_HSHR(15)
+               ICIKT_WROUND("%4", "%5") ICIKT_WROUND("%6", "%7") ICIKT_WROUND("%8", "%7")
+               : "+v"(acc), "=&v"(junk)
+               : "v"(q), "v"(lo), "v"(xa1), "v"(xb1), "v"(xa2), "v"(xb2), "v"(xa3)
+               : "vcc");
+  return acc - ((lo != 0u) ? (15u - (lane & 15u)) : 0u);
+}
+
+// Prefix rebuild for long columns (more than 4 words per lane; arrays padded to 64 * items2 words, items2
+// even: k1_lds_stride): lane l owns words [l*items2, (l+1)*items2).  Pass 1 reads two words at a time and
+// stores the lane-local exclusive counts of both as one dword; after the wave scan pass 2 adds the lane's
+// base to both halves of every dword with one LDS add (no carry between the halves: every count <= n < 2^16).
+__device__ __forceinline__ void rebuild_prefix_long(const unsigned long long* bits, uint16_t* pre, int items2,
+                                                    uint32_t lane) {
+  const uint32_t base = lane * (uint32_t)items2;
+  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(bits + base);
+  uint32_t* p32 = reinterpret_cast<uint32_t*>(pre + base);
+  const int it = items2 >> 1;
+  uint32_t run = 0;
+#pragma unroll 2
+  for (int i = 0; i < it; ++i) {
+    const ulonglong2 v = b2[i];
+    const uint32_t c0 = run;
+    run = (uint32_t)__builtin_popcount((uint32_t)v.x) + run;
+    run = (uint32_t)__builtin_popcount((uint32_t)(v.x >> 32)) + run;
+    const uint32_t c1 = run;
+    run = (uint32_t)__builtin_popcount((uint32_t)v.y) + run;
+    run = (uint32_t)__builtin_popcount((uint32_t)(v.y >> 32)) + run;
+    p32[i] = c0 | (c1 << 16);
+  }
+  const uint32_t excl = wave_incl_scan(run) - run;
+  const uint32_t add = excl | (excl << 16);
+  wave_lds_fence();
+#pragma unroll 2
+  for (int i = 0; i < it; ++i) atomicAdd(&p32[i], add);
+}
+
 // inclusive prefix sum inside each 32-lane half
 __device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
@@ -771,8 +838,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   // (2) pairs inside this step
   if (F == ~0ull) {
     // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
-    const uint32_t c2 = s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q), lo);
-    S.dis += c2;
+    S.dis += wave_allpairs(q, lo, lane);
   } else if (F != 0ull) {
     // mixed step: xg = group ordinal inside the step; rows tied in the streamed column are not
     // discordant, and rows tied in both columns are joint ties
@@ -894,7 +960,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const uint32_t lane = lane_id();
-  const int Wp4 = HI ? 32 * HI : ((Wp + 3) & ~3);             // LDS stride of the per-pair arrays (host: plan_k1)
+  const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
@@ -1032,7 +1098,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       for (int k = 0; k < NP; ++k)
         S[k].dis += pre[k] + (uint32_t)__popcll(wv[k] & low_mask64(lo[k] & 63u));
       if (NP == 1) {
-        S[0].dis += s1_allpairs(dpp_wave_shr1(0xFFFFFFFFu, q[0]), lo[0]);
+        S[0].dis += wave_allpairs(q[0], lo[0], lane);
       } else {
 #pragma unroll
         for (int k = 0; k + 1 < NP; k += 2) {
@@ -1056,7 +1122,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
         rebuild_prefix_hot<NP>(Ls, Wp, items, lane);
       } else {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) rebuild_prefix<PG>(S[k].L.seen, S[k].L.spre, nullptr, Wp, items, lane);
+        for (int k = 0; k < NP; ++k) rebuild_prefix_long(S[k].L.seen, S[k].L.spre, (items + 1) & ~1, lane);
       }
       wave_lds_fence();
       continue;
@@ -1328,8 +1394,8 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
                         unsigned long long*, uint32_t*, int);
 
-// The half-wave hot step exists for two pairs per wave with pend in LDS, one kernel per half_items (1..8
-// words per lane in a half's prefix rebuild: n <= 2 040 * half_items)
+// The half-wave hot step exists for two pairs per wave with pend in LDS, one kernel per half_items
+// (1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild: n <= 2 040 * half_items - 24)
 static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
   if (pend_global) return (np == 1) ? &k1_pairs<1, true, 0> : (np == 2) ? &k1_pairs<2, true, 0> : &k1_pairs<4, true, 0>;
   if (np == 2) {
@@ -1339,9 +1405,6 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       case 3: return &k1_pairs<2, false, 3>;
       case 4: return &k1_pairs<2, false, 4>;
       case 5: return &k1_pairs<2, false, 5>;
-      case 6: return &k1_pairs<2, false, 6>;
-      case 7: return &k1_pairs<2, false, 7>;
-      case 8: return &k1_pairs<2, false, 8>;
       default: break;
     }
   }

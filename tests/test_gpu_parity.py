@@ -272,6 +272,20 @@ def test_long_columns_generic_rebuild(hip_ctx):
         _check(hip_ctx, X, perspective=p)
 
 
+@pytest.mark.parametrize("n", [10177, 10300, 16321, 17000, 21000, 24900, 26000, 41000])
+def test_one_pair_per_wave_plans(hip_ctx, n):
+    """Column lengths on either side of every K1 plan boundary above the half-wave range: one pair per wave
+    with the four-row all-pairs step, <= 4 and > 4 bitset words per lane (two-words-at-a-time rebuild with
+    padded arrays), pend in LDS and in global memory; continuous, tied and half-missing columns."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 4))
+    X[rng.random(X.shape) < 0.04] = np.nan
+    X[:, 1] = np.round(X[:, 1] * 4)            # ~30 distinct values: tie groups spanning many steps
+    X[:, 3] = np.where(rng.random(n) < 0.5, np.nan, 0.5 * X[:, 0] + X[:, 3])
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+
+
 def test_max_length_65535(hip_ctx):
     rng = np.random.default_rng(47)
     n = 65535

@@ -1,0 +1,32 @@
+"""K1 throughput against column length for the default plan and for forced plans (development aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from icikendalltau_amd import _lib
+from bench import make_matrix
+
+ns = [int(a) for a in sys.argv[1:]] or [2000, 5000, 10000, 16000, 17000, 25000, 26000, 40000, 65535]
+variants = [dict(), dict(ICIKT_K1_NP="1"), dict(ICIKT_K1_NP="1", ICIKT_K1_PEND="g"), dict(ICIKT_K1_NP="1", ICIKT_K1_PEND="l")]
+ctx = _lib.Context(0)
+for n in ns:
+    S = 512
+    X = make_matrix(n, S, max(1, n // 50), 5)
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    P = min(S * (S - 1) // 2, max(20000, int(6e8 / n)))
+    ctx.set_pairs_combn(S, 0, P)
+    out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
+    ctx.prepare_dev(dX.data_ptr(), n, S, n, _lib.FLAG_TIMING); ctx.sync()
+    line = [f"n={n:6d} K0/col {ctx.kernel_ms(_lib.K_PREPARE)[0] / S * 1e3:6.1f} us"]
+    ref = None
+    for v in variants:
+        for k in ("ICIKT_K1_PEND", "ICIKT_K1_NP"): os.environ.pop(k, None)
+        os.environ.update(v)
+        ts = []
+        for _ in range(3):
+            ctx.reset_timers(); ctx.run_dev(1, 0, False, _lib.FLAG_TIMING, out.data_ptr()); ctx.sync()
+            ts.append(ctx.kernel_ms(_lib.K_PAIRS)[0])
+        o = out.cpu().numpy()
+        if ref is None: ref = o.copy()
+        tag = "default" if not v else "np" + v["ICIKT_K1_NP"] + v.get("ICIKT_K1_PEND", "")
+        line.append(f"{tag} {P / (min(ts) / 1e3):.3e}{'' if np.array_equal(o, ref, equal_nan=True) else ' DIFF'}")
+    print("  ".join(line), flush=True)

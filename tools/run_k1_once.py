@@ -1,14 +1,17 @@
-"""One prepare + a few K1 launches of the c4 workload (for rocprofv3 counter passes)."""
+"""One prepare + a few K1 launches (default: the c4 workload; N_FEAT / N_SAMP / MAX_PAIRS override) for
+rocprofv3 counter passes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from icikendalltau_amd import _lib
 from bench import make_matrix
-n, S, na, seed = 10000, 1024, 1000, 4
+n = int(os.environ.get("N_FEAT", "10000"))
+S = int(os.environ.get("N_SAMP", "1024"))
+na, seed = n // 10, 4
 X = make_matrix(n, S, na, seed)
 ctx = _lib.Context(0)
 dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
-P = S * (S - 1) // 2
+P = min(S * (S - 1) // 2, int(os.environ.get("MAX_PAIRS", "1000000000")))
 ctx.set_pairs_combn(S, 0, P)
 out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
 ctx.prepare_dev(dX.data_ptr(), n, S, n, 0); ctx.sync()

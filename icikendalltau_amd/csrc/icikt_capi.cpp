@@ -137,7 +137,7 @@ int timer_end(icikt_ctx* c, int k, uint32_t flags) {
 
 // launch plan of the pair kernel for a given n
 struct K1Plan {
-  int np;            // pairs per wave (1, 2 or 4): consecutive pairs with the same pi (the gathered column)
+  int np;            // pairs per wave: 2 (one per half, consecutive pairs with the same pi) or 1
   bool pend_global;  // open-group bitset in global memory (long columns) instead of LDS
   int wpb;           // waves per workgroup
   size_t lds_bytes;
@@ -162,9 +162,10 @@ K1Plan plan_k1(const PrepView& pv) {
     pl.pend_global = !half_ok && full * 20 > lds_cap;
   }
   if (const char* e = getenv("ICIKT_K1_PEND")) pl.pend_global = (e[0] == 'g');
+  // overrides for experiments and tests; a plan without a kernel variant falls back to one pair per wave
   if (const char* e = getenv("ICIKT_K1_NP")) {
     const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) np = v;
+    if (v == 1 || (v == 2 && half_ok)) np = v;
   }
   int wpb = 4;
   if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
@@ -177,12 +178,15 @@ K1Plan plan_k1(const PrepView& pv) {
   // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
   // LDS arrays of such a kernel are padded to 32 * half_items words
   pl.half_items = (pv.Wp + 31) >> 5;
-  if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) { pl.opts &= ~1; pl.half_items = 0; }
+  if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) {
+    pl.opts &= ~1;
+    pl.half_items = 0;
+    np = 1;
+  }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
   pl.perpair_bytes = (int)(pl.pend_global ? (((size_t)pl.stride * (8 + 2) + 15) & ~(size_t)15)
                                           : (size_t)pl.stride * (8 + 8 + 2 + 2));
-  while (np > 1 && (size_t)pl.perpair_bytes * np > lds_cap) np >>= 1;  // only reachable through the overrides
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);

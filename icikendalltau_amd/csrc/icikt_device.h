@@ -59,16 +59,14 @@ struct PrepView {
 // half-wave K1 kernels exist for 1..ICIKT_HALF_ITEMS_MAX words per lane of a half's prefix rebuild (n <= 10 176)
 constexpr int ICIKT_HALF_ITEMS_MAX = 5;
 
-// Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan:
-//  * half-wave kernels: 32 * half_items, so that a half rebuilds its prefix without predicates;
-//  * more than 4 words per lane: 64 * (words per lane rounded up to even), for the two-words-at-a-time
-//    rebuild of long columns;
-//  * else Wp rounded up to 4.
+// Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan.  The
+// arrays are padded so that the hot steps' prefix rebuilds run without predicates:
+//  * half-wave kernels: 32 lanes x half_items words;
+//  * one pair per wave: 64 lanes x (words per lane rounded up to even; two words are read at a time).
 __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
   if (half_items > 0) return 32 * half_items;
   const int items = (Wp + 63) >> 6;
-  if (items > 4) return 64 * ((items + 1) & ~1);
-  return (Wp + 3) & ~3;
+  return 64 * ((items + 1) & ~1);
 }
 
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);

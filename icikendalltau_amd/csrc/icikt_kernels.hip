@@ -384,20 +384,21 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: NP column pairs per wavefront (they share the gathered column; each streams its own)
+// K1: column pairs on wavefronts -- one pair per wave, or two (one per 32-lane half, sharing the gathered
+// column, each streaming its own)
 // ------------------------------------------------------------------------------------------------
 // Column B (= the pairs' common pi) is the random-access side: rec[row] = q | lo << 16, q = the row's
 // position in B's ascending stable order (unique), lo = first position of its tie group.
 // Columns A_0..A_{NP-1} (= pj of the task's pairs) are the streamed side: order[k] = row at position k
 // of A's DESCENDING order, gflag bit k = "position k starts a new tie group of A".
 //
-// The wave walks A from the largest value down, 64 positions per step (one row per lane), and keeps
-// per pair in LDS
+// The wave walks A from the largest value down, 64 positions per step, and keeps per pair in LDS
 //   seen : bitset over B-positions of every row whose A-group is strictly above the current one
 //   spre : per-64-bit-word exclusive prefix popcounts of seen
 // so that   #{rows j : a_j > a_l, b_j < b_l} = spre[lo_l >> 6] + popc(seen[lo_l >> 6] & below(lo_l)).
-// Rows of the SAME step are compared all-pairs with 63 whole-wave DPP shifts; two pairs ride in one
-// register as packed u16 (v_pk_sub_u16 clamp / v_pk_min_u16 / v_pk_add_u16), 4 VALU per shift for 2 pairs.
+// Rows that enter `seen` together are compared all-pairs in registers: DPP shifts inside a 16-lane row and
+// balanced rotations between rows (wave_allpairs: 64 rows of one pair; half_allpairs: 32 rows of each of
+// two pairs), one v_sub_co_u32_dpp + v_addc_co_u32 per compare.
 // Rows of an A tie group that is still open wait in `pend` (prefix ppre) and are merged when the group
 // closes; pend also yields the joint ties (compare_both, kendallc.cpp:33-51) of groups spanning steps.
 struct WaveLds {
@@ -453,98 +454,6 @@ template <bool PG> __device__ __forceinline__ void p_stpre(const PendG& P, int w
 template <bool PG> __device__ __forceinline__ void wave_pend_fence() {
   if (PG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-}
-
-// In-step all-pairs loop for TWO pairs packed as u16 halves of one register.  One step is
-//   qs  = whole-wave shift right by one lane of qs (lane 0 keeps its value)
-//   acc.half += (qs.half < lo.half) ? 1 : 0      as  acc += min(sat_sub(lo, qs), 1)
-// All 62 in-place steps are ONE inline-asm statement because (a) from the equivalent C++ hipcc builds
-// each packed result out of two v_cmp, two v_cndmask and a v_perm, (b) with the DPP move inside the
-// statement the three packed ops of a step cover the two wait states a DPP needs after a VALU write
-// of its source (the first in-place DPP is likewise three instructions behind the out-of-place shift
-// that produced qs_first), and (c) hipcc pads every asm statement boundary with an s_nop.
-#define ICIKT_PKSTEP                                                      \
-  "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"        \
-  "v_pk_sub_u16 %2, %3, %0 clamp\n\t"                                     \
-  "v_pk_min_u16 %2, %2, %4\n\t"                                           \
-  "v_pk_add_u16 %1, %1, %2\n\t"
-#define ICIKT_PKSTEP2 ICIKT_PKSTEP ICIKT_PKSTEP
-#define ICIKT_PKSTEP4 ICIKT_PKSTEP2 ICIKT_PKSTEP2
-#define ICIKT_PKSTEP8 ICIKT_PKSTEP4 ICIKT_PKSTEP4
-#define ICIKT_PKSTEP16 ICIKT_PKSTEP8 ICIKT_PKSTEP8
-#define ICIKT_PKSTEP32 ICIKT_PKSTEP16 ICIKT_PKSTEP16
-#define ICIKT_PKSTEP62 ICIKT_PKSTEP32 ICIKT_PKSTEP16 ICIKT_PKSTEP8 ICIKT_PKSTEP4 ICIKT_PKSTEP2
-
-// qs_first = the packed q's already shifted by one lane (lane 0 = 0xFFFF|0xFFFF, "never below").
-// Returns the packed per-lane counts over all 63 shift distances.
-__device__ __forceinline__ uint32_t pk_allpairs(uint32_t qs_first, uint32_t lop, uint32_t ones) {
-  uint32_t qs = qs_first, acc = 0, d;
-  asm volatile("v_pk_sub_u16 %2, %3, %0 clamp\n\t"
-               "v_pk_min_u16 %2, %2, %4\n\t"
-               "v_pk_add_u16 %1, %1, %2\n\t"
-               ICIKT_PKSTEP62
-               : "+v"(qs), "+v"(acc), "=&v"(d)
-               : "v"(lop), "v"(ones));
-  return acc;
-}
-
-// The same loop for ONE pair, left to hipcc (cmp / cndmask / addc with two interleaved accumulator
-// updates): inside the kernel it measured 16 % faster than a hand-written 3-instruction chain.
-__device__ __forceinline__ uint32_t s1_allpairs(uint32_t qs_first, uint32_t lo) {
-  uint32_t qs = qs_first;
-  uint32_t c2 = (qs < lo) ? 1u : 0u;
-#pragma unroll
-  for (int s = 2; s < 64; ++s) {
-    qs = dpp_wave_shr1(qs, qs);
-    c2 += (qs < lo) ? 1u : 0u;
-  }
-  return c2;
-}
-
-// Hot-step prefix rebuild for NP bitsets at once (items <= 4 words per lane): all LDS reads are issued
-// before the first wait, and two pairs share one DPP scan as packed u16 running counts (each <= n <= 65535,
-// so the halves never carry into each other).
-template <int NP>
-__device__ __forceinline__ void rebuild_prefix_hot(const WaveLds* L, int Wp, int items, uint32_t lane) {
-  const int base = (int)lane * items;
-  unsigned long long v[NP][4];
-#pragma unroll
-  for (int k = 0; k < NP; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = base + i;
-      v[k][i] = (i < items && w < Wp) ? L[k].seen[w] : 0ull;
-    }
-  uint32_t pc[NP][4], local[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    local[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      pc[k][i] = (uint32_t)__popcll(v[k][i]);
-      local[k] += pc[k][i];
-    }
-  }
-  uint32_t run[NP];
-  if (NP == 1) {
-    run[0] = wave_incl_scan(local[0]) - local[0];
-  } else {
-#pragma unroll
-    for (int k = 0; k + 1 < NP; k += 2) {
-      const uint32_t lp = local[k] | (local[k + 1] << 16);
-      const uint32_t ex = wave_incl_scan(lp) - lp;
-      run[k] = ex & 0xFFFFu;
-      run[k + 1] = ex >> 16;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NP; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = base + i;
-      if (i < items && w < Wp) L[k].spre[w] = (uint16_t)run[k];
-      run[k] += pc[k][i];
-    }
 }
 
 // prefix popcounts of bits[0..Wp) (LDS); optionally first merges the pend bitset merge_from into bits
@@ -937,6 +846,8 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   return out;
 }
 
+// Variants: <1, PG, 0> one pair per wave (any n; PG = pend in global memory) and <2, false, HI> two pairs per
+// wave, one per half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild.
 template <int NP, bool PG, int HI>
 __global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
 k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
@@ -963,10 +874,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
   const int nb = (n + 63) >> 6;
+  static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
-  uint32_t pk_ones = 0x00010001u;
-  asm volatile("" : "+v"(pk_ones));  // keep it in a VGPR (VOP3P takes no 32-bit literal)
 
   // persistent waves: the grid is sized to the chip and each wave walks the task list with stride nwaves;
   // the kernel has no workgroup barrier, so the waves of a workgroup run independently
@@ -1076,54 +986,17 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     }
 
     if (!half_mode && all_fast) {
-      // ---- hot step: in every pair of the wave all 64 rows are valid, each row is its own tie group
-      //      of the streamed column, and no group stays open: gather, count, insert into `seen`.
-      //      Loads of all pairs are issued before the first use. ------------------------------------
-      uint32_t r[NP];
-#pragma unroll
-      for (int k = 0; k < NP; ++k) r[k] = gload_u32(recG, row[k]);
-      // prefetch the next step's rows behind the gathers (order[] is zero-padded by one step)
-#pragma unroll
-      for (int k = 0; k < NP; ++k) S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
-      uint32_t pre[NP];
-      unsigned long long wv[NP];
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        q[k] = r[k] & 0xFFFFu;
-        lo[k] = r[k] >> 16;
-        pre[k] = S[k].L.spre[lo[k] >> 6];
-        wv[k] = S[k].L.seen[lo[k] >> 6];
-      }
-#pragma unroll
-      for (int k = 0; k < NP; ++k)
-        S[k].dis += pre[k] + (uint32_t)__popcll(wv[k] & low_mask64(lo[k] & 63u));
-      if (NP == 1) {
-        S[0].dis += wave_allpairs(q[0], lo[0], lane);
-      } else {
-#pragma unroll
-        for (int k = 0; k + 1 < NP; k += 2) {
-          const uint32_t qp = q[k] | (q[k + 1] << 16);
-          const uint32_t lp = lo[k] | (lo[k + 1] << 16);
-          // lane 0 is set to the "never below" value by this first (out-of-place) shift and then
-          // keeps it: a lane that has run out of earlier rows counts nothing
-          const uint32_t cu = pk_allpairs(dpp_wave_shr1(0xFFFFFFFFu, qp), lp, pk_ones);
-          S[k].dis += cu & 0xFFFFu;
-          S[k + 1].dis += cu >> 16;
-        }
-      }
+      // ---- hot step, one pair on the whole wave: all 64 rows are valid, each row is its own tie group of
+      //      the streamed column, and no group stays open: gather, count, insert into `seen`. -----------
+      const uint32_t r = gload_u32(recG, row[0]);
+      // prefetch the next step's rows behind the gather (order[] is zero-padded by one step)
+      S[0].row_next = gload_u16(S[0].ord, (uint32_t)(kpos + 64));
+      const uint32_t q0 = r & 0xFFFFu, lo0 = r >> 16;
+      S[0].dis += prefix_query(S[0].L.seen, S[0].L.spre, lo0) + wave_allpairs(q0, lo0, lane);
       wave_lds_fence();
-#pragma unroll
-      for (int k = 0; k < NP; ++k) atomicOr(&S[k].L.seen[q[k] >> 6], 1ull << (q[k] & 63u));
+      atomicOr(&S[0].L.seen[q0 >> 6], 1ull << (q0 & 63u));
       wave_lds_fence();
-      if (items <= 4) {
-        WaveLds Ls[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) Ls[k] = S[k].L;
-        rebuild_prefix_hot<NP>(Ls, Wp, items, lane);
-      } else {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rebuild_prefix_long(S[k].L.seen, S[k].L.spre, (items + 1) & ~1, lane);
-      }
+      rebuild_prefix_long(S[0].L.seen, S[0].L.spre, (items + 1) & ~1, lane);
       wave_lds_fence();
       continue;
     }
@@ -1397,8 +1270,7 @@ typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int
 // The half-wave hot step exists for two pairs per wave with pend in LDS, one kernel per half_items
 // (1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild: n <= 2 040 * half_items - 24)
 static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
-  if (pend_global) return (np == 1) ? &k1_pairs<1, true, 0> : (np == 2) ? &k1_pairs<2, true, 0> : &k1_pairs<4, true, 0>;
-  if (np == 2) {
+  if (np == 2 && !pend_global) {
     switch (half_items) {
       case 1: return &k1_pairs<2, false, 1>;
       case 2: return &k1_pairs<2, false, 2>;
@@ -1408,7 +1280,8 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       default: break;
     }
   }
-  return (np == 1) ? &k1_pairs<1, false, 0> : (np == 2) ? &k1_pairs<2, false, 0> : &k1_pairs<4, false, 0>;
+  if (np != 1) return nullptr;
+  return pend_global ? &k1_pairs<1, true, 0> : &k1_pairs<1, false, 0>;
 }
 
 hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
@@ -1417,6 +1290,7 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
                      int opts, hipStream_t s) {
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
   k1_fn_t fn = k1_select(np, pend_global, half_items);
+  if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -1428,6 +1302,7 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
 // resident workgroups per CU of the pair kernel for a launch shape (occupancy query)
 hipError_t k1_blocks_per_cu(int np, bool pend_global, int half_items, int wpb, size_t lds_bytes, int* out) {
   k1_fn_t fn = k1_select(np, pend_global, half_items);
+  if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;

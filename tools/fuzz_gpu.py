@@ -71,7 +71,7 @@ def one_case(ctx, rng, case):
     if rng.random() < 0.3 and S > 2:  # correlated columns: shared rows missing, shared ties
         X[:, 1] = np.where(rng.random(n) < 0.7, X[:, 0], X[:, 1])
     env = {
-        "ICIKT_K1_NP": rng.choice(["", "1", "2", "4"]),
+        "ICIKT_K1_NP": rng.choice(["", "1", "2"]),
         "ICIKT_K1_PEND": rng.choice(["", "lds", "global"]),
         "ICIKT_K1_HALF": rng.choice(["", "0", "1"]),
         "ICIKT_K1_TGMAX": rng.choice(["", "-1", "2", "1000000"]),

@@ -27,7 +27,7 @@ if stats:
     shutil.copy(stats[0], os.path.join(out, f"{a.tag}_kernel_stats.csv"))
 
 means = collections.defaultdict(dict)
-for d in ("prof_fetch", "prof_write", "prof_sq"):
+for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2", "prof_ta", "prof_tcp", "prof_tcc"):
     for f in glob.glob(os.path.join(a.src, d, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         meta = {}

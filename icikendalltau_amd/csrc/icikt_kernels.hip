@@ -46,6 +46,11 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
 
 // Orders this wave's LDS traffic for the compiler: lanes of one wave exchange data through LDS
 // (atomic OR by one lane, read by another).  The hardware keeps one wave's DS operations in order;
@@ -727,8 +732,8 @@ __device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint
 template <bool PG>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
-                                                               const bool Fn, const bool valid, const uint32_t row,
-                                                               const uint32_t q, const uint32_t lo,
+                                                               const bool Fn, const bool valid, const bool tailrow,
+                                                               const uint32_t row, const uint32_t q, const uint32_t lo,
                                                                const uint16_t* hiG, const uint32_t* tg, const int ntg,
                                                                const int Wp, const int items,
                                                                const uint32_t lane) {
@@ -737,6 +742,8 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   //     closes, each tie group of B contributes C(rows of the group inside it, 2).  A step inside the
   //     missing-value group of A then costs one query and one atomic OR.
   //   row mode (ntg < 0): every row asks pend how many earlier rows of its A group share its B group.
+  // tailrow: the row belongs to A's LAST tie group and the task counts that group's discordant pairs in
+  // closed form (k1_pairs): its rows add nothing to dis here.
   const bool list = ntg >= 0;
   StepAcc S;
   S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
@@ -747,7 +754,8 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   // (2) pairs inside this step
   if (F == ~0ull) {
     // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
-    S.dis += wave_allpairs(q, lo, lane);
+    // (a tail row can only be the last lane here; as a target with lo = 0 it counts nothing)
+    S.dis += wave_allpairs(q, tailrow ? 0u : lo, lane);
   } else if (F != 0ull) {
     // mixed step: xg = group ordinal inside the step; rows tied in the streamed column are not
     // discordant, and rows tied in both columns are joint ties
@@ -765,7 +773,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
       xs = dpp_wave_shr1(xs, xs);
       ls = dpp_wave_shr1(ls, ls);
     }
-    S.dis += valid ? c2 : 0u;
+    S.dis += (valid && !tailrow) ? c2 : 0u;
     // list mode: groups that pass through pend are counted when they close, not here
     const bool counted_here = list ? (valid && !olane && (Fn || !tlane)) : valid;
     S.tie += counted_here ? c3 : 0u;
@@ -782,7 +790,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
         pend_rebuild<PG>(Pg, Wp, items, lane);
         wave_pend_fence<PG>();
         wave_lds_fence();
-        if (valid && !olane) S.dis += pend_query<PG>(Pg, lo);
+        if (valid && !olane && !tailrow) S.dis += pend_query<PG>(Pg, lo);
       }
     } else if (olane) {
       // joint ties with the group's rows of earlier steps
@@ -939,8 +947,38 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     S[k].row_next = gload_u16(S[k].ord, lane);
   }
 
+  // The LAST tie group of a streamed column (on data with missing values: the fill group) in closed form.
+  // Every row outside it is above it, so for a row r of the group
+  //   #{j above : b_j < b_r} = lo_r - #{j in the group : b_j < b_r},
+  // and summed over the group:  sum(lo_r) - (C(m, 2) - T),  m = rows of the group, T = its joint ties.
+  // Steps that lie entirely inside the group then only gather, add lo and (for T) collect the rows in pend.
+  // Used in list mode when at least one step lies entirely inside the group; last_start = the group's first
+  // position (rows at or after it add lo instead of their counts).
+  // It is used when that holds for every pair of the wave; the step loop then ends at t_main (the first step
+  // inside the last group of all pairs) and a gather-only loop runs the rest.
+  int last_start[NP];
+  int t_main = 0;
+  bool closed_form = ntgB >= 0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    int best = 0;
+    for (int w = lane; w < W; w += 64) {
+      unsigned long long f = S[k].gf[w];
+      if (w == W - 1 && (n & 63)) f &= (1ull << (n & 63)) - 1ull;
+      if (f != 0ull) best = max(best, w * 64 + 63 - (int)__builtin_clzll(f));
+    }
+    last_start[k] = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
+    closed_form = closed_form && ((last_start[k] >> 6) + 1 <= nb - 1);
+    t_main = max(t_main, (last_start[k] >> 6) + 1);
+  }
+  if (!closed_form) {
+    t_main = nb;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) last_start[k] = 0x7FFFFFFF;
+  }
+
   uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
-  for (int t = 0; t < nb; ++t) {
+  for (int t = 0; t < t_main; ++t) {
     const int kpos = t * 64 + (int)lane;
     const bool valid = kpos < n;
     unsigned long long F[NP];
@@ -1010,18 +1048,51 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
       // (1) rows of strictly higher groups of the streamed column that are already in `seen`
       const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
-      S[k].dis += valid ? cnt : 0u;
+      S[k].dis += valid ? ((kpos >= last_start[k]) ? lo[k] : cnt) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, row[k], q[k], lo[k], hiG, tgB, ntgB, Wp, items, lane);
+      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, valid && kpos >= last_start[k], row[k],
+                                              q[k], lo[k], hiG, tgB, ntgB, Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
+    }
+  }
+
+  // steps entirely inside the last tie group of every pair's streamed column: gather, add lo, collect in pend;
+  // then the group's joint ties T from pend and the correction C(m, 2) - T of the summed lo's
+  unsigned long long corr[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) corr[k] = 0ull;
+  if (closed_form) {
+    for (int t = t_main; t < nb; ++t) {
+      const int kpos = t * 64 + (int)lane;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const uint32_t r = gload_u32(recG, S[k].row_next);
+        S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
+        if (kpos < n) {
+          S[k].dis += r >> 16;
+          if (ntgB > 0) p_or<PG>(Pg[k], (int)((r & 0xFFFFu) >> 6), 1ull << (r & 63u));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t tl = (ntgB > 0) ? close_group_ties<PG>(Pg[k], tgB, ntgB, Wp, items, lane) : 0u;
+      S[k].tie += tl;
+      const unsigned long long m = (unsigned long long)(n - last_start[k]);
+      corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
+      if (PG) {  // a global pend slot is left all zero for the next task
+        wave_pend_fence<PG>();
+        for (int w = lane; w < Wp; w += 64) p_st<PG>(Pg[k], w, 0ull);
+        wave_pend_fence<PG>();
+      }
     }
   }
 
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const unsigned long long dis = wave_sum_u64(S[k].dis + (((lane >= 32u) == (k == NP - 1 && NP == 2)) ? dis_half : 0u));
+    const unsigned long long dis = wave_sum_u64(S[k].dis + (((lane >= 32u) == (k == NP - 1 && NP == 2)) ? dis_half : 0u)) - corr[k];
     const unsigned long long ntie = wave_sum_u64(S[k].tie) + (wave_sum_u64(S[k].tie2) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);
     const unsigned long long ggs = wave_sum_u64(gg[k]);

@@ -562,7 +562,7 @@ __device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, 
 //    upper row's ~lo rotated by one position), xb = what the lane compares with (upper: lo, lower: ~q); with
 //    row_ror:0..7 (lane p reads p - r) the upper lanes cover (lower - upper) mod 16 in {0, 15, .., 9} and
 //    the lower lanes {1, .., 8}.
-// 23 subtract-with-borrow + 23 add-with-carry per 32 rows of a pair, against 63 x 2 per 64 rows in the packed loop.
+// 23 subtract-with-borrow + 23 add-with-carry per 32 rows of a pair.
 #define ICIKT_HSHR(b) "v_sub_co_u32_dpp %1, vcc, %2, %3 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
                       "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
 #define ICIKT_HROR(b) "v_sub_co_u32_dpp %1, vcc, %4, %5 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \

@@ -109,6 +109,47 @@ __device__ T block_reduce(T v, T* scratch, Op op) {
   return r;
 }
 
+// ---- bitonic stages held in registers ---------------------------------------------------------------
+// With a full tile (4096 elements, 1024 threads) thread t owns elements 4t..4t+3: compare-exchange distances
+// 1 and 2 stay inside the thread, distances 4..128 pair it with lane t ^ (j / 4) of its own wave (shuffles,
+// no LDS memory, no barrier); only distances >= 256 need the LDS tile and a workgroup barrier.  Of the 78
+// stages of a tile sort 68 run this way.
+__device__ __forceinline__ bool kv_gt(unsigned long long ka, uint32_t ia, unsigned long long kb, uint32_t ib) {
+  return (ka > kb) || (ka == kb && ia > ib);
+}
+// stages j = jmax .. 1 (jmax <= 128) of merge step k; gi = global index of the thread's first element
+__device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint32_t (&ei)[4], int k, int jmax,
+                                              int gi, int tid) {
+  for (int j = jmax; j >= 4; j >>= 1) {
+    const int lx = j >> 2;
+    const bool lower = (tid & lx) == 0;
+    const bool up = (gi & k) == 0;       // k >= 8 here: the same for the thread's four elements
+    const bool want_gt = (lower == up);  // take the partner's element when (mine > theirs) == want_gt
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned long long ok = __shfl_xor(ek[r], lx, 64);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)ei[r], lx, 64);
+      if (kv_gt(ek[r], ei[r], ok, oi) == want_gt) { ek[r] = ok; ei[r] = oi; }
+    }
+  }
+#define ICIKT_CE(a, b, upv)                                                          \
+  {                                                                                  \
+    if (kv_gt(ek[a], ei[a], ek[b], ei[b]) == (upv)) {                                \
+      const unsigned long long tk = ek[a]; ek[a] = ek[b]; ek[b] = tk;                \
+      const uint32_t ti = ei[a]; ei[a] = ei[b]; ei[b] = ti;                          \
+    }                                                                                \
+  }
+  if (jmax >= 2) {
+    const bool up = (gi & k) == 0;       // k >= 4
+    ICIKT_CE(0, 2, up) ICIKT_CE(1, 3, up)
+  }
+  {
+    const bool up0 = (gi & k) == 0, up2 = ((gi + 2) & k) == 0;  // differ only for k == 2
+    ICIKT_CE(0, 1, up0) ICIKT_CE(2, 3, up2)
+  }
+#undef ICIKT_CE
+}
+
 __global__ void __launch_bounds__(K0_THREADS)
 k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin) {
   __shared__ long long sh_ll[K0_THREADS];
@@ -184,61 +225,98 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   {
     const int T = (npow2 < K0_TILE) ? npow2 : K0_TILE;
     const int ntiles = npow2 / T;
-    // stages k = 2..T entirely inside each tile
-    for (int tile = 0; tile < ntiles; ++tile) {
-      const int tb = tile * T;
-      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[tb + i]; sh_ti[i] = idx[tb + i]; }
+    if (T == K0_TILE) {
+      // full tiles: register / shuffle stages (k0_reg_stages) around the LDS stages with distance >= 256
+      unsigned long long ek[4];
+      uint32_t ei[4];
+      for (int tile = 0; tile < ntiles; ++tile) {
+        const int tb = tile * T;
+        const int gi = tb + 4 * tid;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ek[r] = keys[gi + r]; ei[r] = idx[gi + r]; }
+        for (int k = 2; k <= 256; k <<= 1) k0_reg_stages(ek, ei, k, k >> 1, gi, tid);
+        for (int k = 512; k <= T; k <<= 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = ek[r]; sh_ti[4 * tid + r] = ei[r]; }
+          __syncthreads();
+          for (int j = k >> 1; j >= 256; j >>= 1) {
+            for (int t = tid; t < (T >> 1); t += K0_THREADS) {
+              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const int l = i | j;
+              const bool up = (((tb + i) & k) == 0);
+              const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
+              const uint32_t ia = sh_ti[i], ib = sh_ti[l];
+              if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+            }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = sh_ti[4 * tid + r]; }
+          __syncthreads();  // the tile is rewritten by the next step's stores
+          k0_reg_stages(ek, ei, k, 128, gi, tid);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; idx[gi + r] = ei[r]; }
+      }
+      __syncthreads();
+      // merges across tiles: distances >= T in global memory, 2048..256 on the LDS tile, the rest in registers
+      for (int k = 2 * T; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j >= T; j >>= 1) {
+          for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const bool up = ((i & k) == 0);
+            const unsigned long long ka = keys[i], kb = keys[l];
+            const uint32_t ia = idx[i], ib = idx[l];
+            if (kv_gt(ka, ia, kb, ib) == up) { keys[i] = kb; keys[l] = ka; idx[i] = ib; idx[l] = ia; }
+          }
+          __syncthreads();
+        }
+        for (int tile = 0; tile < ntiles; ++tile) {
+          const int tb = tile * T;
+          const int gi = tb + 4 * tid;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = keys[gi + r]; sh_ti[4 * tid + r] = idx[gi + r]; }
+          __syncthreads();
+          const bool up = ((tb & k) == 0);  // constant inside a tile because k > T
+          for (int j = T >> 1; j >= 256; j >>= 1) {
+            for (int t = tid; t < (T >> 1); t += K0_THREADS) {
+              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const int l = i | j;
+              const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
+              const uint32_t ia = sh_ti[i], ib = sh_ti[l];
+              if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+            }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = sh_ti[4 * tid + r]; }
+          __syncthreads();
+          k0_reg_stages(ek, ei, k, 128, gi, tid);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; idx[gi + r] = ei[r]; }
+        }
+        __syncthreads();
+      }
+    } else {
+      // short columns (npow2 < 4096): one partial tile, every stage on LDS
+      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[i]; sh_ti[i] = idx[i]; }
       __syncthreads();
       for (int k = 2; k <= T; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
           for (int t = tid; t < (T >> 1); t += K0_THREADS) {
             const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
             const int l = i | j;
-            const bool up = (((tb + i) & k) == 0);
+            const bool up = ((i & k) == 0);
             const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
             const uint32_t ia = sh_ti[i], ib = sh_ti[l];
-            const bool gt = (ka > kb) || (ka == kb && ia > ib);
-            if (gt == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+            if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
           }
           __syncthreads();
         }
       }
-      for (int i = tid; i < T; i += K0_THREADS) { keys[tb + i] = sh_tk[i]; idx[tb + i] = sh_ti[i]; }
+      for (int i = tid; i < T; i += K0_THREADS) { keys[i] = sh_tk[i]; idx[i] = sh_ti[i]; }
       __syncthreads();
-    }
-    // merges across tiles: distances >= T in global memory, the rest per tile in LDS
-    for (int k = 2 * T; k <= npow2; k <<= 1) {
-      for (int j = k >> 1; j >= T; j >>= 1) {
-        for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int l = i | j;
-          const bool up = ((i & k) == 0);
-          const unsigned long long ka = keys[i], kb = keys[l];
-          const uint32_t ia = idx[i], ib = idx[l];
-          const bool gt = (ka > kb) || (ka == kb && ia > ib);
-          if (gt == up) { keys[i] = kb; keys[l] = ka; idx[i] = ib; idx[l] = ia; }
-        }
-        __syncthreads();
-      }
-      for (int tile = 0; tile < ntiles; ++tile) {
-        const int tb = tile * T;
-        for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[tb + i]; sh_ti[i] = idx[tb + i]; }
-        __syncthreads();
-        const bool up = ((tb & k) == 0);  // constant inside a tile because k > T
-        for (int j = T >> 1; j > 0; j >>= 1) {
-          for (int t = tid; t < (T >> 1); t += K0_THREADS) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const int l = i | j;
-            const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
-            const uint32_t ia = sh_ti[i], ib = sh_ti[l];
-            const bool gt = (ka > kb) || (ka == kb && ia > ib);
-            if (gt == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
-          }
-          __syncthreads();
-        }
-        for (int i = tid; i < T; i += K0_THREADS) { keys[tb + i] = sh_tk[i]; idx[tb + i] = sh_ti[i]; }
-        __syncthreads();
-      }
     }
   }
 

@@ -17,6 +17,7 @@ for n in ns:
     out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
     ctx.prepare_dev(dX.data_ptr(), n, S, n, _lib.FLAG_TIMING); ctx.sync()
     line = [f"n={n:6d} K0/col {ctx.kernel_ms(_lib.K_PREPARE)[0] / S * 1e3:6.1f} us"]
+    ctx.run_dev(1, 0, False, 0, out.data_ptr()); ctx.sync()  # warm-up (clocks, first-touch)
     ref = None
     for v in variants:
         for k in ("ICIKT_K1_PEND", "ICIKT_K1_NP"): os.environ.pop(k, None)

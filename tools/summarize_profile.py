@@ -22,13 +22,13 @@ a = ap.parse_args()
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 
-stats = glob.glob(os.path.join(a.src, "prof_stats", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(a.src, "prof_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if stats:  # gpurun merges every call's files into the same directories: the newest one is this run's
+    shutil.copy(stats[-1], os.path.join(out, f"{a.tag}_kernel_stats.csv"))
 
 means = collections.defaultdict(dict)
 for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2", "prof_ta", "prof_tcp", "prof_tcc"):
-    for f in glob.glob(os.path.join(a.src, d, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(a.src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(list)
         meta = {}
         for r in csv.DictReader(open(f)):

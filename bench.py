@@ -150,7 +150,7 @@ def main():
     # N > 1: each rank sorts only its S/N columns (K0) and the prepared state is all-gathered (RCCL over xGMI)
     # instead of every rank repeating the whole pre-pass; falls back to the replicated pre-pass if that fails.
     prep_mode = "single"
-    cols_per = -(-S // world)
+    cols_per = 2 * -(-S // (2 * world))  # even: the rec table interleaves column pairs
     alloc_cols = cols_per * world
     c0, c1 = min(S, rank * cols_per), min(S, (rank + 1) * cols_per)
     shards = None

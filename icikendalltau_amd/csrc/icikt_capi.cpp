@@ -194,20 +194,70 @@ K1Plan plan_k1(const PrepView& pv) {
   return pl;
 }
 
-// tasks: maximal runs of <= np consecutive pairs sharing pi (one wave each)
+// Tasks (one wave each), as (pair index, pair index or -1).  np == 1: one pair per task.  np == 2: two pairs
+// that share their streamed column pj and whose gathered columns pi are the two columns (2a, 2a+1) of one
+// block of the interleaved rec table, so that ONE 8-byte gather per row serves both pairs; pairs without such
+// a partner run alone.  Tasks are ordered by gathered block, then streamed column (cache locality of the
+// block's rec table).
 void build_units(icikt_ctx* c, int np) {
-  c->h_units.clear();
+  auto& u = c->h_units;
+  u.clear();
   const int64_t P = c->n_pairs;
-  int64_t p = 0;
-  while (p < P) {
-    c->h_units.push_back((int32_t)p);
-    const int32_t b = c->h_pi[p];
-    int64_t e = p + 1;
-    while (e < P && e - p < np && c->h_pi[e] == b) ++e;
-    p = e;
+  const int32_t* pi = c->h_pi.data();
+  const int32_t* pj = c->h_pj.data();
+  u.reserve((size_t)P * 2);
+  auto push = [&u](int64_t a, int64_t b) { u.push_back((int32_t)a); u.push_back((int32_t)b); };
+  if (np == 1) {
+    for (int64_t p = 0; p < P; ++p) push(p, -1);
+  } else {
+    // combn ranges and setup_comparisons lists are sorted by (pi, pj): merge the rows 2a and 2a+1 on pj
+    bool sorted = true;
+    for (int64_t p = 1; p < P && sorted; ++p)
+      sorted = (pi[p] > pi[p - 1]) || (pi[p] == pi[p - 1] && pj[p] > pj[p - 1]);
+    if (sorted) {
+      int64_t a = 0;
+      while (a < P) {
+        int64_t ae = a;
+        while (ae < P && pi[ae] == pi[a]) ++ae;
+        if ((pi[a] & 1) == 0 && ae < P && pi[ae] == pi[a] + 1) {
+          int64_t be = ae;
+          while (be < P && pi[be] == pi[ae]) ++be;
+          int64_t x = a, y = ae;
+          while (x < ae || y < be) {
+            if (x < ae && y < be && pj[x] == pj[y]) { push(x, y); ++x; ++y; }
+            else if (y >= be || (x < ae && pj[x] < pj[y])) { push(x, -1); ++x; }
+            else { push(y, -1); ++y; }
+          }
+          a = be;
+        } else {
+          for (int64_t x = a; x < ae; ++x) push(x, -1);
+          a = ae;
+        }
+      }
+    } else {
+      // any other list: order the pairs by (block of pi, pj, parity of pi) and pair up neighbours
+      std::vector<int64_t> idx((size_t)P);
+      for (int64_t p = 0; p < P; ++p) idx[(size_t)p] = p;
+      auto key = [pi, pj](int64_t p) {
+        return ((uint64_t)(uint32_t)(pi[p] >> 1) << 33) | ((uint64_t)(uint32_t)pj[p] << 1) | (uint64_t)(pi[p] & 1);
+      };
+      std::sort(idx.begin(), idx.end(), [&key](int64_t x, int64_t y) {
+        const uint64_t kx = key(x), ky = key(y);
+        return kx < ky || (kx == ky && x < y);
+      });
+      int64_t i = 0;
+      while (i < P) {
+        const int64_t x = idx[(size_t)i];
+        if (i + 1 < P) {
+          const int64_t y = idx[(size_t)i + 1];
+          if ((pi[x] & 1) == 0 && pi[y] == pi[x] + 1 && pj[y] == pj[x]) { push(x, y); i += 2; continue; }
+        }
+        push(x, -1);
+        ++i;
+      }
+    }
   }
-  c->h_units.push_back((int32_t)P);
-  c->n_units = (int)c->h_units.size() - 1;
+  c->n_units = (int)(u.size() / 2);
   c->wpb = np;
 }
 
@@ -323,6 +373,9 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
   if (col_begin < 0 || col_end < col_begin || col_end > n_samp || alloc_cols < n_samp)
     return fail(c, ICIKT_E_INVALID, "prepare: bad column range");
+  // rec is interleaved in blocks of two columns: a column range is contiguous memory only on even boundaries
+  if ((col_begin & 1) || ((col_end & 1) && col_end != n_samp))
+    return fail(c, ICIKT_E_INVALID, "prepare: a column range must start on an even column and end on one (or at n_samp)");
   int rc = use_device(c);
   if (rc) return rc;
   c->prepared = false;
@@ -343,7 +396,7 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
 
   HIPCHK(c, c->order.reserve(S * pv.n_ord));
   HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
-  HIPCHK(c, c->rec.reserve(S * pv.n_pad));
+  HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
   HIPCHK(c, c->mask.reserve(S * pv.Wp));
   HIPCHK(c, c->fillmask.reserve(S * pv.Wp));
   HIPCHK(c, c->gflag.reserve(S * pv.Wp));

@@ -42,7 +42,8 @@ struct PrepView {
   int n_samp;
   // per column, stride n_pad
   uint16_t* order;   // [S][n_ord]  row at processing position k (descending value)
-  uint32_t* rec;     // [S][n_pad]  per row: q | lo << 16  (ascending stable position, group start)
+  uint32_t* rec;     // [S/2][n_pad][2]  per row: q | lo << 16  (ascending stable position, group start),
+                     // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
   uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
   // per column, stride Wp
   unsigned long long* mask;      // [S][Wp] missing rows
@@ -70,7 +71,7 @@ __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
 }
 
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
-hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
+hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
                      int opts, hipStream_t s);

@@ -77,6 +77,11 @@ __device__ __forceinline__ uint32_t gload_u16(const uint16_t* base, uint32_t idx
   return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(base) + (size_t)(idx << 1));
 }
 
+// both columns of a rec block for the lane's row: [row][2] u32, one 8-byte gather
+__device__ __forceinline__ uint2 gload_rec2(const uint32_t* blk, uint32_t row) {
+  return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blk) + (size_t)(row << 3));
+}
+
 __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
   return (1ull << bits) - 1ull;
 }
@@ -171,7 +176,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   unsigned long long* fmask = pv.fillmask + (int64_t)c * pv.Wp;
   unsigned long long* gflag = pv.gflag + (int64_t)c * pv.Wp;
   uint16_t* order = pv.order + (int64_t)c * pv.n_ord;
-  uint32_t* rec = pv.rec + (int64_t)c * pv.n_pad;
+  uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
   uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
   uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
 
@@ -382,7 +387,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     const int lo = run_lo;
     const uint32_t row = idx[k];
     const int hi = (int)hirow[row];  // written by this thread above
-    rec[row] = (uint32_t)k | ((uint32_t)lo << 16);
+    rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
     order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
     if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
     if (st) {
@@ -775,10 +780,6 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
 // state of one pair inside a wave
 struct PairState {
   WaveLds L;
-  const uint16_t* ord;              // streamed column: rows in descending order
-  const unsigned long long* gf;     // streamed column: group-start flags
-  unsigned long long Fnext;
-  uint32_t row_next;
   uint32_t dis, tie, tie2;
 };
 
@@ -934,15 +935,18 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
 
 // Variants: <1, PG, 0> one pair per wave (any n; PG = pend in global memory) and <2, false, HI> two pairs per
 // wave, one per half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild.
+// A task is (pair, pair or -1).  The two pairs of a task share their STREAMED column (pj) and their gathered
+// columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
+// build_units).
 template <int NP, bool PG, int HI>
-__global__ void __launch_bounds__(512, NP <= 2 ? 6 : 4)  // 6 waves per SIMD (<= 80 VGPRs) for NP <= 2
-k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
+__global__ void __launch_bounds__(512, 6)  // 6 waves per SIMD (<= 80 VGPRs)
+k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
          int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
          int opts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // XCD-aware mapping: consecutive tasks share their gathered column, so keep them on one XCD
+  // XCD-aware mapping: consecutive tasks share their gathered block, so keep them on one XCD
   // (workgroups are dealt round-robin over the 8 XCDs).  Bijective for any grid size.
   int blk;
   {
@@ -967,27 +971,44 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   // persistent waves: the grid is sized to the chip and each wave walks the task list with stride nwaves;
   // the kernel has no workgroup barrier, so the waves of a workgroup run independently
   for (int task = gwave; task < n_tasks; task += nwaves) {
-  const int p0 = __builtin_amdgcn_readfirstlane(task_start[task]);
-  const int np = __builtin_amdgcn_readfirstlane(task_start[task + 1]) - p0;  // 1..NP pairs, same pi
-  // the gathered (random-access) column is the pairs' common pi: the waves of a workgroup, and the
-  // workgroups of an XCD, mostly share it, which keeps its rec table in L1 / L2
-  const int bcol = __builtin_amdgcn_readfirstlane(pi[p0]);
-  const uint32_t* recG = pv.rec + (int64_t)bcol * pv.n_pad;
-  const uint16_t* hiG = pv.hirow + (int64_t)bcol * pv.n_pad;
-  const unsigned long long* mb = pv.mask + (int64_t)bcol * Wp;
-  const unsigned long long* fb = pv.fillmask + (int64_t)bcol * Wp;
-  // few tie groups in the gathered column: joint ties of multi-step groups are counted at group close
-  const uint32_t* tgB = pv.tgroups + (int64_t)bcol * pv.tg_stride;
-  const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.stats[bcol].ntg);
-  const int ntgB = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
+  int pidx[NP];
+  pidx[0] = __builtin_amdgcn_readfirstlane(tasks[2 * task]);
+  const int p_second = __builtin_amdgcn_readfirstlane(tasks[2 * task + 1]);
+  const int np = (NP == 2 && p_second >= 0) ? 2 : 1;
+  if (NP == 2) pidx[NP - 1] = (p_second >= 0) ? p_second : pidx[0];  // an unused slot repeats the pair; not written
 
+  // streamed column (shared by the task's pairs): rows in descending order, group-start flags
+  const int scol = __builtin_amdgcn_readfirstlane(pj[pidx[0]]);
+  const uint16_t* ord = pv.order + (int64_t)scol * pv.n_ord;
+  const unsigned long long* gf = pv.gflag + (int64_t)scol * Wp;
+  const unsigned long long* ma = pv.mask + (int64_t)scol * Wp;
+  const unsigned long long* fa = pv.fillmask + (int64_t)scol * Wp;
+
+  // gathered (random-access) columns: the pairs' pi, both in one block of the interleaved rec table.  The waves
+  // of a workgroup, and the workgroups of an XCD, mostly share the block, which keeps it in L1 / L2.
+  uint32_t comp[NP];           // which column of the block a pair reads
+  const uint16_t* hiG[NP];
+  const uint32_t* tgB[NP];     // few tie groups in the gathered column: joint ties of multi-step groups are
+  int ntgB[NP];                // counted at group close from this list (-1: row mode)
   PairState S[NP];
   PendG Pg[NP];
   uint32_t cb[NP], gg[NP];
+  const uint32_t* rec_blk;
+  {
+    const int g0 = __builtin_amdgcn_readfirstlane(pi[pidx[0]]);
+    rec_blk = pv.rec + ((int64_t)(g0 >> 1) * pv.n_pad) * 2;
+  }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    // an unused slot repeats the task's last pair; its result is not written
-    const int acol = __builtin_amdgcn_readfirstlane(pj[p0 + (k < np ? k : np - 1)]);
+    const int gcol = __builtin_amdgcn_readfirstlane(pi[pidx[k]]);
+    comp[k] = (uint32_t)(gcol & 1);
+    hiG[k] = pv.hirow + (int64_t)gcol * pv.n_pad;
+    tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
+    const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.stats[gcol].ntg);
+    ntgB[k] = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
+    const unsigned long long* mb = pv.mask + (int64_t)gcol * Wp;
+    const unsigned long long* fb = pv.fillmask + (int64_t)gcol * Wp;
+
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
     S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
     if (PG) {
@@ -1005,12 +1026,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
         S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; S[k].L.spre[w] = 0; Pg[k].pre16[w] = 0;
       }
     }
-    S[k].ord = pv.order + (int64_t)acol * pv.n_ord;
-    S[k].gf = pv.gflag + (int64_t)acol * Wp;
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
-    const unsigned long long* ma = pv.mask + (int64_t)acol * Wp;
-    const unsigned long long* fa = pv.fillmask + (int64_t)acol * Wp;
     cb[k] = 0; gg[k] = 0;
     for (int w = lane; w < W; w += 64) {
       cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
@@ -1019,68 +1036,53 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   }
   wave_lds_fence();
 
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    S[k].Fnext = (nb > 0) ? S[k].gf[0] : 0ull;
-    S[k].row_next = gload_u16(S[k].ord, lane);
-  }
+  unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
+  uint32_t row_next = gload_u16(ord, lane);
 
-  // The LAST tie group of a streamed column (on data with missing values: the fill group) in closed form.
+  // The LAST tie group of the streamed column (on data with missing values: the fill group) in closed form.
   // Every row outside it is above it, so for a row r of the group
   //   #{j above : b_j < b_r} = lo_r - #{j in the group : b_j < b_r},
   // and summed over the group:  sum(lo_r) - (C(m, 2) - T),  m = rows of the group, T = its joint ties.
   // Steps that lie entirely inside the group then only gather, add lo and (for T) collect the rows in pend.
-  // Used in list mode when at least one step lies entirely inside the group; last_start = the group's first
-  // position (rows at or after it add lo instead of their counts).
-  // It is used when that holds for every pair of the wave; the step loop then ends at t_main (the first step
-  // inside the last group of all pairs) and a gather-only loop runs the rest.
-  int last_start[NP];
-  int t_main = 0;
-  bool closed_form = ntgB >= 0;
+  // Used when the gathered columns are in list mode and at least one step lies entirely inside the group:
+  // the step loop ends at t_main (the first such step) and a gather-only loop runs the rest; last_start =
+  // the group's first position (rows at or after it add lo instead of their counts).
+  int last_start, t_main;
+  bool closed_form = true;
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
+  for (int k = 0; k < NP; ++k) closed_form = closed_form && (ntgB[k] >= 0);
+  {
     int best = 0;
     for (int w = lane; w < W; w += 64) {
-      unsigned long long f = S[k].gf[w];
+      unsigned long long f = gf[w];
       if (w == W - 1 && (n & 63)) f &= (1ull << (n & 63)) - 1ull;
       if (f != 0ull) best = max(best, w * 64 + 63 - (int)__builtin_clzll(f));
     }
-    last_start[k] = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
-    closed_form = closed_form && ((last_start[k] >> 6) + 1 <= nb - 1);
-    t_main = max(t_main, (last_start[k] >> 6) + 1);
-  }
-  if (!closed_form) {
-    t_main = nb;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) last_start[k] = 0x7FFFFFFF;
+    last_start = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
+    t_main = (last_start >> 6) + 1;
+    closed_form = closed_form && (t_main <= nb - 1);
+    if (!closed_form) { t_main = nb; last_start = 0x7FFFFFFF; }
   }
 
   uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
   for (int t = 0; t < t_main; ++t) {
     const int kpos = t * 64 + (int)lane;
     const bool valid = kpos < n;
-    unsigned long long F[NP];
-    bool Fn[NP];
-    uint32_t row[NP], q[NP], lo[NP];
-    bool all_fast = true;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      F[k] = uniform_u64(S[k].Fnext);
-      S[k].Fnext = (t + 1 < nb) ? S[k].gf[t + 1] : 1ull;
-      Fn[k] = (uniform_u64(S[k].Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
-      all_fast = all_fast && (F[k] == ~0ull) && Fn[k];
-      row[k] = S[k].row_next;
-    }
+    const unsigned long long F = uniform_u64(Fnext);
+    Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
+    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
+    const bool all_fast = (F == ~0ull) && Fn;
+    const uint32_t row = row_next;
+    uint32_t q[NP], lo[NP];
 
     if (half_mode && all_fast) {
-      // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.
-      //      permlane32_swap turns the two 64-lane row registers into the two sub-steps' rows. --------
-      const auto sw = __builtin_amdgcn_permlane32_swap(row[0], row[NP - 1], false, false);
-      const uint32_t rr0 = gload_u32(recG, sw[0]);
-      const uint32_t rr1 = gload_u32(recG, sw[1]);
-      // prefetch the next step's rows behind the gathers (order[] is zero-padded by one step)
-#pragma unroll
-      for (int k = 0; k < NP; ++k) S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
+      // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One
+      //      8-byte gather per row; permlane32_swap turns the two 64-row registers (pair 0, pair 1) into
+      //      the two sub-steps' operands [pair 0 rows 0..31 | pair 1 rows 0..31], [.. rows 32..63]. ------
+      const uint2 rv = gload_rec2(rec_blk, row);
+      // prefetch the next step's rows behind the gather (order[] is zero-padded by one step)
+      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
+      const auto sw = __builtin_amdgcn_permlane32_swap(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, false, false);
       const bool hi = lane >= 32u;
       unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
       uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
@@ -1088,7 +1090,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       const uint32_t cross_idx = half_cross_idx(lane);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const uint32_t r = sub ? rr1 : rr0;
+        const uint32_t r = sub ? sw[1] : sw[0];
         const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
         const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
         dis_half += cnt + half_count(qh, loh, lane, cross_idx);
@@ -1104,9 +1106,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
     if (!half_mode && all_fast) {
       // ---- hot step, one pair on the whole wave: all 64 rows are valid, each row is its own tie group of
       //      the streamed column, and no group stays open: gather, count, insert into `seen`. -----------
-      const uint32_t r = gload_u32(recG, row[0]);
-      // prefetch the next step's rows behind the gather (order[] is zero-padded by one step)
-      S[0].row_next = gload_u16(S[0].ord, (uint32_t)(kpos + 64));
+      const uint32_t r = gload_u32(rec_blk, 2u * row + comp[0]);
+      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
       const uint32_t q0 = r & 0xFFFFu, lo0 = r >> 16;
       S[0].dis += prefix_query(S[0].L.seen, S[0].L.spre, lo0) + wave_allpairs(q0, lo0, lane);
       wave_lds_fence();
@@ -1117,26 +1118,35 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       continue;
     }
 
-    // ---- general step (tie groups in a streamed column, open groups, the last partial step) ----------
+    // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
+    {
+      uint32_t rk[NP];
+      if (NP == 2) {
+        const uint2 rv = gload_rec2(rec_blk, row);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const uint32_t r = gload_u32(recG, row[k]);
-      S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
-      q[k] = valid ? (r & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
-      lo[k] = valid ? (r >> 16) : 0u;              // nothing is below 0
-      // (1) rows of strictly higher groups of the streamed column that are already in `seen`
-      const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
-      S[k].dis += valid ? ((kpos >= last_start[k]) ? lo[k] : cnt) : 0u;
+        for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+      } else {
+        rk[0] = gload_u32(rec_blk, 2u * row + comp[0]);
+      }
+      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        q[k] = valid ? (rk[k] & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
+        lo[k] = valid ? (rk[k] >> 16) : 0u;              // nothing is below 0
+        // (1) rows of strictly higher groups of the streamed column that are already in `seen`
+        const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
+        S[k].dis += valid ? ((kpos >= last_start) ? lo[k] : cnt) : 0u;
+      }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F[k], Fn[k], valid, valid && kpos >= last_start[k], row[k],
-                                              q[k], lo[k], hiG, tgB, ntgB, Wp, items, lane);
+      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F, Fn, valid, valid && kpos >= last_start, row, q[k], lo[k],
+                                              hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
   }
 
-  // steps entirely inside the last tie group of every pair's streamed column: gather, add lo, collect in pend;
+  // steps entirely inside the last tie group of the streamed column: gather, add lo, collect in pend;
   // then the group's joint ties T from pend and the correction C(m, 2) - T of the summed lo's
   unsigned long long corr[NP];
 #pragma unroll
@@ -1144,21 +1154,28 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
   if (closed_form) {
     for (int t = t_main; t < nb; ++t) {
       const int kpos = t * 64 + (int)lane;
+      uint32_t rk[NP];
+      if (NP == 2) {
+        const uint2 rv = gload_rec2(rec_blk, row_next);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const uint32_t r = gload_u32(recG, S[k].row_next);
-        S[k].row_next = gload_u16(S[k].ord, (uint32_t)(kpos + 64));
-        if (kpos < n) {
-          S[k].dis += r >> 16;
-          if (ntgB > 0) p_or<PG>(Pg[k], (int)((r & 0xFFFFu) >> 6), 1ull << (r & 63u));
+        for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+      } else {
+        rk[0] = gload_u32(rec_blk, 2u * row_next + comp[0]);
+      }
+      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
+      if (kpos < n) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          S[k].dis += rk[k] >> 16;
+          if (ntgB[k] > 0) p_or<PG>(Pg[k], (int)((rk[k] & 0xFFFFu) >> 6), 1ull << (rk[k] & 63u));
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t tl = (ntgB > 0) ? close_group_ties<PG>(Pg[k], tgB, ntgB, Wp, items, lane) : 0u;
+      const uint32_t tl = (ntgB[k] > 0) ? close_group_ties<PG>(Pg[k], tgB[k], ntgB[k], Wp, items, lane) : 0u;
       S[k].tie += tl;
-      const unsigned long long m = (unsigned long long)(n - last_start[k]);
+      const unsigned long long m = (unsigned long long)(n - last_start);
       corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
       if (PG) {  // a global pend slot is left all zero for the next task
         wave_pend_fence<PG>();
@@ -1180,7 +1197,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ task_start, int n_tasks,
       o.ntie = ntie;
       o.c_both = (uint32_t)cbs;
       o.g = (uint32_t)ggs;
-      raw[p0 + k] = o;
+      raw[pidx[k]] = o;
     }
   }
   wave_lds_fence();
@@ -1433,7 +1450,7 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
   return pend_global ? &k1_pairs<1, true, 0> : &k1_pairs<1, false, 0>;
 }
 
-hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks, const int32_t* pi,
+hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
                      int opts, hipStream_t s) {
@@ -1443,7 +1460,7 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* task_start, int n_tasks,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, task_start, n_tasks, pi, pj, raw,
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, tasks, n_tasks, pi, pj, raw,
                      perpair_bytes, pend_bits, pend_pre, opts);
   return hipGetLastError();
 }

@@ -116,7 +116,9 @@ int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t 
  * columns (so that every rank's slice has the same size) but only columns [col_begin, col_end) are computed.
  * The caller then all-gathers the column slices of the ICIKT_PREP_ARRAYS arrays returned by
  * icikt_prep_arrays() across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
- * [alloc_cols][bytes_per_col[i]] bytes, column-contiguous. */
+ * alloc_cols * bytes_per_col[i] bytes; a rank's columns are one contiguous slice of it provided col_begin is
+ * even and col_end is even or n_samp (one array interleaves column pairs; other ranges are refused), so give
+ * every rank an even number of columns. */
 #define ICIKT_PREP_ARRAYS 8
 int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
                            int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);

@@ -145,6 +145,26 @@ def test_explicit_pair_list_and_self_pairs(hip_ctx):
     _check(hip_ctx, X, pi, pj, perspective="local")
 
 
+def test_unsorted_pair_lists_group_into_tasks(hip_ctx):
+    """Arbitrary pair lists (shuffled, duplicates, pi > pj, self pairs, odd column counts): the host groups
+    pairs that share pj and whose pi are the two columns of one rec block into one task; every pair's
+    result must still land at its own position."""
+    rng = np.random.default_rng(61)
+    n, S = 1500, 9
+    X = rng.standard_normal((n, S))
+    X[rng.random(X.shape) < 0.15] = np.nan
+    X[:, 4] = np.round(X[:, 4] * 2)
+    pi, pj = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    pi, pj = pi.ravel().astype(np.int32), pj.ravel().astype(np.int32)     # all 81 ordered pairs incl. self
+    for trial in range(3):
+        perm = rng.permutation(len(pi))
+        sel = np.concatenate([perm, perm[:17]])                              # duplicates
+        _check(hip_ctx, X, pi[sel], pj[sel], perspective="global")
+    # sorted by (pi, pj) but with gaps: rows without a partner row, partner rows with different pj sets
+    keep = rng.random(len(pi)) < 0.6
+    _check(hip_ctx, X, pi[keep], pj[keep], perspective="local")
+
+
 def test_golden_snapshot_50000(hip_ctx, golden_dir, expected):
     # reference snapshot: tests/testthat/_snaps/kendall-tau.md:6-7 (n = 50 000, no ties)
     z = np.load(f"{golden_dir}/snapshot_50000.npz")
@@ -330,7 +350,7 @@ def test_sharded_prepass_matches_full(hip_ctx):
     full, _, _ = hip_ctx.pairs(X, perspective="global", want_counts=False)
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
     world = 4
-    cols_per = -(-S // world)
+    cols_per = 2 * -(-S // (2 * world))  # even: the rec table interleaves column pairs
     alloc = cols_per * world
     for r in range(world):  # one context plays all ranks in turn: the slices land in the same arrays
         c0, c1 = min(S, r * cols_per), min(S, (r + 1) * cols_per)

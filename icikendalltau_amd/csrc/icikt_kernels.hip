@@ -82,6 +82,12 @@ __device__ __forceinline__ uint2 gload_rec2(const uint32_t* blk, uint32_t row) {
   return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(blk) + (size_t)(row << 3));
 }
 
+// set bit `pos` of an LDS bitset: a 32-bit LDS atomic on the half of the 64-bit word that holds the bit
+// (little endian: word w = dwords 2w, 2w+1), half the data of a 64-bit one
+__device__ __forceinline__ void seen_insert(unsigned long long* bits, uint32_t pos) {
+  atomicOr(reinterpret_cast<uint32_t*>(bits) + (pos >> 5), 1u << (pos & 31u));
+}
+
 __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
   return (1ull << bits) - 1ull;
 }
@@ -1095,7 +1101,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
         dis_half += cnt + half_count(qh, loh, lane, cross_idx);
         wave_lds_fence();
-        atomicOr(&seenH[qh >> 6], 1ull << (qh & 63u));
+        seen_insert(seenH, qh);
         wave_lds_fence();
         rebuild_prefix_half<(HI > 0 ? HI : 1)>(seenH, spreH, l32);
         wave_lds_fence();
@@ -1111,7 +1117,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const uint32_t q0 = r & 0xFFFFu, lo0 = r >> 16;
       S[0].dis += prefix_query(S[0].L.seen, S[0].L.spre, lo0) + wave_allpairs(q0, lo0, lane);
       wave_lds_fence();
-      atomicOr(&S[0].L.seen[q0 >> 6], 1ull << (q0 & 63u));
+      seen_insert(S[0].L.seen, q0);
       wave_lds_fence();
       rebuild_prefix_long(S[0].L.seen, S[0].L.spre, (items + 1) & ~1, lane);
       wave_lds_fence();

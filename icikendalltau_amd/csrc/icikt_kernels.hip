@@ -242,6 +242,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
       uint32_t ei[4];
       for (int tile = 0; tile < ntiles; ++tile) {
         const int tb = tile * T;
+        if (tb >= n) continue;  // a tile of padding only (equal keys) is sorted in either direction already
         const int gi = tb + 4 * tid;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ek[r] = keys[gi + r]; ei[r] = idx[gi + r]; }

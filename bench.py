@@ -147,8 +147,9 @@ def main():
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-    # N > 1: each rank sorts only its S/N columns (K0) and the prepared state is all-gathered (RCCL over xGMI)
-    # instead of every rank repeating the whole pre-pass; falls back to the replicated pre-pass if that fails.
+    # N > 1: each rank sorts only its S/N columns (K0); order, the bitsets and stats are all-gathered (RCCL over
+    # xGMI) and the rest of the prepared state is rebuilt locally, instead of every rank repeating the whole
+    # pre-pass; falls back to the replicated pre-pass if that cannot be set up.
     prep_mode = "single"
     cols_per = 2 * -(-S // (2 * world))  # even: the rec table interleaves column pairs
     alloc_cols = cols_per * world
@@ -157,6 +158,15 @@ def main():
 
     def prepare_sharded():
         ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, flags)
+        exchange_shards()
+        # rec / hirow / tgroups of the received columns are functions of their order and gflag: rebuilt here
+        # instead of being sent (24 KB instead of 104 KB per column cross xGMI)
+        if c0 > 0:
+            ctx.expand_cols_dev(0, min(c0, S), flags)
+        if c1 < S:
+            ctx.expand_cols_dev(c1, S, flags)
+
+    def exchange_shards():
         for full, nbytes in shards:
             mine = full[rank * nbytes:(rank + 1) * nbytes]
             if backend == "nccl":
@@ -172,8 +182,9 @@ def main():
         err = None
         try:
             ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, 0)
-            shards = [(torch.as_tensor(_DevBytes(ptr, bpc * alloc_cols), device=dev), bpc * cols_per)
-                      for ptr, bpc in ctx.prep_arrays()]
+            arrays = ctx.prep_arrays()
+            shards = [(torch.as_tensor(_DevBytes(arrays[i][0], arrays[i][1] * alloc_cols), device=dev),
+                       arrays[i][1] * cols_per) for i in _lib.PREP_EXCHANGE]
         except Exception as e:  # noqa: BLE001
             err, shards = e, None
         ok = torch.tensor([0 if shards is None else 1], dtype=torch.int32, device=comm_dev)

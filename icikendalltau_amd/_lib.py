@@ -29,6 +29,7 @@ CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
 MAX_FEATURES = 65535
 PREP_ARRAYS = 8
+PREP_EXCHANGE = (0, 3, 4, 5, 6)  # order, mask, fillmask, gflag, stats: the rest is rebuilt by expand_cols_dev()
 
 REASON_OK, REASON_ALL_MISSING, REASON_SHORT, REASON_SINGLE_UNIQUE, REASON_TIES_EQ_TOTAL = range(5)
 REASON_WARNINGS = {
@@ -39,7 +40,7 @@ REASON_WARNINGS = {
 
 EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
-    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prep_arrays", "icikt_set_pairs", "icikt_set_pairs_combn",
+    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prep_arrays", "icikt_expand_cols_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
     "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest",
 )
@@ -108,6 +109,7 @@ def lib():
     L.icikt_prepare_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_u32]
     L.icikt_prepare_cols_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_u32]
     L.icikt_prep_arrays.argtypes = [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)]
+    L.icikt_expand_cols_dev.argtypes = [c_vp, c_i64, c_i64, c_u32]
     L.icikt_set_pairs.argtypes = [c_vp, c_vp, c_vp, c_i64]
     L.icikt_set_pairs_combn.argtypes = [c_vp, c_i64, c_i64, c_i64]
     L.icikt_num_pairs.argtypes = [c_vp]
@@ -192,6 +194,10 @@ class Context:
         bpc = (ctypes.c_int64 * PREP_ARRAYS)()
         self._chk(lib().icikt_prep_arrays(self._h, ptrs, bpc), "icikt_prep_arrays")
         return [(int(ptrs[i] or 0), int(bpc[i])) for i in range(PREP_ARRAYS)]
+
+    def expand_cols_dev(self, col_begin: int, col_end: int, flags: int = 0):
+        """Rebuild rec / hirow / tgroups of columns [col_begin, col_end) from their (received) order and gflag."""
+        self._chk(lib().icikt_expand_cols_dev(self._h, col_begin, col_end, flags), "icikt_expand_cols_dev")
 
     def set_pairs(self, pi, pj):
         pi = np.ascontiguousarray(pi, dtype=np.int32)

@@ -441,6 +441,19 @@ int icikt_prepare_cols_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64
   return prepare_impl(c, dX, n_feat, n_samp, ld, col_begin, col_end, alloc_cols, flags);
 }
 
+int icikt_expand_cols_dev(icikt_ctx* c, int64_t col_begin, int64_t col_end, uint32_t flags) {
+  if (!c) return ICIKT_E_INVALID;
+  if (!c->prepared) return fail(c, ICIKT_E_STATE, "expand_cols: nothing prepared");
+  if (col_begin < 0 || col_end < col_begin || col_end > c->pv.n_samp)
+    return fail(c, ICIKT_E_INVALID, "expand_cols: bad column range");
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = timer_begin(c, ICIKT_K_PREPARE, flags);
+  if (rc) return rc;
+  HIPCHK(c, icikt::launch_k0_expand(c->pv, (int)col_begin, (int)(col_end - col_begin), c->stream));
+  return timer_end(c, ICIKT_K_PREPARE, flags);
+}
+
 int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
   if (!c || !ptrs || !bytes_per_col) return ICIKT_E_INVALID;
   if (!c->prepared) return fail(c, ICIKT_E_STATE, "prep_arrays: nothing prepared");

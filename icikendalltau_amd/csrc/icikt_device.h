@@ -71,6 +71,7 @@ __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
 }
 
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
+hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s);
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,

@@ -479,6 +479,97 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K0x: rebuild rec / hirow / tgroups of a column from its order and gflag
+// ------------------------------------------------------------------------------------------------
+// order (the descending permutation) and gflag (its tie-group starts) determine the other per-row arrays:
+// for the row at descending position k, in the group [s, e] of descending positions,
+//   q = n-1-k,  lo = n-1-e,  hi = n-1-s   (ascending position, first and last position of its tie group).
+// Ranks therefore exchange only order, the three bitsets and stats (24 KB per column of length 10 000 instead
+// of 104 KB) and rebuild the rest locally.  One workgroup per column: wave 0 scans the flag words, then the
+// waves take the 64-position steps in turn.
+constexpr int KX_WAVES = 4;
+__global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_begin, int ncols) {
+  __shared__ int prevs[1032];   // highest group start in the words before w (-1: none)
+  __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
+  __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
+  const int wave = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  const int c = col_begin + (int)blockIdx.x;
+  const int n = pv.n, W = pv.W, Wp = pv.Wp;
+  const unsigned long long* gf = pv.gflag + (int64_t)c * Wp;
+  const uint16_t* ord = pv.order + (int64_t)c * pv.n_ord;
+  uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
+  uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
+  uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
+
+  // starts of groups of size >= 2: a start whose successor position exists and is not a start
+  auto multi = [&](int w) -> unsigned long long {
+    const unsigned long long f = gf[w];
+    const unsigned long long fn = (f >> 1) | (gf[w + 1] << 63);  // gflag has a zero guard word at W
+    unsigned long long m = f & ~fn;
+    const int last = n - 2 - w * 64;  // positions k <= n-2 have a successor
+    if (last < 63) m &= (last < 0) ? 0ull : ((2ull << last) - 1ull);
+    return m;
+  };
+  if (wave == 0) {
+  const int items = (W + 63) >> 6;
+  const int w0 = min(W, lane * items), w1 = min(W, w0 + items);
+  int hb = -1, lb = n, mc = 0;
+  for (int w = w0; w < w1; ++w) {
+    const unsigned long long f = gf[w];
+    if (f != 0ull) {
+      hb = w * 64 + 63 - (int)__builtin_clzll(f);
+      if (lb == n) lb = w * 64 + (int)__builtin_ctzll(f);
+    }
+    mc += (int)__popcll(multi(w));
+  }
+  // exclusive prefix max of hb, exclusive suffix min of lb, exclusive suffix sum of mc over the lanes
+  int pmax = hb, smin = lb, ssum = mc;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int a = __shfl_up(pmax, o, 64), b = __shfl_down(smin, o, 64), d = __shfl_down(ssum, o, 64);
+    if (lane >= o) pmax = max(pmax, a);
+    if (lane + o < 64) { smin = min(smin, b); ssum += d; }
+  }
+  int run_prev = __shfl_up(pmax, 1, 64);
+  if (lane == 0) run_prev = -1;
+  int run_next = __shfl_down(smin, 1, 64), run_ms = __shfl_down(ssum, 1, 64);
+  if (lane == 63) { run_next = n; run_ms = 0; }
+  for (int w = w0; w < w1; ++w) {
+    prevs[w] = run_prev;
+    const unsigned long long f = gf[w];
+    if (f != 0ull) run_prev = w * 64 + 63 - (int)__builtin_clzll(f);
+  }
+  for (int w = w1 - 1; w >= w0; --w) {
+    nexts[w] = run_next;
+    msuf[w] = run_ms;
+    const unsigned long long f = gf[w];
+    if (f != 0ull) run_next = w * 64 + (int)__builtin_ctzll(f);
+    run_ms += (int)__popcll(multi(w));
+  }
+  }
+  __syncthreads();
+
+  for (int w = wave; w < W; w += KX_WAVES) {
+    const int k = w * 64 + lane;
+    if (k >= n) break;
+    const unsigned long long f = gf[w];
+    const unsigned long long le = (lane < 63) ? ((2ull << lane) - 1ull) : ~0ull;  // bits <= lane
+    const unsigned long long below = f & le, above = f & ~le;
+    const int s = (below != 0ull) ? w * 64 + 63 - (int)__builtin_clzll(below) : prevs[w];
+    const int e = ((above != 0ull) ? w * 64 + (int)__builtin_ctzll(above) : nexts[w]) - 1;
+    const uint32_t row = ord[k];
+    const uint32_t lo = (uint32_t)(n - 1 - e), hi = (uint32_t)(n - 1 - s);
+    rec[2 * row] = (uint32_t)(n - 1 - k) | (lo << 16);
+    hirow[row] = (uint16_t)hi;
+    if (k == s && e > s) {
+      // tgroups is ascending in lo: groups that start after me (descending) come first
+      const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
+      tgl[i] = lo | (hi << 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: column pairs on wavefronts -- one pair per wave, or two (one per 32-lane half, sharing the gathered
 // column, each streaming its own)
 // ------------------------------------------------------------------------------------------------
@@ -1490,6 +1581,12 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
   const int64_t blocks = (n_pairs + threads - 1) / threads;
   hipLaunchKernelGGL(k2_epilogue, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, raw, n_pairs,
                      perspective, alternative, continuity, exact64, out4, counts, reasons);
+  return hipGetLastError();
+}
+
+hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s) {
+  if (ncols <= 0 || pv.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k0_expand, dim3(ncols), dim3(64 * KX_WAVES), 0, s, pv, col_begin, ncols);
   return hipGetLastError();
 }
 

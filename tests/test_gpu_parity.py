@@ -365,6 +365,55 @@ def test_sharded_prepass_matches_full(hip_ctx):
     assert np.array_equal(out.cpu().numpy(), full, equal_nan=True)
 
 
+def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
+    """icikt_expand_cols_dev: rec / hirow / tgroups rebuilt from order + gflag equal what the pre-pass wrote
+    (ranks exchange only order, the bitsets and stats), for continuous, tied, constant and all-missing columns."""
+    import torch
+    from icikendalltau_amd import _lib
+    rng = np.random.default_rng(67)
+    for n in (1, 63, 64, 65, 900, 5000, 20000):
+        S = 7
+        X = np.asfortranarray(rng.standard_normal((n, S)))
+        X[rng.random(X.shape) < 0.1] = np.nan
+        X[:, 1] = np.round(X[:, 1] * 2)
+        X[:, 2] = 3.0
+        X[:, 3] = np.nan
+        X[: n // 2, 4] = np.nan
+        X[:, 5] = np.round(X[:, 5] * 50)
+        dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+        hip_ctx.prepare_dev(dX.data_ptr(), n, S, n)
+        hip_ctx.sync()
+        arrays = hip_ctx.prep_arrays()
+
+        def view(i, cols):
+            ptr, bpc = arrays[i]
+            class _D:  # zero-copy view of the library's buffer
+                __cuda_array_interface__ = {"shape": (bpc * cols,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+            return torch.as_tensor(_D(), device="cuda")
+
+        alloc = S + (S & 1)
+        derived = {i: view(i, alloc if i == 1 else S) for i in (1, 2, 7)}
+        want = {i: t.clone() for i, t in derived.items()}
+        # tgroups beyond a column's ntg entries and the pad rows of rec / hirow are unspecified: compare what K1 reads
+        for t in derived.values():
+            t.fill_(0xEE)
+        hip_ctx.expand_cols_dev(0, S)
+        hip_ctx.sync()
+        stats = view(6, S).cpu().numpy().view(np.uint32).reshape(S, -1)
+        ntg = stats[:, 7]
+        n_pad = arrays[2][1] // 2
+        rec_w = want[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
+        rec_g = derived[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
+        hi_w = want[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
+        hi_g = derived[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
+        tg_w = want[7].cpu().numpy().view(np.uint32).reshape(S, -1)
+        tg_g = derived[7].cpu().numpy().view(np.uint32).reshape(S, -1)
+        for c in range(S):
+            assert np.array_equal(rec_g[c >> 1, :n, c & 1], rec_w[c >> 1, :n, c & 1]), (n, c)
+            assert np.array_equal(hi_g[c, :n], hi_w[c, :n]), (n, c)
+            assert np.array_equal(tg_g[c, :ntg[c]], tg_w[c, :ntg[c]]), (n, c)
+
+
 def test_kt_fast_through_hip_engine(hip_ctx, golden_dir, expected):
     """kt_fast() NA policies on the MI355X engine against the reference's snapshots and the checker engine."""
     from icikendalltau_amd import api

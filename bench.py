@@ -190,8 +190,14 @@ def main():
         ok = torch.tensor([0 if shards is None else 1], dtype=torch.int32, device=comm_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
-            prepare_sharded()  # one trial pass before the timed region
-            torch.cuda.synchronize()
+            try:
+                prepare_sharded()  # one trial pass before the timed region
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             prep_mode = "sharded+allgather"
         else:
             print(f"[bench] rank {rank}: sharded pre-pass unavailable ({err!r}); every rank runs the whole pre-pass",

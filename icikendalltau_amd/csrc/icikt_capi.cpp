@@ -171,7 +171,8 @@ K1Plan plan_k1(const PrepView& pv) {
   if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
   pl.opts = 1;
   if (const char* e = getenv("ICIKT_K1_HALF")) pl.opts = (e[0] == '1') ? 1 : 0;
-  int tg_max = 256;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
+  int tg_max = 128;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
+                     // (measured on 10 000-row columns: list mode wins at 50 groups, row mode at 200: tools/tie_sweep.py)
   if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only

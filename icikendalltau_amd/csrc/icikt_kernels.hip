@@ -875,6 +875,21 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
   for (int i = 1; i < HI; ++i) pre[base + i] = (uint16_t)(excl + c[i - 1]);
 }
 
+// ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages)
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)v, j, 64);
+      const bool up = (lane & (uint32_t)k) == 0u;       // k == 64: every lane
+      const bool lower = (lane & (uint32_t)j) == 0u;
+      v = (lower == up) ? min(v, other) : max(v, other);
+    }
+  }
+  return v;
+}
+
 // state of one pair inside a wave
 struct PairState {
   WaveLds L;
@@ -910,7 +925,7 @@ template <bool PG>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
                                                                const bool Fn, const bool valid, const bool tailrow,
-                                                               const uint32_t row, const uint32_t q, const uint32_t lo,
+                                                               uint32_t row, uint32_t q, uint32_t lo,
                                                                const uint16_t* hiG, const uint32_t* tg, const int ntg,
                                                                const int Wp, const int items,
                                                                const uint32_t lane) {
@@ -934,23 +949,27 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     // (a tail row can only be the last lane here; as a target with lo = 0 it counts nothing)
     S.dis += wave_allpairs(q, tailrow ? 0u : lo, lane);
   } else if (F != 0ull) {
-    // mixed step: xg = group ordinal inside the step; rows tied in the streamed column are not
-    // discordant, and rows tied in both columns are joint ties
-    const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));
-    const uint32_t lot = valid ? lo : 0xFFFFFFFFu;
-    uint32_t qs = dpp_wave_shr1(0xFFFFFFFFu, q);
-    uint32_t xs = dpp_wave_shr1(0xFFFFFFFFu, xg);
-    uint32_t ls = dpp_wave_shr1(0xFFFFFFFEu, lot);
-    uint32_t c2 = 0, c3 = 0;
-    for (int s = 1; s < 64; ++s) {
-      const bool same = (xs == xg);
-      c2 += (!same && qs < lo) ? 1u : 0u;
-      c3 += (same && ls == lot) ? 1u : 0u;
-      qs = dpp_wave_shr1(qs, qs);
-      xs = dpp_wave_shr1(xs, xs);
-      ls = dpp_wave_shr1(ls, ls);
-    }
-    S.dis += (valid && !tailrow) ? c2 : 0u;
+    // mixed step: several tie groups of the streamed column (contiguous lane ranges) in one step.  Rows tied
+    // in the streamed column are not discordant, and rows tied in both columns are joint ties.  The order of
+    // the rows INSIDE a group is free, so the lanes are first re-sorted by (group, q descending): then for two
+    // rows of one group the earlier lane has the larger q, "q_a < lo_j" is false by itself, and the plain
+    // all-pairs count of the step is already the count over different groups; rows of one group that share a
+    // tie group of the gathered column become neighbours, so the joint ties are run lengths.  q, lo and row
+    // keep their new lanes for the rest of the step (group membership per lane is unchanged).
+    const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));   // 1..64, non-decreasing over the lanes
+    const uint32_t key = valid ? ((xg << 22) | ((0xFFFFu - (q & 0xFFFFu)) << 6) | lane) : 0xFFFFFFFFu;
+    const uint32_t src = (wave_sort_u32(key, lane) & 63u) << 2;            // invalid lanes stay behind the valid ones
+    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)q);
+    const uint32_t lo2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)lo);
+    const uint32_t row2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)row);
+    if (valid) { q = q2; lo = lo2; row = row2; }
+    S.dis += wave_allpairs(q, (valid && !tailrow) ? lo : 0u, lane);
+    // joint ties inside the step: earlier lanes of my run of equal (group, lo)
+    const uint32_t pk = valid ? ((xg << 16) | lo) : 0xFFFFFFFFu;
+    const uint32_t pprev = dpp_wave_shr1(0xFFFFFFFEu, pk);
+    const unsigned long long starts = __ballot(!valid || pk != pprev);
+    const unsigned long long upto = starts & ((2ull << lane) - 1ull);      // lane 0 is always a start
+    const uint32_t c3 = lane - (63u - (uint32_t)__builtin_clzll(upto));
     // list mode: groups that pass through pend are counted when they close, not here
     const bool counted_here = list ? (valid && !olane && (Fn || !tlane)) : valid;
     S.tie += counted_here ? c3 : 0u;

@@ -924,7 +924,7 @@ __device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint
 template <bool PG>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
-                                                               const bool Fn, const bool valid, const bool tailrow,
+                                                               const bool Fn, const bool valid,
                                                                uint32_t row, uint32_t q, uint32_t lo,
                                                                const uint16_t* hiG, const uint32_t* tg, const int ntg,
                                                                const int Wp, const int items,
@@ -934,8 +934,6 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   //     closes, each tie group of B contributes C(rows of the group inside it, 2).  A step inside the
   //     missing-value group of A then costs one query and one atomic OR.
   //   row mode (ntg < 0): every row asks pend how many earlier rows of its A group share its B group.
-  // tailrow: the row belongs to A's LAST tie group and the task counts that group's discordant pairs in
-  // closed form (k1_pairs): its rows add nothing to dis here.
   const bool list = ntg >= 0;
   StepAcc S;
   S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
@@ -946,8 +944,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   // (2) pairs inside this step
   if (F == ~0ull) {
     // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
-    // (a tail row can only be the last lane here; as a target with lo = 0 it counts nothing)
-    S.dis += wave_allpairs(q, tailrow ? 0u : lo, lane);
+    S.dis += wave_allpairs(q, lo, lane);
   } else if (F != 0ull) {
     // mixed step: several tie groups of the streamed column (contiguous lane ranges) in one step.  Rows tied
     // in the streamed column are not discordant, and rows tied in both columns are joint ties.  The order of
@@ -963,7 +960,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     const uint32_t lo2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)lo);
     const uint32_t row2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)row);
     if (valid) { q = q2; lo = lo2; row = row2; }
-    S.dis += wave_allpairs(q, (valid && !tailrow) ? lo : 0u, lane);
+    S.dis += wave_allpairs(q, valid ? lo : 0u, lane);
     // joint ties inside the step: earlier lanes of my run of equal (group, lo)
     const uint32_t pk = valid ? ((xg << 16) | lo) : 0xFFFFFFFFu;
     const uint32_t pprev = dpp_wave_shr1(0xFFFFFFFEu, pk);
@@ -986,7 +983,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
         pend_rebuild<PG>(Pg, Wp, items, lane);
         wave_pend_fence<PG>();
         wave_lds_fence();
-        if (valid && !olane && !tailrow) S.dis += pend_query<PG>(Pg, lo);
+        if (valid && !olane) S.dis += pend_query<PG>(Pg, lo);
       }
     } else if (olane) {
       // joint ties with the group's rows of earlier steps
@@ -1153,18 +1150,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   }
   wave_lds_fence();
 
-  unsigned long long Fnext = (nb > 0) ? gf[0] : 0ull;
   uint32_t row_next = gload_u16(ord, lane);
 
   // The LAST tie group of the streamed column (on data with missing values: the fill group) in closed form.
   // Every row outside it is above it, so for a row r of the group
   //   #{j above : b_j < b_r} = lo_r - #{j in the group : b_j < b_r},
   // and summed over the group:  sum(lo_r) - (C(m, 2) - T),  m = rows of the group, T = its joint ties.
-  // Steps that lie entirely inside the group then only gather, add lo and (for T) collect the rows in pend.
-  // Used when the gathered columns are in list mode and at least one step lies entirely inside the group:
-  // the step loop ends at t_main (the first such step) and a gather-only loop runs the rest; last_start =
-  // the group's first position (rows at or after it add lo instead of their counts).
-  int last_start, t_main;
+  // The group's rows then only gather, add lo and (for T) collect in pend.  Used when the gathered columns are
+  // in list mode and the group is longer than one step: the step loop ends at its first position last_start
+  // and a gather-only loop runs the rest.
+  int last_start;
   bool closed_form = true;
 #pragma unroll
   for (int k = 0; k < NP; ++k) closed_form = closed_form && (ntgB[k] >= 0);
@@ -1176,30 +1171,66 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       if (f != 0ull) best = max(best, w * 64 + 63 - (int)__builtin_clzll(f));
     }
     last_start = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
-    t_main = (last_start >> 6) + 1;
-    closed_form = closed_form && (t_main <= nb - 1);
-    if (!closed_form) { t_main = nb; last_start = 0x7FFFFFFF; }
+    closed_form = closed_form && (n - last_start > 64);
   }
+  const int end_main = closed_form ? last_start : n;
 
+  // Steps are cut at tie-group boundaries of the streamed column: a step holds up to 64 rows of COMPLETE
+  // groups (then nothing of it stays open: no pend, no merge), or a piece of ONE group that is longer than a
+  // step (the open-group path of pair_step_rest).  pos = first position of the step, nact = its rows, F =
+  // group-start flags of its rows, Fn = "the row after the step starts a group".
   uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
-  for (int t = 0; t < t_main; ++t) {
-    const int kpos = t * 64 + (int)lane;
-    const bool valid = kpos < n;
-    const unsigned long long F = uniform_u64(Fnext);
-    Fnext = (t + 1 < nb) ? gf[t + 1] : 1ull;
-    const bool Fn = (uniform_u64(Fnext) & 1ull) != 0ull;  // the next step opens a new group (or end)
-    const bool all_fast = (F == ~0ull) && Fn;
+  int pos = 0;
+  unsigned long long fw0 = gf[0], fw1 = gf[min(1, W)];  // flag words of the window at pos (gf[W] is a zero guard)
+  while (pos < end_main) {
+    // the step's rec gather first: its latency runs behind the window logic
     const uint32_t row = row_next;
+    uint32_t rk[NP];
+    if (NP == 2) {
+      const uint2 rv = gload_rec2(rec_blk, row);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+    } else {
+      rk[0] = gload_u32(rec_blk, 2u * row + comp[0]);
+    }
+    const int fb = pos & 63;
+    const unsigned long long w0 = uniform_u64(fw0), w1 = uniform_u64(fw1);
+    unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+    const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
+    const int remaining = end_main - pos;
+    const bool reach_end = remaining <= 64;
+    if (remaining < 64) F &= (1ull << remaining) - 1ull;
+    int nact;
+    bool Fn;
+    if ((F & 1ull) == 0ull) {                  // inside a group that is longer than a step
+      if (F == 0ull) { nact = reach_end ? remaining : 64; Fn = reach_end || fnbit; }
+      else { nact = (int)__builtin_ctzll(F); F = 0ull; Fn = true; }   // its last piece
+    } else if (reach_end || fnbit) {           // the window ends where a group ends
+      nact = reach_end ? remaining : 64;
+      Fn = true;
+    } else {                                   // the window's last group is incomplete: stop in front of it
+      const int L = 63 - (int)__builtin_clzll(F);
+      if (L == 0) { nact = 64; Fn = false; }   // ... unless it is all there is: a group longer than a step begins
+      else { nact = L; F &= (1ull << L) - 1ull; Fn = true; }
+    }
+    const int pos_next = pos + nact;
+    {
+      const int wn = pos_next >> 6;
+      fw0 = gf[min(wn, W)];
+      fw1 = gf[min(wn + 1, W)];
+    }
+    const int kpos = pos + (int)lane;
+    const bool valid = (int)lane < nact;
+    const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
+    pos = pos_next;
+    row_next = gload_u16(ord, (uint32_t)pos + lane);  // the next step's rows (order[] is zero-padded by one step)
     uint32_t q[NP], lo[NP];
 
     if (half_mode && all_fast) {
       // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One
       //      8-byte gather per row; permlane32_swap turns the two 64-row registers (pair 0, pair 1) into
       //      the two sub-steps' operands [pair 0 rows 0..31 | pair 1 rows 0..31], [.. rows 32..63]. ------
-      const uint2 rv = gload_rec2(rec_blk, row);
-      // prefetch the next step's rows behind the gather (order[] is zero-padded by one step)
-      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
-      const auto sw = __builtin_amdgcn_permlane32_swap(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, false, false);
+      const auto sw = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false);
       const bool hi = lane >= 32u;
       unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
       uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
@@ -1223,9 +1254,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     if (!half_mode && all_fast) {
       // ---- hot step, one pair on the whole wave: all 64 rows are valid, each row is its own tie group of
       //      the streamed column, and no group stays open: gather, count, insert into `seen`. -----------
-      const uint32_t r = gload_u32(rec_blk, 2u * row + comp[0]);
-      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
-      const uint32_t q0 = r & 0xFFFFu, lo0 = r >> 16;
+      const uint32_t q0 = rk[0] & 0xFFFFu, lo0 = rk[0] >> 16;
       S[0].dis += prefix_query(S[0].L.seen, S[0].L.spre, lo0) + wave_allpairs(q0, lo0, lane);
       wave_lds_fence();
       seen_insert(S[0].L.seen, q0);
@@ -1237,40 +1266,31 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 
     // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
     {
-      uint32_t rk[NP];
-      if (NP == 2) {
-        const uint2 rv = gload_rec2(rec_blk, row);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
-      } else {
-        rk[0] = gload_u32(rec_blk, 2u * row + comp[0]);
-      }
-      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         q[k] = valid ? (rk[k] & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
         lo[k] = valid ? (rk[k] >> 16) : 0u;              // nothing is below 0
         // (1) rows of strictly higher groups of the streamed column that are already in `seen`
         const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
-        S[k].dis += valid ? ((kpos >= last_start) ? lo[k] : cnt) : 0u;
+        S[k].dis += valid ? cnt : 0u;
       }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F, Fn, valid, valid && kpos >= last_start, row, q[k], lo[k],
+      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
                                               hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
   }
 
-  // steps entirely inside the last tie group of the streamed column: gather, add lo, collect in pend;
-  // then the group's joint ties T from pend and the correction C(m, 2) - T of the summed lo's
+  // the rows of the last tie group of the streamed column: gather, add lo, collect in pend; then the group's
+  // joint ties T from pend and the correction C(m, 2) - T of the summed lo's
   unsigned long long corr[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) corr[k] = 0ull;
   if (closed_form) {
-    for (int t = t_main; t < nb; ++t) {
-      const int kpos = t * 64 + (int)lane;
+    for (int p = last_start; p < n; p += 64) {
+      const int kpos = p + (int)lane;
       uint32_t rk[NP];
       if (NP == 2) {
         const uint2 rv = gload_rec2(rec_blk, row_next);

@@ -921,7 +921,7 @@ __device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint
   return t;
 }
 
-template <bool PG>
+template <bool PG, int HI>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
                                                                const bool Fn, const bool valid,
@@ -955,7 +955,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     // keep their new lanes for the rest of the step (group membership per lane is unchanged).
     const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));   // 1..64, non-decreasing over the lanes
     const uint32_t key = valid ? ((xg << 22) | ((0xFFFFu - (q & 0xFFFFu)) << 6) | lane) : 0xFFFFFFFFu;
-    const uint32_t src = (wave_sort_u32(key, lane) & 63u) << 2;            // invalid lanes stay behind the valid ones
+    const uint32_t src = (wave_sort_u32(key, lane) & 63u) << 2;          // invalid lanes stay behind the valid ones
     const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)q);
     const uint32_t lo2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)lo);
     const uint32_t row2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)row);
@@ -1030,7 +1030,13 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     if (list && (F & 1ull) == 0ull) S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
     wave_lds_fence();
     wave_pend_fence<PG>();
-    rebuild_prefix<PG>(S.L.seen, S.L.spre, ((F & 1ull) == 0ull) ? &Pg : nullptr, Wp, items, lane);
+    if ((F & 1ull) == 0ull) {
+      rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+    } else if (HI > 0) {
+      rebuild_prefix<PG>(S.L.seen, S.L.spre, nullptr, Wp, items, lane);
+    } else {  // nothing to merge: the unpredicated rebuild of the hot steps (arrays padded to 64 lanes x items2)
+      rebuild_prefix_long(S.L.seen, S.L.spre, (items + 1) & ~1, lane);
+    }
     if (!Fn) {
       wave_pend_fence<PG>();
       if (tlane) p_or<PG>(Pg, (int)qw, bit);
@@ -1277,7 +1283,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
+      const StepCounts c = pair_step_rest<PG, HI>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
                                               hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }

@@ -896,9 +896,13 @@ struct PairState {
   uint32_t dis, tie, tie2;
 };
 
-// General 64-row step of one pair, after the `seen` query: tie groups of the streamed column, open
-// groups, the last partial step.  Rare on continuous data, so it is a real (noinline) call that takes
-// its state by value and returns the three counter increments: the hot step's registers stay small.
+// General step of one pair on all 64 lanes, after the `seen` query.  k1_pairs cuts steps at tie-group
+// boundaries of the streamed column, so a step is either (a) up to 64 rows of complete groups (F & 1 set, Fn
+// true: nothing stays open) or (b) a piece of one group that is longer than a step (F == 1 with !Fn: its first
+// piece; F == 0: a later piece, the last one when Fn).  The code below also covers an open group that closes
+// in the middle of a step followed by further groups, which that cutting never produces.  Rare on continuous
+// data, so it is a real (noinline) call that takes its state by value and returns the three counter
+// increments: the hot step's registers stay small.
 struct StepCounts { uint32_t dis, tie, tie2; };
 struct StepAcc { WaveLds L; uint32_t dis, tie, tie2; };
 
@@ -1083,7 +1087,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t lane = lane_id();
   const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
-  const int nb = (n + 63) >> 6;
   static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B

@@ -1223,10 +1223,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       else { nact = L; F &= (1ull << L) - 1ull; Fn = true; }
     }
     const int pos_next = pos + nact;
-    {
-      const int wn = pos_next >> 6;
-      fw0 = gf[min(wn, W)];
-      fw1 = gf[min(wn + 1, W)];
+    if ((pos_next >> 6) != (pos >> 6)) {  // the window moves on by one flag word at most (nact <= 64)
+      fw0 = fw1;
+      fw1 = gf[min((pos_next >> 6) + 1, W)];
     }
     const int kpos = pos + (int)lane;
     const bool valid = (int)lane < nact;

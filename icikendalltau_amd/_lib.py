@@ -13,7 +13,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libicikt_hip.so")
+LIB_PATH = os.environ.get("ICIKT_LIB") or os.path.join(_PKG, "libicikt_hip.so")  # ICIKT_LIB: A/B of builds (tools)
 SOURCES = [os.path.join(_PKG, "csrc", "icikt_kernels.hip"), os.path.join(_PKG, "csrc", "icikt_capi.cpp")]
 HEADERS = [os.path.join(_ROOT, "include", "icikt.h"), os.path.join(_PKG, "csrc", "icikt_device.h")]
 

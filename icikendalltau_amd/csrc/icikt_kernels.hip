@@ -925,7 +925,16 @@ __device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint
   return t;
 }
 
-template <bool PG, int HI>
+// prefix rebuild without a merge, out of line: keeps the general step's register footprint (and with it the
+// allocation of the hot loop around its call site) independent of this code
+template <bool PG, bool LONGR>
+__device__ __attribute__((noinline)) void rebuild_nomerge(unsigned long long* bits, uint16_t* pre, int Wp, int items,
+                                                          uint32_t lane) {
+  if (LONGR) rebuild_prefix_long(bits, pre, (items + 1) & ~1, lane);
+  else rebuild_prefix<PG>(bits, pre, nullptr, Wp, items, lane);
+}
+
+template <bool PG, bool LONGR>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
                                                                const bool Fn, const bool valid,
@@ -1036,10 +1045,8 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
     wave_pend_fence<PG>();
     if ((F & 1ull) == 0ull) {
       rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
-    } else if (HI > 0) {
-      rebuild_prefix<PG>(S.L.seen, S.L.spre, nullptr, Wp, items, lane);
-    } else {  // nothing to merge: the unpredicated rebuild of the hot steps (arrays padded to 64 lanes x items2)
-      rebuild_prefix_long(S.L.seen, S.L.spre, (items + 1) & ~1, lane);
+    } else {  // nothing to merge
+      rebuild_nomerge<PG, LONGR>(S.L.seen, S.L.spre, Wp, items, lane);
     }
     if (!Fn) {
       wave_pend_fence<PG>();
@@ -1172,14 +1179,19 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool closed_form = true;
 #pragma unroll
   for (int k = 0; k < NP; ++k) closed_form = closed_form && (ntgB[k] >= 0);
+  int hot_until;  // steps [pos, pos + 64) with pos + 64 <= hot_until hold singleton groups only: no flag work at all
   {
-    int best = 0;
+    int best = 0, first_cont = n;  // highest group start; first position that continues a group
     for (int w = lane; w < W; w += 64) {
       unsigned long long f = gf[w];
-      if (w == W - 1 && (n & 63)) f &= (1ull << (n & 63)) - 1ull;
+      unsigned long long z = ~f;
+      if (w == W - 1 && (n & 63)) { f &= (1ull << (n & 63)) - 1ull; z &= (1ull << (n & 63)) - 1ull; }
       if (f != 0ull) best = max(best, w * 64 + 63 - (int)__builtin_clzll(f));
+      if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
     }
     last_start = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
+    first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
+    hot_until = (first_cont < n) ? first_cont - 1 : n;
     closed_form = closed_form && (n - last_start > 64);
   }
   const int end_main = closed_form ? last_start : n;
@@ -1190,7 +1202,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // group-start flags of its rows, Fn = "the row after the step starts a group".
   uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
   int pos = 0;
-  unsigned long long fw0 = gf[0], fw1 = gf[min(1, W)];  // flag words of the window at pos (gf[W] is a zero guard)
+  unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
+  int fw_word = -1;
   while (pos < end_main) {
     // the step's rec gather first: its latency runs behind the window logic
     const uint32_t row = row_next;
@@ -1202,31 +1215,42 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     } else {
       rk[0] = gload_u32(rec_blk, 2u * row + comp[0]);
     }
-    const int fb = pos & 63;
-    const unsigned long long w0 = uniform_u64(fw0), w1 = uniform_u64(fw1);
-    unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
-    const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
-    const int remaining = end_main - pos;
-    const bool reach_end = remaining <= 64;
-    if (remaining < 64) F &= (1ull << remaining) - 1ull;
     int nact;
     bool Fn;
-    if ((F & 1ull) == 0ull) {                  // inside a group that is longer than a step
-      if (F == 0ull) { nact = reach_end ? remaining : 64; Fn = reach_end || fnbit; }
-      else { nact = (int)__builtin_ctzll(F); F = 0ull; Fn = true; }   // its last piece
-    } else if (reach_end || fnbit) {           // the window ends where a group ends
-      nact = reach_end ? remaining : 64;
-      Fn = true;
-    } else {                                   // the window's last group is incomplete: stop in front of it
-      const int L = 63 - (int)__builtin_clzll(F);
-      if (L == 0) { nact = 64; Fn = false; }   // ... unless it is all there is: a group longer than a step begins
-      else { nact = L; F &= (1ull << L) - 1ull; Fn = true; }
+    unsigned long long F;
+    if (pos + 64 <= hot_until) {
+      nact = 64; Fn = true; F = ~0ull;
+    } else {
+      const int wc = pos >> 6, fb = pos & 63;
+      if (fw_word != wc) {  // first step after the singleton region (or the very first)
+        fw0 = gf[min(wc, W)];
+        fw1 = gf[min(wc + 1, W)];
+        fw_word = wc;
+      }
+      const unsigned long long w0 = uniform_u64(fw0), w1 = uniform_u64(fw1);
+      F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+      const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
+      const int remaining = end_main - pos;
+      const bool reach_end = remaining <= 64;
+      if (remaining < 64) F &= (1ull << remaining) - 1ull;
+      if ((F & 1ull) == 0ull) {                  // inside a group that is longer than a step
+        if (F == 0ull) { nact = reach_end ? remaining : 64; Fn = reach_end || fnbit; }
+        else { nact = (int)__builtin_ctzll(F); F = 0ull; Fn = true; }   // its last piece
+      } else if (reach_end || fnbit) {           // the window ends where a group ends
+        nact = reach_end ? remaining : 64;
+        Fn = true;
+      } else {                                   // the window's last group is incomplete: stop in front of it
+        const int L = 63 - (int)__builtin_clzll(F);
+        if (L == 0) { nact = 64; Fn = false; }   // ... unless it is all there is: a group longer than a step begins
+        else { nact = L; F &= (1ull << L) - 1ull; Fn = true; }
+      }
+      if (((pos + nact) >> 6) != wc) {  // the window moves on by one flag word at most (nact <= 64)
+        fw0 = fw1;
+        fw1 = gf[min(((pos + nact) >> 6) + 1, W)];
+        fw_word = (pos + nact) >> 6;
+      }
     }
     const int pos_next = pos + nact;
-    if ((pos_next >> 6) != (pos >> 6)) {  // the window moves on by one flag word at most (nact <= 64)
-      fw0 = fw1;
-      fw1 = gf[min((pos_next >> 6) + 1, W)];
-    }
     const int kpos = pos + (int)lane;
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
@@ -1285,7 +1309,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG, HI>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
+      const StepCounts c = pair_step_rest<PG, (HI == 0)>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
                                               hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }

@@ -264,6 +264,31 @@ def test_api_through_hip_engine(hip_ctx, golden_dir, expected):
         api.ici_kt(np.arange(10.0), np.ones(10))
 
 
+def test_c5_shape_include_only_subset(hip_ctx):
+    """Config c5's shape at a column count the oracle finishes in seconds: n = 50 000, 1 000 smallest values per
+    column missing, include_only = the first four names (vector form: every pair with one of them),
+    perspective local and global, plus pairwise_completeness on the same subset."""
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+    rng = np.random.default_rng(5)
+    n, S = 50000, 40
+    X = rng.standard_normal((n, S))
+    idx = np.argpartition(X, 1000, axis=0)[:1000]
+    np.put_along_axis(X, idx, np.nan, axis=0)
+    names = [f"s{i}" for i in range(S)]
+    for persp in ("global", "local"):
+        g = api.ici_kendalltau(X, colnames=names, include_only=names[:4], perspective=persp, return_matrix=False)["cor"]
+        o = api.ici_kendalltau(X, colnames=names, include_only=names[:4], perspective=persp, return_matrix=False,
+                               engine=OracleEngine())["cor"]
+        assert len(g) == 4 * (S - 1) - 6 + S and list(g["s1"]) == list(o["s1"]) and list(g["s2"]) == list(o["s2"])
+        for k in ("raw", "pvalue", "taumax", "completeness", "cor"):
+            assert np.nanmax(np.abs(g[k].to_numpy() - o[k].to_numpy())) <= ATOL, (persp, k)
+    pc_g = api.pairwise_completeness(X, colnames=names, include_only=names[:4], return_matrix=False)
+    pc_o = api.pairwise_completeness(X, colnames=names, include_only=names[:4], return_matrix=False, engine=OracleEngine())
+    assert np.array_equal(pc_g["missingness"].to_numpy(), pc_o["missingness"].to_numpy())
+    assert np.allclose(pc_g["completeness"].to_numpy(), pc_o["completeness"].to_numpy(), rtol=0, atol=1e-15)
+
+
 @pytest.mark.parametrize("np_", ["1", "2"])
 def test_pairs_per_wave_variants(hip_ctx, np_, monkeypatch):
     """K1 launch plans: one pair per wave or two (one per half); odd run lengths leave partly filled waves."""

@@ -16,7 +16,7 @@ struct ColStats {
   int32_t nna;       // missing rows
   int32_t ngroups;   // distinct values after the fill (unique(), kendallc.cpp:234-235)
   int32_t tfill;     // size of the fill group (missing rows + rows equal to min-0.1); 0 if nna == 0
-  int32_t maxgroup;  // largest tie group
+  int32_t maxgroup;  // largest tie group: size << 16 | its first ascending position
   uint32_t s0, s1, s2;  // count_rank_tie sums in wrapping int32: t(t-1), t(t-1)(t-2), t(t-1)(2t+5)
   uint32_t ntg;      // tie groups of size >= 2 (length of the column's tgroups list)
   long long e0, e1, e2;  // the same sums exactly

@@ -401,7 +401,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
       const int t = hi - lo + 1;
       ++ngroups;
       if (t >= 2) ++ntg_local;
-      maxgroup = max(maxgroup, t);
+      maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
       if (lo == 0) tfill = t;
       if (t >= 2) {
         const uint32_t ut = (uint32_t)t;
@@ -456,7 +456,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   }
   const int ntg = block_reduce<int>(ntg_local, sh_i, [](int a, int b) { return a + b; });
   ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });
-  maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return a > b ? a : b; });
+  maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; });
   tfill = block_reduce<int>(tfill, sh_i, [](int a, int b) { return a > b ? a : b; });
   s0 = (uint32_t)block_reduce<int>((int)s0, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
   s1 = (uint32_t)block_reduce<int>((int)s1, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
@@ -1504,9 +1504,27 @@ k2_epilogue(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restri
         tie_terms32(sy.tfill, a0, a1, a2); tie_terms32((int)(sy.tfill - shrink), b0, b1, b2);
         ytie = (double)((int32_t)(sy.s0 - a0 + b0) / 2); y0 = (double)((int32_t)(sy.s1 - a1 + b1) / 2);
         y1 = (double)(int32_t)(sy.s2 - a2 + b2);
-        // sum((cnt * (cnt - 1)) / 2) in int32 (:267): only a cell of >= 46342 rows can wrap
+        // sum((cnt * (cnt - 1)) / 2) in int32 (:267): only a cell of >= 46342 rows can wrap, and a pair has at
+        // most one (n <= 65535).  It is the cell of the two columns' largest tie groups: the (fill, fill) cell is
+        // known (g); any other one is counted here, row by row -- both columns must have a group that large, rare
         const int32_t cell = (g2 >= 2) ? ((int32_t)((uint32_t)g2 * (uint32_t)(g2 - 1)) / 2) : 0;
-        ntie = (double)(int32_t)((uint32_t)others + (uint32_t)cell);
+        long long rest = others;
+        int32_t cell2 = 0;
+        const int mgx = (int)((uint32_t)sx.maxgroup >> 16), mgy = (int)((uint32_t)sy.maxgroup >> 16);
+        const uint32_t lbx = (uint32_t)sx.maxgroup & 0xFFFFu, lby = (uint32_t)sy.maxgroup & 0xFFFFu;
+        const bool fill_fill = (sx.nna > 0 && lbx == 0u) && (sy.nna > 0 && lby == 0u);
+        if (mgx >= 46342 && mgy >= 46342 && !fill_fill) {
+          const int cx = pi[p], cy = pj[p];
+          const uint32_t* rx = pv.rec + ((int64_t)(cx >> 1) * pv.n_pad) * 2 + (cx & 1);
+          const uint32_t* ry = pv.rec + ((int64_t)(cy >> 1) * pv.n_pad) * 2 + (cy & 1);
+          long long c = 0;
+          for (int r = 0; r < pv.n; ++r) c += ((rx[2 * r] >> 16) == lbx && (ry[2 * r] >> 16) == lby) ? 1 : 0;
+          if (c >= 46342) {
+            rest -= c * (c - 1) / 2;
+            cell2 = (int32_t)((uint32_t)c * (uint32_t)(c - 1)) / 2;
+          }
+        }
+        ntie = (double)(int32_t)((uint32_t)rest + (uint32_t)cell + (uint32_t)cell2);
       }
       const long long dis = (long long)rw.dis;  // both-missing rows are never discordant
       const long long tot = ne * (ne - 1) / 2;                                // :280

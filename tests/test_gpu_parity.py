@@ -349,6 +349,23 @@ def test_max_length_65535(hip_ctx):
         hip_ctx.pair(np.zeros(65536), np.zeros(65536))
 
 
+def test_int32_wrap_of_a_large_joint_cell(hip_ctx):
+    """Q2 at its far end: a joint (x group, y group) cell of >= 46 342 rows makes the reference's int32
+    cnt * (cnt - 1) wrap in `ntie`.  The (fill, fill) cell, a (value, fill) cell and a (value, value) cell,
+    against the oracle's int32 and exact modes."""
+    rng = np.random.default_rng(71)
+    n = 60000
+    big = rng.permutation(n)[:50000]
+    X = rng.standard_normal((n, 4))
+    X[big, 0] = 1.25            # one value 50 000 times
+    X[big[:48000], 1] = np.nan  # 48 000 missing, all inside column 0's big group: a (value, fill) cell
+    X[big[:47000], 2] = -3.0    # (value, value) cell with column 0
+    X[big[:49000], 3] = np.nan  # with column 1: a (fill, fill) cell of 48 000 rows
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p, flags=0)
+        _check(hip_ctx, X, perspective=p, flags=1)
+
+
 def test_int32_wrap_regime_matches_oracle(hip_ctx):
     """Q2: tie groups >= 1024 rows make the reference's int32 tie sums wrap; default mode reproduces the
     wrap, ICIKT_FLAG_EXACT_INT64 does not (both against the oracle's two modes)."""

@@ -87,10 +87,6 @@ def one_case(ctx, rng, case):
         else:
             os.environ.pop(k, None)
     flags = int(rng.random() < 0.25)  # exact int64 sums
-    if n >= 46342:
-        # documented gap of the int32-compat mode: a joint cell of >= 46 342 rows outside the
-        # (fill, fill) cell wraps in the reference's int32 element and is computed exactly here; compare exact sums
-        flags = 1
     persp = rng.choice(["global", "local"])
     alt = rng.choice(["two.sided", "less", "greater"])
     cont = bool(rng.random() < 0.3)

@@ -721,9 +721,9 @@ int icikt_selftest(icikt_ctx* c) {
   if (!c) return ICIKT_E_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
-  HIPCHK(c, c->d_self.reserve(448));
+  HIPCHK(c, c->d_self.reserve(576));
   HIPCHK(c, icikt::launch_selftest(c->d_self.p, c->stream));
-  uint32_t h[448];
+  uint32_t h[576];
   HIPCHK(c, hipMemcpyAsync(h, c->d_self.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (uint32_t l = 0; l < 64; ++l) {
@@ -734,6 +734,16 @@ int icikt_selftest(icikt_ctx* c) {
     if (h[320 + l] != (l < 32 ? 32u + l : 100u + l)) return fail(c, ICIKT_E_HIP, "selftest: permlane32_swap[1] mismatch");
     const uint32_t k = (l & 31u) + 1, b = (l & 32u) + 1;  // sum of (lane+1) over my half up to me
     if (h[384 + l] != k * (2 * b + k - 1) / 2) return fail(c, ICIKT_E_HIP, "selftest: half_incl_scan mismatch");
+    if (h[448 + l] != 63u) {
+      if (getenv("ICIKT_DEBUG_PLAN")) fprintf(stderr, "[icikt] selftest lane %u: lane_xor pass mask %u\n", l, h[448 + l]);
+      return fail(c, ICIKT_E_HIP, "selftest: lane_xor mismatch");
+    }
+    if (l > 0 && h[512 + l] < h[512 + l - 1]) return fail(c, ICIKT_E_HIP, "selftest: wave_sort_u32 not sorted");
+  }
+  {  // the sort is a permutation of its input
+    unsigned long long want = 0, got = 0;
+    for (uint32_t l = 0; l < 64; ++l) { want += (l * 2654435761u) >> 8; got += h[512 + l]; }
+    if (want != got) return fail(c, ICIKT_E_HIP, "selftest: wave_sort_u32 lost values");
   }
   // half-wave all-pairs: per 32-lane half, #{(a, j): a before j, q_a < lo_j}; the lanes' shares are summed
   for (uint32_t half = 0; half < 2; ++half) {

@@ -875,18 +875,45 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
   for (int i = 1; i < HI; ++i) pre[base + i] = (uint16_t)(excl + c[i - 1]);
 }
 
-// ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages)
-__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t other = (uint32_t)__shfl_xor((int)v, j, 64);
-      const bool up = (lane & (uint32_t)k) == 0u;       // k == 64: every lane
-      const bool lower = (lane & (uint32_t)j) == 0u;
-      v = (lower == up) ? min(v, other) : max(v, other);
-    }
+// value of lane ^ J for J = 1, 2, 4, 8, 16, 32 without LDS: quad_perm for 1 and 2, row_shl / row_shr 4 with a
+// select, row_ror:8 (inside a 16-lane row rotating by 8 IS xor 8), v_permlane16_swap / v_permlane32_swap of two
+// copies for 16 and 32.  Every DPP runs with all lanes active; the selects come afterwards.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
+  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false);
+  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, false);
+  if (J == 4) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /*row_shl:4*/, 0xf, 0xf, false);
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+    return (lane & 4u) ? dn : up;
   }
+  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+  if (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+    return (lane & 16u) ? r[0] : r[1];
+  }
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // r[0] = halves [lo, lo], r[1] = [hi, hi]
+  return (lane & 32u) ? r[0] : r[1];
+}
+
+// ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages, no LDS)
+template <int K, int J>
+__device__ __forceinline__ uint32_t wave_sort_stage(uint32_t v, uint32_t lane) {
+  const uint32_t other = lane_xor<J>(v, lane);
+  const bool up = (lane & (uint32_t)K) == 0u;  // K == 64: every lane
+  const bool lower = (lane & (uint32_t)J) == 0u;
+  return (lower == up) ? min(v, other) : max(v, other);
+}
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t v, uint32_t lane) {
+  v = wave_sort_stage<2, 1>(v, lane);
+  v = wave_sort_stage<4, 2>(v, lane); v = wave_sort_stage<4, 1>(v, lane);
+  v = wave_sort_stage<8, 4>(v, lane); v = wave_sort_stage<8, 2>(v, lane); v = wave_sort_stage<8, 1>(v, lane);
+  v = wave_sort_stage<16, 8>(v, lane); v = wave_sort_stage<16, 4>(v, lane); v = wave_sort_stage<16, 2>(v, lane);
+  v = wave_sort_stage<16, 1>(v, lane);
+  v = wave_sort_stage<32, 16>(v, lane); v = wave_sort_stage<32, 8>(v, lane); v = wave_sort_stage<32, 4>(v, lane);
+  v = wave_sort_stage<32, 2>(v, lane); v = wave_sort_stage<32, 1>(v, lane);
+  v = wave_sort_stage<64, 32>(v, lane); v = wave_sort_stage<64, 16>(v, lane); v = wave_sort_stage<64, 8>(v, lane);
+  v = wave_sort_stage<64, 4>(v, lane); v = wave_sort_stage<64, 2>(v, lane); v = wave_sort_stage<64, 1>(v, lane);
   return v;
 }
 
@@ -1607,6 +1634,15 @@ __global__ void k_selftest(uint32_t* out) {
   out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)
   out[320 + lane] = sw[1];                                     // lanes < 32: 32 + lane, else 100 + lane
   out[384 + lane] = half_incl_scan(lane + 1u);
+  // lane_xor<J>(lane * 5 + 1) must be (lane ^ J) * 5 + 1 for every J; packed as a 6-bit pass mask
+  const uint32_t t5 = lane * 5u + 1u;
+  out[448 + lane] = (lane_xor<1>(t5, lane) == ((lane ^ 1u) * 5u + 1u) ? 1u : 0u) |
+                    (lane_xor<2>(t5, lane) == ((lane ^ 2u) * 5u + 1u) ? 2u : 0u) |
+                    (lane_xor<4>(t5, lane) == ((lane ^ 4u) * 5u + 1u) ? 4u : 0u) |
+                    (lane_xor<8>(t5, lane) == ((lane ^ 8u) * 5u + 1u) ? 8u : 0u) |
+                    (lane_xor<16>(t5, lane) == ((lane ^ 16u) * 5u + 1u) ? 16u : 0u) |
+                    (lane_xor<32>(t5, lane) == ((lane ^ 32u) * 5u + 1u) ? 32u : 0u);
+  out[512 + lane] = wave_sort_u32((lane * 2654435761u) >> 8, lane);  // the host checks the sequence is sorted
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -740,7 +740,8 @@ __device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, 
 //    16.  An upper lane asks "lo_me > q_l" of 8 lower lanes; a lower lane asks the same question about
 //    itself, "lo_u > q_me", of the other 8 upper lanes, as "~q_me > ~lo_u" so that the same instruction
 //    serves both.  xa holds what a lane's DPP sources offer (upper lanes: the lower row's q; lower lanes: the
-//    upper row's ~lo rotated by one position), xb = what the lane compares with (upper: lo, lower: ~q); with
+//    upper row's ~lo rotated by one position; half_count builds it), xb = what the lane compares with (upper: lo,
+//    lower: ~q); with
 //    row_ror:0..7 (lane p reads p - r) the upper lanes cover (lower - upper) mod 16 in {0, 15, .., 9} and
 //    the lower lanes {1, .., 8}.
 // 23 subtract-with-borrow + 23 add-with-carry per 32 rows of a pair.
@@ -765,16 +766,16 @@ __device__ __forceinline__ uint32_t half_allpairs(uint32_t q, uint32_t lo, uint3
   return acc - ((lo != 0u) ? (15u - (lane & 15u)) : 0u);
 }
 
-// ds_bpermute byte index of the lane whose `offer` a lane reads for the cross-row compares: upper row <- same
-// position of the lower row, lower row <- the upper row rotated by one
-__device__ __forceinline__ uint32_t half_cross_idx(uint32_t lane) {
-  return ((lane & 16u) ? lane - 16u : ((lane & 32u) | 16u | ((lane - 1u) & 15u))) << 2;
-}
 // per-lane share of #{rows a before row j in the same 32-lane half : q_a < lo_j}; only the sum over the half
 // is meaningful (lower-row lanes carry part of the upper row's counts)
-__device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t lane, uint32_t cross_idx) {
+__device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t lane) {
   const uint32_t offer = (lane & 16u) ? ~lo : q;
-  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)cross_idx, (int)offer);
+  // the rows of a half exchanged in registers (the LDS is the busiest unit of this kernel): v_permlane16_swap
+  // of two copies gives r[0] = the lower rows' offers in both rows, r[1] = the upper rows'; the lower rows read
+  // the upper row rotated by one position
+  const auto r = __builtin_amdgcn_permlane16_swap(offer, offer, false, false);
+  const uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[1], 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+  const uint32_t xa = (lane & 16u) ? r[0] : rot;
   return half_allpairs(q, lo, xa, ~offer, lane);
 }
 
@@ -1294,13 +1295,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
       uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
       const uint32_t l32 = lane & 31u;
-      const uint32_t cross_idx = half_cross_idx(lane);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const uint32_t r = sub ? sw[1] : sw[0];
         const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
         const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
-        dis_half += cnt + half_count(qh, loh, lane, cross_idx);
+        dis_half += cnt + half_count(qh, loh, lane);
         wave_lds_fence();
         seen_insert(seenH, qh);
         wave_lds_fence();
@@ -1629,7 +1629,7 @@ __global__ void k_selftest(uint32_t* out) {
   out[128 + lane] = v;                                         // lanes < 41: ~0, else lane-41
   // half-wave pieces: q, lo from a fixed pseudo-random table; the host recomputes the counts
   const uint32_t q = (lane * 2654435761u >> 20) & 0xFFFu, lo = ((lane * 40503u + 977u) >> 3) & 0xFFFu;
-  out[192 + lane] = half_count(q, lo, lane, half_cross_idx(lane));  // summed per half by the host
+  out[192 + lane] = half_count(q, lo, lane);  // summed per half by the host
   const auto sw = __builtin_amdgcn_permlane32_swap(lane, 100u + lane, false, false);
   out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)
   out[320 + lane] = sw[1];                                     // lanes < 32: 32 + lane, else 100 + lane

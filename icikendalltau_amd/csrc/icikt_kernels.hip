@@ -120,10 +120,31 @@ __device__ T block_reduce(T v, T* scratch, Op op) {
   return r;
 }
 
+// value of lane ^ J for J = 1, 2, 4, 8, 16, 32 without LDS: quad_perm for 1 and 2, row_shl / row_shr 4 with a
+// select, row_ror:8 (inside a 16-lane row rotating by 8 IS xor 8), v_permlane16_swap / v_permlane32_swap of two
+// copies for 16 and 32.  Every DPP runs with all lanes active; the selects come afterwards.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
+  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false);
+  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, false);
+  if (J == 4) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /*row_shl:4*/, 0xf, 0xf, false);
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+    return (lane & 4u) ? dn : up;
+  }
+  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+  if (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+    return (lane & 16u) ? r[0] : r[1];
+  }
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // r[0] = halves [lo, lo], r[1] = [hi, hi]
+  return (lane & 32u) ? r[0] : r[1];
+}
+
 // ---- bitonic stages held in registers ---------------------------------------------------------------
 // With a full tile (4096 elements, 1024 threads) thread t owns elements 4t..4t+3: compare-exchange distances
-// 1 and 2 stay inside the thread, distances 4..128 pair it with lane t ^ (j / 4) of its own wave (shuffles,
-// no LDS memory, no barrier); only distances >= 256 need the LDS tile and a workgroup barrier.  Of the 78
+// 1 and 2 stay inside the thread, distances 4..128 pair it with lane t ^ (j / 4) of its own wave (DPP and
+// permlane exchanges: no LDS, no barrier); only distances >= 256 need the LDS tile and a workgroup barrier.  Of the 78
 // stages of a tile sort 68 run this way.
 __device__ __forceinline__ bool kv_gt(unsigned long long ka, uint32_t ia, unsigned long long kb, uint32_t ib) {
   return (ka > kb) || (ka == kb && ia > ib);
@@ -131,18 +152,21 @@ __device__ __forceinline__ bool kv_gt(unsigned long long ka, uint32_t ia, unsign
 // stages j = jmax .. 1 (jmax <= 128) of merge step k; gi = global index of the thread's first element
 __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint32_t (&ei)[4], int k, int jmax,
                                               int gi, int tid) {
-  for (int j = jmax; j >= 4; j >>= 1) {
-    const int lx = j >> 2;
-    const bool lower = (tid & lx) == 0;
-    const bool up = (gi & k) == 0;       // k >= 8 here: the same for the thread's four elements
-    const bool want_gt = (lower == up);  // take the partner's element when (mine > theirs) == want_gt
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned long long ok = __shfl_xor(ek[r], lx, 64);
-      const uint32_t oi = (uint32_t)__shfl_xor((int)ei[r], lx, 64);
-      if (kv_gt(ek[r], ei[r], ok, oi) == want_gt) { ek[r] = ok; ei[r] = oi; }
-    }
+  const uint32_t lane = (uint32_t)tid & 63u;
+  const bool up48 = (gi & k) == 0;  // k >= 8 in these stages: the same for the thread's four elements
+  // one stage: partner lane = lane ^ LX (element distance 4 * LX), exchanged in registers (lane_xor: DPP / permlane)
+#define ICIKT_K0_XSTAGE(LX)                                                                              \
+  if (jmax >= 4 * (LX)) {                                                                                \
+    const bool want_gt = (((tid & (LX)) == 0) == up48); /* take the partner's when (mine > theirs) == want_gt */ \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
+      const uint32_t klo = lane_xor<(LX)>((uint32_t)ek[r], lane), khi = lane_xor<(LX)>((uint32_t)(ek[r] >> 32), lane); \
+      const uint32_t oi = lane_xor<(LX)>(ei[r], lane);                                                   \
+      const unsigned long long ok = (unsigned long long)klo | ((unsigned long long)khi << 32);           \
+      if (kv_gt(ek[r], ei[r], ok, oi) == want_gt) { ek[r] = ok; ei[r] = oi; }                            \
+    }                                                                                                    \
   }
+  ICIKT_K0_XSTAGE(32) ICIKT_K0_XSTAGE(16) ICIKT_K0_XSTAGE(8) ICIKT_K0_XSTAGE(4) ICIKT_K0_XSTAGE(2) ICIKT_K0_XSTAGE(1)
+#undef ICIKT_K0_XSTAGE
 #define ICIKT_CE(a, b, upv)                                                          \
   {                                                                                  \
     if (kv_gt(ek[a], ei[a], ek[b], ei[b]) == (upv)) {                                \
@@ -874,27 +898,6 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
   pre[base] = (uint16_t)excl;
 #pragma unroll
   for (int i = 1; i < HI; ++i) pre[base + i] = (uint16_t)(excl + c[i - 1]);
-}
-
-// value of lane ^ J for J = 1, 2, 4, 8, 16, 32 without LDS: quad_perm for 1 and 2, row_shl / row_shr 4 with a
-// select, row_ror:8 (inside a 16-lane row rotating by 8 IS xor 8), v_permlane16_swap / v_permlane32_swap of two
-// copies for 16 and 32.  Every DPP runs with all lanes active; the selects come afterwards.
-template <int J>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
-  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false);
-  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, false);
-  if (J == 4) {
-    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /*row_shl:4*/, 0xf, 0xf, false);
-    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
-    return (lane & 4u) ? dn : up;
-  }
-  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
-  if (J == 16) {
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
-    return (lane & 16u) ? r[0] : r[1];
-  }
-  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // r[0] = halves [lo, lo], r[1] = [hi, hi]
-  return (lane & 32u) ? r[0] : r[1];
 }
 
 // ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages, no LDS)

@@ -512,7 +512,12 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
 // of 104 KB) and rebuild the rest locally.  One workgroup per column: wave 0 scans the flag words, then the
 // waves take the 64-position steps in turn.
 constexpr int KX_WAVES = 4;
-__global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_begin, int ncols) {
+__global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_begin, int ncols, int staged) {
+  // staged: the scattered per-row writes go to an LDS copy of the column's rec / hirow first and leave as
+  // sequential stores (dynamic LDS: n_pad * 6 bytes; the host stages columns of up to 16 384 rows)
+  extern __shared__ __attribute__((aligned(16))) unsigned char kx_stage[];
+  uint32_t* rec_s = reinterpret_cast<uint32_t*>(kx_stage);
+  uint16_t* hi_s = reinterpret_cast<uint16_t*>(kx_stage + (size_t)pv.n_pad * 4);
   __shared__ int prevs[1032];   // highest group start in the words before w (-1: none)
   __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
@@ -583,12 +588,20 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     const int e = ((above != 0ull) ? w * 64 + (int)__builtin_ctzll(above) : nexts[w]) - 1;
     const uint32_t row = ord[k];
     const uint32_t lo = (uint32_t)(n - 1 - e), hi = (uint32_t)(n - 1 - s);
-    rec[2 * row] = (uint32_t)(n - 1 - k) | (lo << 16);
-    hirow[row] = (uint16_t)hi;
+    const uint32_t rv = (uint32_t)(n - 1 - k) | (lo << 16);
+    if (staged) { rec_s[row] = rv; hi_s[row] = (uint16_t)hi; }
+    else { rec[2 * row] = rv; hirow[row] = (uint16_t)hi; }
     if (k == s && e > s) {
       // tgroups is ascending in lo: groups that start after me (descending) come first
       const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
       tgl[i] = lo | (hi << 16);
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    for (int r = (int)threadIdx.x; r < n; r += 64 * KX_WAVES) {
+      rec[2 * r] = rec_s[r];
+      hirow[r] = hi_s[r];
     }
   }
 }
@@ -1714,7 +1727,13 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
 
 hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s) {
   if (ncols <= 0 || pv.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k0_expand, dim3(ncols), dim3(64 * KX_WAVES), 0, s, pv, col_begin, ncols);
+  const int staged = (pv.n_pad <= 16384) ? 1 : 0;
+  const size_t lds = staged ? (size_t)pv.n_pad * 6 : 0;
+  if (staged) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0_expand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k0_expand, dim3(ncols), dim3(64 * KX_WAVES), lds, s, pv, col_begin, ncols, staged);
   return hipGetLastError();
 }
 

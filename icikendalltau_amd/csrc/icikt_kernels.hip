@@ -190,8 +190,11 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   __shared__ long long sh_ll[K0_THREADS];
   __shared__ int sh_i[K0_THREADS];
   __shared__ unsigned long long sh_bits[1024];  // fill-group bitset, W <= 1024 words
-  __shared__ unsigned long long sh_tk[K0_TILE];  // sort tile: keys
-  __shared__ uint32_t sh_ti[K0_TILE];            // sort tile: row indices
+  __shared__ unsigned long long sh_sort[K0_TILE + K0_TILE / 2];  // 48 KB: the sort tile, later the rec staging area
+  unsigned long long* sh_tk = sh_sort;                                      // sort tile: keys
+  uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + K0_TILE);         // sort tile: row indices
+  uint32_t* rec_s = reinterpret_cast<uint32_t*>(sh_sort);                   // after the sort: rec by row
+  const bool stage_rec = pv.n_pad <= 3 * K0_TILE;                           // 12 288 rows x 4 B fit
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -418,7 +421,9 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     const int lo = run_lo;
     const uint32_t row = idx[k];
     const int hi = (int)hirow[row];  // written by this thread above
-    rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
+    // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
+    if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
+    else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
     order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
     if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
     if (st) {
@@ -441,6 +446,9 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     }
   }
   __syncthreads();
+  if (stage_rec) {
+    for (int r = tid; r < n; r += K0_THREADS) rec[2 * r] = rec_s[r];
+  }
 
   // group-start flags in PROCESSING order k' = n-1-k: a group starts at k' where it ends at k
   for (int base = 0; base < pv.n_pad; base += K0_THREADS) {

@@ -28,8 +28,8 @@ FLAG_TIMING = 2
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
 MAX_FEATURES = 65535
-PREP_ARRAYS = 8
-PREP_EXCHANGE = (0, 3, 4, 5, 6)  # order, mask, fillmask, gflag, stats: the rest is rebuilt by expand_cols_dev()
+PREP_ARRAYS = 5  # order, rec, hirow, meta (bitsets + stats per column), tgroups
+PREP_EXCHANGE = (0, 3)  # order and meta: the rest is rebuilt by expand_cols_dev()
 
 REASON_OK, REASON_ALL_MISSING, REASON_SHORT, REASON_SINGLE_UNIQUE, REASON_TIES_EQ_TOTAL = range(5)
 REASON_WARNINGS = {

@@ -59,9 +59,8 @@ struct icikt_ctx {
   PrepView pv{};
   DevBuf<uint16_t> order, hirow;
   DevBuf<uint32_t> rec, tgroups;
-  DevBuf<unsigned long long> mask, fillmask, gflag, sort_keys;
+  DevBuf<unsigned long long> meta, sort_keys;
   DevBuf<uint32_t> sort_idx;
-  DevBuf<ColStats> stats;
   int sort_chunk = 0;
   int64_t alloc_cols = 0;  // columns the prepared-state arrays are allocated for (>= n_samp)
 
@@ -330,8 +329,8 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->order.release(); c->hirow.release(); c->rec.release(); c->mask.release(); c->fillmask.release();
-  c->gflag.release(); c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release(); c->stats.release();
+  c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
+  c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release();
   c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -401,10 +400,8 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   HIPCHK(c, c->order.reserve(S * pv.n_ord));
   HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
   HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
-  HIPCHK(c, c->mask.reserve(S * pv.Wp));
-  HIPCHK(c, c->fillmask.reserve(S * pv.Wp));
-  HIPCHK(c, c->gflag.reserve(S * pv.Wp));
-  HIPCHK(c, c->stats.reserve(S));
+  pv.mstride = 3 * pv.Wp + (int)(sizeof(ColStats) / 8);
+  HIPCHK(c, c->meta.reserve(S * (size_t)pv.mstride));
   pv.tg_stride = pv.n_pad / 2 + 1;
   HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
   // sort scratch: bounded to ~1 GiB
@@ -414,8 +411,8 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   c->sort_chunk = (int)chunk;
 
   pv.order = c->order.p; pv.hirow = c->hirow.p; pv.rec = c->rec.p;
-  pv.mask = c->mask.p; pv.fillmask = c->fillmask.p; pv.gflag = c->gflag.p;
-  pv.stats = c->stats.p; pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
+  pv.meta = c->meta.p;
+  pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;
   c->pv = pv;
   c->alloc_cols = (int64_t)S;
@@ -423,7 +420,8 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   rc = timer_begin(c, ICIKT_K_PREPARE, flags);
   if (rc) return rc;
   if (col_end > col_begin)
-    HIPCHK(c, hipMemsetAsync(c->stats.p + col_begin, 0, (size_t)(col_end - col_begin) * sizeof(ColStats), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
+                             (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), c->stream));
   if (n_feat > 0) {
     for (int64_t c0 = col_begin; c0 < col_end; c0 += (int64_t)chunk) {
       const int nc = (int)std::min<int64_t>((int64_t)chunk, col_end - c0);
@@ -465,11 +463,8 @@ int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
   ptrs[0] = pv.order;    bytes_per_col[0] = (int64_t)pv.n_ord * 2;
   ptrs[1] = pv.rec;      bytes_per_col[1] = (int64_t)pv.n_pad * 4;
   ptrs[2] = pv.hirow;    bytes_per_col[2] = (int64_t)pv.n_pad * 2;
-  ptrs[3] = pv.mask;     bytes_per_col[3] = (int64_t)pv.Wp * 8;
-  ptrs[4] = pv.fillmask; bytes_per_col[4] = (int64_t)pv.Wp * 8;
-  ptrs[5] = pv.gflag;    bytes_per_col[5] = (int64_t)pv.Wp * 8;
-  ptrs[6] = pv.stats;    bytes_per_col[6] = (int64_t)sizeof(ColStats);
-  ptrs[7] = pv.tgroups;  bytes_per_col[7] = (int64_t)pv.tg_stride * 4;
+  ptrs[3] = pv.meta;     bytes_per_col[3] = (int64_t)pv.mstride * 8;
+  ptrs[4] = pv.tgroups;  bytes_per_col[4] = (int64_t)pv.tg_stride * 4;
   return ICIKT_SUCCESS;
 }
 

@@ -32,6 +32,8 @@ struct PairRaw {
 };
 
 // Device pointers + sizes of the prepared matrix (HBM layout).
+static_assert(sizeof(ColStats) == 64, "ColStats is 8 words of a column's meta record");
+
 struct PrepView {
   int n;       // n_feat (rows per column)
   int n_pad;   // n rounded up to a multiple of 64
@@ -46,10 +48,19 @@ struct PrepView {
                      // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
   uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
   // per column, stride Wp
-  unsigned long long* mask;      // [S][Wp] missing rows
-  unsigned long long* fillmask;  // [S][Wp] rows in the fill group
-  unsigned long long* gflag;     // [S][Wp] bit k: processing position k starts a tie group
-  ColStats* stats;               // [S]
+  // per column one record of mstride = 3 * Wp + 8 words (one array: one collective moves it between ranks):
+  //   [Wp] mask      missing rows
+  //   [Wp] fillmask  rows in the fill group
+  //   [Wp] gflag     bit k: processing position k starts a tie group
+  //   [8]  ColStats
+  unsigned long long* meta;
+  int mstride;
+  __host__ __device__ unsigned long long* col_mask(int c) const { return meta + (int64_t)c * mstride; }
+  __host__ __device__ unsigned long long* col_fillmask(int c) const { return meta + (int64_t)c * mstride + Wp; }
+  __host__ __device__ unsigned long long* col_gflag(int c) const { return meta + (int64_t)c * mstride + 2 * Wp; }
+  __host__ __device__ ColStats* col_stats(int c) const {
+    return reinterpret_cast<ColStats*>(meta + (int64_t)c * mstride + 3 * Wp);
+  }
   uint32_t* tgroups;             // [S][tg_stride] tie groups (size >= 2), ascending: lo | hi << 16
   int tg_stride;                 // n_pad / 2 + 1
   // sort scratch (per column of the current chunk)

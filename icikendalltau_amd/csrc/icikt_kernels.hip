@@ -205,9 +205,9 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   const double* col = X + (int64_t)c * ld;
   unsigned long long* keys = pv.sort_keys + (int64_t)blockIdx.x * npow2;
   uint32_t* idx = pv.sort_idx + (int64_t)blockIdx.x * npow2;
-  unsigned long long* mask = pv.mask + (int64_t)c * pv.Wp;
-  unsigned long long* fmask = pv.fillmask + (int64_t)c * pv.Wp;
-  unsigned long long* gflag = pv.gflag + (int64_t)c * pv.Wp;
+  unsigned long long* mask = pv.col_mask(c);
+  unsigned long long* fmask = pv.col_fillmask(c);
+  unsigned long long* gflag = pv.col_gflag(c);
   uint16_t* order = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
   uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
@@ -506,7 +506,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     st.s0 = s0; st.s1 = s1; st.s2 = s2; st.ntg = (uint32_t)ntg;
     st.e0 = e0; st.e1 = e1; st.e2 = e2;
     st.fill = fill;
-    pv.stats[c] = st;
+    *pv.col_stats(c) = st;
   }
 }
 
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   const int lane = (int)(threadIdx.x & 63);
   const int c = col_begin + (int)blockIdx.x;
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
-  const unsigned long long* gf = pv.gflag + (int64_t)c * Wp;
+  const unsigned long long* gf = pv.col_gflag(c);
   const uint16_t* ord = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
   uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
@@ -1162,9 +1162,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // streamed column (shared by the task's pairs): rows in descending order, group-start flags
   const int scol = __builtin_amdgcn_readfirstlane(pj[pidx[0]]);
   const uint16_t* ord = pv.order + (int64_t)scol * pv.n_ord;
-  const unsigned long long* gf = pv.gflag + (int64_t)scol * Wp;
-  const unsigned long long* ma = pv.mask + (int64_t)scol * Wp;
-  const unsigned long long* fa = pv.fillmask + (int64_t)scol * Wp;
+  const unsigned long long* gf = pv.col_gflag(scol);
+  const unsigned long long* ma = pv.col_mask(scol);
+  const unsigned long long* fa = pv.col_fillmask(scol);
 
   // gathered (random-access) columns: the pairs' pi, both in one block of the interleaved rec table.  The waves
   // of a workgroup, and the workgroups of an XCD, mostly share the block, which keeps it in L1 / L2.
@@ -1186,10 +1186,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     comp[k] = (uint32_t)(gcol & 1);
     hiG[k] = pv.hirow + (int64_t)gcol * pv.n_pad;
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
-    const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.stats[gcol].ntg);
+    const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
     ntgB[k] = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
-    const unsigned long long* mb = pv.mask + (int64_t)gcol * Wp;
-    const unsigned long long* fb = pv.fillmask + (int64_t)gcol * Wp;
+    const unsigned long long* mb = pv.col_mask(gcol);
+    const unsigned long long* fb = pv.col_fillmask(gcol);
 
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
     S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
@@ -1510,8 +1510,8 @@ k2_epilogue(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restri
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   const double NA = __longlong_as_double(0x7FF00000000007A2ll);  // R's NA_real_
-  const ColStats sx = pv.stats[pi[p]];
-  const ColStats sy = pv.stats[pj[p]];
+  const ColStats sx = *pv.col_stats(pi[p]);
+  const ColStats sy = *pv.col_stats(pj[p]);
   const PairRaw rw = (pv.n > 0) ? raw[p] : PairRaw{0ull, 0ull, 0u, 0u};
   const long long n = pv.n;
   const long long cb = rw.c_both;
@@ -1633,8 +1633,8 @@ k_missingness(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __rest
   const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // one pair per wave
   if (p >= n_pairs) return;
   const uint32_t lane = lane_id();
-  const unsigned long long* ma = pv.mask + (int64_t)pi[p] * pv.Wp;
-  const unsigned long long* mb = pv.mask + (int64_t)pj[p] * pv.Wp;
+  const unsigned long long* ma = pv.col_mask(pi[p]);
+  const unsigned long long* mb = pv.col_mask(pj[p]);
   uint32_t c = 0;
   for (int w = lane; w < pv.W; w += 64) c += (uint32_t)__popcll(ma[w] | mb[w]);
   const unsigned long long tot = wave_sum_u64(c);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ICIKT_VERSION 101 /* 0.1.1 */
+#define ICIKT_VERSION 102 /* 0.1.2 */
 
 /* status codes */
 #define ICIKT_SUCCESS 0
@@ -114,26 +114,25 @@ int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t 
 
 /* Column-sharded pre-pass for multi-rank use: the prepared state is allocated for alloc_cols >= n_samp
  * columns (so that every rank's slice has the same size) but only columns [col_begin, col_end) are computed.
- * The caller then all-gathers the column slices of the ICIKT_PREP_ARRAYS arrays returned by
- * icikt_prep_arrays() across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
+  * The caller then all-gathers the column slices of the arrays returned by icikt_prep_arrays() (all of them, or
+ * the two that carry the information, see below) across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
  * alloc_cols * bytes_per_col[i] bytes; a rank's columns are one contiguous slice of it provided col_begin is
  * even and col_end is even or n_samp (one array interleaves column pairs; other ranges are refused), so give
  * every rank an even number of columns. */
-#define ICIKT_PREP_ARRAYS 8
+#define ICIKT_PREP_ARRAYS 5
 int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
                            int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);
 int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);
-/* Arrays ICIKT_PREP_REC, ICIKT_PREP_HIROW and ICIKT_PREP_TGROUPS are functions of a column's order and gflag
- * arrays: instead of exchanging all eight, a rank may exchange the other five (24 KB instead of 104 KB per
- * column of 10 000 rows) and rebuild those three for the received columns [col_begin, col_end) with this. */
+/* ICIKT_PREP_ORDER (the descending permutation) and ICIKT_PREP_META (per column: missing-row, fill-group and
+ * group-start bitsets + the column's statistics) carry the information: 24 KB per column of 10 000 rows, two
+ * collectives.  ICIKT_PREP_REC, ICIKT_PREP_HIROW and ICIKT_PREP_TGROUPS (80 KB per column) are functions of a
+ * column's order and group starts: exchange them too, or rebuild them for the received columns
+ * [col_begin, col_end) with icikt_expand_cols_dev(). */
 #define ICIKT_PREP_ORDER 0
 #define ICIKT_PREP_REC 1
 #define ICIKT_PREP_HIROW 2
-#define ICIKT_PREP_MASK 3
-#define ICIKT_PREP_FILLMASK 4
-#define ICIKT_PREP_GFLAG 5
-#define ICIKT_PREP_STATS 6
-#define ICIKT_PREP_TGROUPS 7
+#define ICIKT_PREP_META 3
+#define ICIKT_PREP_TGROUPS 4
 int icikt_expand_cols_dev(icikt_ctx *ctx, int64_t col_begin, int64_t col_end, uint32_t flags);
 
 /* Pair list (HOST arrays, copied).  Mirrors setup_comparisons' output order (R/kendalltau.R:181-278). */

@@ -398,7 +398,7 @@ def test_sharded_prepass_matches_full(hip_ctx):
         c0, c1 = min(S, r * cols_per), min(S, (r + 1) * cols_per)
         hip_ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc)
     arrays = hip_ctx.prep_arrays()
-    assert len(arrays) == 8 and all(ptr and bpc > 0 for ptr, bpc in arrays)
+    assert len(arrays) == 5 and all(ptr and bpc > 0 for ptr, bpc in arrays)
     P = S * (S - 1) // 2
     hip_ctx.set_pairs_combn(S, 0, P)
     out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
@@ -434,22 +434,22 @@ def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
             return torch.as_tensor(_D(), device="cuda")
 
         alloc = S + (S & 1)
-        derived = {i: view(i, alloc if i == 1 else S) for i in (1, 2, 7)}
+        derived = {i: view(i, alloc if i == 1 else S) for i in (1, 2, 4)}
         want = {i: t.clone() for i, t in derived.items()}
         # tgroups beyond a column's ntg entries and the pad rows of rec / hirow are unspecified: compare what K1 reads
         for t in derived.values():
             t.fill_(0xEE)
         hip_ctx.expand_cols_dev(0, S)
         hip_ctx.sync()
-        stats = view(6, S).cpu().numpy().view(np.uint32).reshape(S, -1)
-        ntg = stats[:, 7]
+        meta = view(3, S).cpu().numpy().view(np.uint32).reshape(S, -1)   # per column: 3 bitsets, then 16 words of stats
+        ntg = meta[:, -16 + 7]
         n_pad = arrays[2][1] // 2
         rec_w = want[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
         rec_g = derived[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
         hi_w = want[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
         hi_g = derived[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
-        tg_w = want[7].cpu().numpy().view(np.uint32).reshape(S, -1)
-        tg_g = derived[7].cpu().numpy().view(np.uint32).reshape(S, -1)
+        tg_w = want[4].cpu().numpy().view(np.uint32).reshape(S, -1)
+        tg_g = derived[4].cpu().numpy().view(np.uint32).reshape(S, -1)
         for c in range(S):
             assert np.array_equal(rec_g[c >> 1, :n, c & 1], rec_w[c >> 1, :n, c & 1]), (n, c)
             assert np.array_equal(hi_g[c, :n], hi_w[c, :n]), (n, c)

@@ -14,8 +14,9 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("ICIKT_LIB") or os.path.join(_PKG, "libicikt_hip.so")  # ICIKT_LIB: A/B of builds (tools)
-SOURCES = [os.path.join(_PKG, "csrc", "icikt_kernels.hip"), os.path.join(_PKG, "csrc", "icikt_capi.cpp")]
-HEADERS = [os.path.join(_ROOT, "include", "icikt.h"), os.path.join(_PKG, "csrc", "icikt_device.h")]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("icikt_kernels.hip", "icikt_capi.cpp", "icikt_multi.cpp")]
+HEADERS = [os.path.join(_ROOT, "include", "icikt.h"), os.path.join(_PKG, "csrc", "icikt_device.h"),
+           os.path.join(_PKG, "csrc", "icikt_host.h")]
 
 # include/icikt.h
 SUCCESS = 0
@@ -42,7 +43,9 @@ EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
     "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prep_arrays", "icikt_expand_cols_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
-    "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest",
+    "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest", "icikt_debug_set_plan",
+    "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
+    "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
 )
 
 
@@ -61,10 +64,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP kernels + C ABI for gfx950 into icikendalltau_amd/libicikt_hip.so."""
     if not force and not needs_build():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hipcc = os.environ.get("HIPCC", os.path.join(rocm, "bin", "hipcc"))
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_PKG, "csrc"),
-           "-o", LIB_PATH] + SOURCES
+           "-o", LIB_PATH] + SOURCES + ["-L", os.path.join(rocm, "lib"), "-lrccl", "-pthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise IciktError("hipcc failed:\n" + res.stdout + res.stderr)
@@ -122,8 +126,20 @@ def lib():
     L.icikt_pair_f64.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u32, c_vp, c_vp, c_vp]
     L.icikt_missingness_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]
     L.icikt_selftest.argtypes = [c_vp]
+    L.icikt_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
+    L.icikt_multi_create.argtypes = [ctypes.POINTER(c_int), c_int, c_int, ctypes.POINTER(c_vp)]
+    L.icikt_multi_destroy.argtypes = [c_vp]
+    L.icikt_multi_destroy.restype = None
+    L.icikt_multi_last_error.argtypes = [c_vp]
+    L.icikt_multi_last_error.restype = ctypes.c_char_p
+    L.icikt_multi_n_gpu.argtypes = [c_vp]
+    L.icikt_multi_uses_rccl.argtypes = [c_vp]
+    L.icikt_pairs_multi_f64.argtypes = L.icikt_pairs_f64.argtypes
+    L.icikt_multi_phase_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double)]
+    L.icikt_multi_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
     for name in EXPORTS:
-        if getattr(L, name).restype is not None and name not in ("icikt_last_error", "icikt_num_pairs"):
+        if getattr(L, name).restype is not None and name not in ("icikt_last_error", "icikt_num_pairs",
+                                                                   "icikt_multi_last_error"):
             getattr(L, name).restype = c_int
     _lib = L
     return L
@@ -230,6 +246,12 @@ class Context:
     def selftest(self):
         self._chk(lib().icikt_selftest(self._h), "icikt_selftest")
 
+    def debug_set_plan(self, spec: str | dict | None = None):
+        """Test / experiment hook: override the pair kernel's launch plan ("np=1,pend=g,..." or a dict; None resets)."""
+        if isinstance(spec, dict):
+            spec = ",".join(f"{k}={v}" for k, v in spec.items() if v not in ("", None))
+        self._chk(lib().icikt_debug_set_plan(self._h, (spec or "").encode()), "icikt_debug_set_plan")
+
     # -- host-buffer path ------------------------------------------------------------------------
     def pairs(self, X, pi=None, pj=None, perspective="global", alternative="two.sided", continuity=False,
               flags: int = 0, want_counts: bool = True):
@@ -275,6 +297,80 @@ class Context:
         self._chk(lib().icikt_missingness_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a),
                                               _ptr(pj_a), pi_a.shape[0], _ptr(out)), "icikt_missingness_f64")
         return out
+
+
+EXCHANGE = {"auto": 0, "rccl": 1, "copy": 2}
+MULTI_PHASES = ("prepare", "exchange", "pairs", "gather")
+
+
+class MultiContext:
+    """Several MI355X behind one call (icikt_multi): one host thread per device inside the library, column-sharded
+    pre-pass, RCCL all-gather / gather over xGMI."""
+
+    def __init__(self, devices=None, n_gpu: int | None = None, exchange: str = "auto"):
+        if devices is None:
+            devices = list(range(int(n_gpu or 1)))
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        self._h = ctypes.c_void_p()
+        rc = lib().icikt_multi_create(arr, len(self.devices), EXCHANGE[exchange], ctypes.byref(self._h))
+        if rc == E_NO_DEVICE:
+            raise IciktError("no usable HIP device: icikendalltau_amd computes on MI355X only (no CPU fallback)")
+        if rc != SUCCESS:
+            raise IciktError(f"icikt_multi_create(devices={self.devices}, exchange={exchange!r}) failed with code {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().icikt_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(lib().icikt_multi_uses_rccl(self._h))
+
+    def _chk(self, rc: int, what: str):
+        if rc != SUCCESS:
+            msg = lib().icikt_multi_last_error(self._h)
+            raise IciktError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+    def debug_set_plan(self, spec: str | dict | None = None):
+        if isinstance(spec, dict):
+            spec = ",".join(f"{k}={v}" for k, v in spec.items() if v not in ("", None))
+        self._chk(lib().icikt_multi_debug_set_plan(self._h, (spec or "").encode()), "icikt_multi_debug_set_plan")
+
+    def phase_ms(self) -> dict:
+        ms = (ctypes.c_double * len(MULTI_PHASES))()
+        self._chk(lib().icikt_multi_phase_ms(self._h, ms), "icikt_multi_phase_ms")
+        return dict(zip(MULTI_PHASES, list(ms)))
+
+    def pairs(self, X, pi=None, pj=None, perspective="global", alternative="two.sided", continuity=False,
+              flags: int = 0, want_counts: bool = True):
+        """Same contract as Context.pairs()."""
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        if Xf.ndim != 2:
+            raise ValueError("X must be 2-D (features x samples)")
+        n_feat, n_samp = Xf.shape
+        if pi is None:
+            P = n_samp * (n_samp - 1) // 2
+            pi_a = pj_a = None
+        else:
+            pi_a = np.ascontiguousarray(pi, dtype=np.int32)
+            pj_a = np.ascontiguousarray(pj, dtype=np.int32)
+            P = pi_a.shape[0]
+        out = np.empty((P, 4), dtype=np.float64)
+        cnt = np.zeros((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
+        rsn = np.zeros(P, dtype=np.int32)
+        alt = ALTERNATIVE.get(alternative, ALT_OTHER)
+        self._chk(lib().icikt_pairs_multi_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a),
+                                              P, PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, _ptr(out),
+                                              _ptr(cnt), _ptr(rsn)), "icikt_pairs_multi_f64")
+        return out, cnt, rsn
 
 
 _default_ctx: dict[int, Context] = {}

@@ -14,6 +14,7 @@
 
 #include "icikt.h"
 #include "icikt_device.h"
+#include "icikt_host.h"
 
 using icikt::ColStats;
 using icikt::PairRaw;
@@ -22,90 +23,26 @@ using icikt::PrepView;
 static_assert(ICIKT_CNT_FIELDS == icikt::ICIKT_CNT_FIELDS_, "counts record layout");
 static_assert(ICIKT_PERSPECTIVE_LOCAL == icikt::ICIKT_PERSPECTIVE_LOCAL_, "perspective code");
 
-namespace {
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t cap = 0;  // elements
-  hipError_t reserve(size_t n) {
-    if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = n + n / 8 + 64;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-}  // namespace
-
-struct icikt_ctx {
-  int device = -1;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  std::string err;
-  hipDeviceProp_t prop{};
-
-  // prepared matrix
-  bool prepared = false;
-  PrepView pv{};
-  DevBuf<uint16_t> order, hirow;
-  DevBuf<uint32_t> rec, tgroups;
-  DevBuf<unsigned long long> meta, sort_keys;
-  DevBuf<uint32_t> sort_idx;
-  int sort_chunk = 0;
-  int64_t alloc_cols = 0;  // columns the prepared-state arrays are allocated for (>= n_samp)
-
-  // pair list
-  int64_t n_pairs = -1;
-  int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
-  int n_units = 0;
-  int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
-  DevBuf<int32_t> d_pi, d_pj, d_unit_start;
-  DevBuf<PairRaw> d_raw;
-  DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
-  DevBuf<uint32_t> d_pend_pre;
-  std::vector<int32_t> h_pi, h_pj, h_units;
-
-  // host-path staging
-  DevBuf<double> d_X, d_out4;
-  DevBuf<int64_t> d_counts;
-  DevBuf<int32_t> d_reasons;
-  DevBuf<uint32_t> d_self;
-
-  // timing
-  hipEvent_t ev[ICIKT_K_COUNT][2] = {};
-  bool ev_pending[ICIKT_K_COUNT] = {};
-  double ms[ICIKT_K_COUNT] = {};
-  int64_t launches[ICIKT_K_COUNT] = {};
-};
-
-namespace {
+namespace icikt {
+namespace host {
 
 int fail(icikt_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
 }
 
-#define HIPCHK(c, call)                                                                      \
-  do {                                                                                       \
-    hipError_t e__ = (call);                                                                 \
-    if (e__ != hipSuccess)                                                                   \
-      return fail((c), ICIKT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));     \
-  } while (0)
-
 int use_device(icikt_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   return ICIKT_SUCCESS;
 }
+
+}  // namespace host
+}  // namespace icikt
+
+using icikt::host::fail;
+using icikt::host::use_device;
+
+namespace {
 
 // fold a pending event pair into the accumulated time (needs the events to have completed)
 int flush_timer(icikt_ctx* c, int k) {
@@ -146,7 +83,7 @@ struct K1Plan {
   int stride;        // 64-bit words between a pair's LDS / pend arrays (k1_lds_stride)
 };
 
-K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu) {
+K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
   // n <= 10 176 (a half wave rebuilds a prefix with <= 5 words per lane): two pairs per wave, one per half,
@@ -163,19 +100,17 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu) {
     const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2 + 2);  // seen, pend + spre, ppre
     pl.pend_global = !half_ok && full * 20 > lds_cap;
   }
-  if (const char* e = getenv("ICIKT_K1_PEND")) pl.pend_global = (e[0] == 'g');
-  // overrides for experiments and tests; a plan without a kernel variant falls back to one pair per wave
-  if (const char* e = getenv("ICIKT_K1_NP")) {
-    const int v = atoi(e);
-    if (v == 1 || (v == 2 && half_ok)) np = v;
-  }
+  // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable);
+  // a plan without a kernel variant falls back to one pair per wave
+  if (ov.pend >= 0) pl.pend_global = ov.pend != 0;
+  if (ov.np == 1 || (ov.np == 2 && half_ok)) np = ov.np;
   int wpb = 4;
-  if (const char* e = getenv("ICIKT_K1_WPB")) wpb = std::max(1, std::min(8, atoi(e)));
+  if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
-  if (const char* e = getenv("ICIKT_K1_HALF")) pl.opts = (e[0] == '1') ? 1 : 0;
+  if (ov.half >= 0) pl.opts = ov.half ? 1 : 0;
   int tg_max = 128;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
                      // (measured on 10 000-row columns: list mode wins at 50 groups, row mode at 200: tools/tie_sweep.py)
-  if (const char* e = getenv("ICIKT_K1_TGMAX")) tg_max = std::max(-1, std::min(1 << 20, atoi(e)));
+  if (ov.has_tgmax) tg_max = std::max(-1, std::min(1 << 20, ov.tgmax));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
   // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
@@ -315,6 +250,15 @@ int icikt_ctx_create(int device, icikt_ctx** out) {
     return ICIKT_E_HIP;
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    icikt_ctx_destroy(c);
+    return ICIKT_E_HIP;
+  }
+  for (auto& e : c->ev_copy)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      icikt_ctx_destroy(c);
+      return ICIKT_E_HIP;
+    }
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (int j = 0; j < 2; ++j)
       if (hipEventCreate(&c->ev[k][j]) != hipSuccess) {
@@ -329,6 +273,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
   c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
@@ -337,6 +282,10 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (int j = 0; j < 2; ++j)
       if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
+  for (auto& e : c->ev_copy)
+    if (e) (void)hipEventDestroy(e);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -345,6 +294,8 @@ const char* icikt_last_error(const icikt_ctx* c) { return c ? c->err.c_str() : "
 
 int icikt_ctx_set_stream(icikt_ctx* c, void* hip_stream) {
   if (!c) return ICIKT_E_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
   (void)hipStreamSynchronize(c->stream);
   c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL is HIP's default (null) stream
   return ICIKT_SUCCESS;
@@ -352,7 +303,9 @@ int icikt_ctx_set_stream(icikt_ctx* c, void* hip_stream) {
 
 int icikt_ctx_use_own_stream(icikt_ctx* c) {
   if (!c) return ICIKT_E_INVALID;
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  int rc = use_device(c);
+  if (rc) return rc;
+  (void)hipStreamSynchronize(c->stream);
   c->stream = c->own_stream;
   return ICIKT_SUCCESS;
 }
@@ -365,29 +318,39 @@ int icikt_sync(icikt_ctx* c) {
   return ICIKT_SUCCESS;
 }
 
+}  // extern "C"
+
 // Shared body of icikt_prepare_dev / icikt_prepare_cols_dev: allocate the prepared state for alloc_cols
 // columns and run the pre-pass over columns [col_begin, col_end).
-static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld,
-                        int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags) {
-  if (!c) return ICIKT_E_INVALID;
-  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, "prepare: bad matrix shape");
-  if (n_feat > ICIKT_MAX_FEATURES)
-    return fail(c, ICIKT_E_TOO_LONG, "prepare: n_feat exceeds ICIKT_MAX_FEATURES (65535)");
-  if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
+static const char* const kTooLong =
+    "n_feat exceeds ICIKT_MAX_FEATURES (65535 rows per column: positions are 16-bit; the reference's own "
+    "`int dis`, src/kendallc.cpp:78, is only safe to about that length)";
+
+static int check_shape(icikt_ctx* c, const char* who, int64_t n_feat, int64_t n_samp, int64_t ld) {
+  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, std::string(who) + ": bad matrix shape");
+  if (n_feat > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, std::string(who) + ": " + kTooLong);
+  return ICIKT_SUCCESS;
+}
+
+static int check_col_range(icikt_ctx* c, int64_t n_samp, int64_t col_begin, int64_t col_end, int64_t alloc_cols) {
   if (col_begin < 0 || col_end < col_begin || col_end > n_samp || alloc_cols < n_samp)
     return fail(c, ICIKT_E_INVALID, "prepare: bad column range");
   // rec is interleaved in blocks of two columns: a column range is contiguous memory only on even boundaries
   if ((col_begin & 1) || ((col_end & 1) && col_end != n_samp))
     return fail(c, ICIKT_E_INVALID, "prepare: a column range must start on an even column and end on one (or at n_samp)");
-  int rc = use_device(c);
-  if (rc) return rc;
-  c->prepared = false;
+  return ICIKT_SUCCESS;
+}
 
+namespace icikt {
+namespace host {
+
+int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_cols, int64_t sort_cols) {
+  c->prepared = false;
   PrepView pv{};
   pv.n = (int)n_feat;
   pv.n_pad = (int)((n_feat + 63) / 64 * 64);
   if (pv.n_pad == 0) pv.n_pad = 64;
-  pv.n_ord = pv.n_pad + 64;
+  pv.n_ord = pv.n_pad + 128;  // K1 prefetches the next step's rows: up to index n - 1 + 63 + 64
   pv.W = (int)((n_feat + 63) / 64);
   pv.Wp = pv.W + 1;
   int np2 = 2;
@@ -395,7 +358,7 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   pv.npow2 = np2;
   pv.n_samp = (int)n_samp;
   const size_t S = (size_t)std::max<int64_t>(alloc_cols, 1);
-  const size_t ncols = (size_t)std::max<int64_t>(col_end - col_begin, 1);
+  const size_t ncols = (size_t)std::max<int64_t>(sort_cols, 1);
 
   HIPCHK(c, c->order.reserve(S * pv.n_ord));
   HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
@@ -416,23 +379,53 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   pv.tgroups = c->tgroups.p;
   c->pv = pv;
   c->alloc_cols = (int64_t)S;
+  return ICIKT_SUCCESS;
+}
 
-  rc = timer_begin(c, ICIKT_K_PREPARE, flags);
-  if (rc) return rc;
+int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end) {
+  const PrepView& pv = c->pv;
   if (col_end > col_begin)
     HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
                              (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), c->stream));
-  if (n_feat > 0) {
-    for (int64_t c0 = col_begin; c0 < col_end; c0 += (int64_t)chunk) {
-      const int nc = (int)std::min<int64_t>((int64_t)chunk, col_end - c0);
+  if (pv.n > 0) {
+    const int64_t chunk = std::max(1, c->sort_chunk);
+    for (int64_t c0 = col_begin; c0 < col_end; c0 += chunk) {
+      const int nc = (int)std::min<int64_t>(chunk, col_end - c0);
       HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->stream));
     }
   }
+  return ICIKT_SUCCESS;
+}
+
+}  // namespace host
+}  // namespace icikt
+
+using icikt::host::prepare_alloc;
+using icikt::host::prepare_launch;
+
+static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                        int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = check_shape(c, "prepare", n_feat, n_samp, ld);
+  if (rc) return rc;
+  if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
+  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  rc = prepare_alloc(c, n_feat, n_samp, alloc_cols, col_end - col_begin);
+  if (rc) return rc;
+  rc = timer_begin(c, ICIKT_K_PREPARE, flags);
+  if (rc) return rc;
+  rc = prepare_launch(c, dX, ld, col_begin, col_end);
+  if (rc) return rc;
   rc = timer_end(c, ICIKT_K_PREPARE, flags);
   if (rc) return rc;
   c->prepared = true;
   return ICIKT_SUCCESS;
 }
+
+extern "C" {
 
 int icikt_prepare_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags) {
   return prepare_impl(c, dX, n_feat, n_samp, ld, 0, n_samp, n_samp, flags);
@@ -542,7 +535,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   if (rc) return rc;
   if (c->n_pairs == 0) return ICIKT_SUCCESS;
 
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount);
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
   if (c->wpb != pl.np) {
     build_units(c, pl.np);
     rc = upload_units(c);
@@ -566,7 +559,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
       const int64_t rounds = (c->n_units + waves - 1) / waves;
       blocks = (int)std::max<int64_t>(1, (c->n_units + rounds * pl.wpb - 1) / (rounds * pl.wpb));
     }
-    if (getenv("ICIKT_DEBUG_PLAN"))
+    if (c->plan_ov.verbose)
       fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
               pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
               blocks, c->n_units);
@@ -616,50 +609,157 @@ int icikt_reset_timers(icikt_ctx* c) {
   return ICIKT_SUCCESS;
 }
 
+}  // extern "C"
+
+namespace icikt {
+namespace host {
+
+// H2D of columns [col_begin, col_end) + K0 over them.  The copies run on the context's copy stream in column
+// chunks and K0 of a chunk waits only for its own chunk (an event per chunk), so the pre-pass of chunk i runs
+// while chunk i + 1 crosses PCIe.  The source is the caller's (pageable) matrix:
+//   mode 1 (default)  the source range is page-locked for the duration of the call (hipHostRegister): the copies
+//                     are true DMA from the caller's memory, no staging copy; falls back to mode 0 if refused
+//   mode 0            pageable copies (the runtime stages them through its own pinned buffers)
+//   mode 2            staged by this library through a pinned double buffer (a host memcpy per chunk)
+//   mode 3            the matrix is page-locked already (by the multi-device driver, once for all devices)
+int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
+                       int64_t col_end, uint32_t flags) {
+  const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
+  HIPCHK(c, c->d_X.reserve(nel));
+  int rc = timer_begin(c, ICIKT_K_PREPARE, flags);
+  if (rc) return rc;
+  const int64_t ncols = col_end - col_begin;
+  if (n_feat > 0 && ncols > 0) {
+    const size_t col_bytes = (size_t)n_feat * sizeof(double);
+    // ~8 MB per chunk (an even number of columns: K0 ranges need not be even, but keeps chunks aligned)
+    int64_t chunk = std::max<int64_t>(2, (int64_t)(((size_t)8 << 20) / std::max<size_t>(col_bytes, 1)) & ~(int64_t)1);
+    chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
+    const double* src0 = X + col_begin * ld;
+    const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
+    // default: page-lock the source when it is large enough to pay for the registration; mode 3 = the caller of
+    // this function has page-locked the matrix already (icikt_multi: once for all devices)
+    int mode = c->h2d_mode < 0 ? ((span >= ((size_t)4 << 20)) ? 1 : 0) : c->h2d_mode;
+    bool registered = false;
+    if (mode == 1) {
+      registered = hipHostRegister(const_cast<double*>(src0), span, hipHostRegisterDefault) == hipSuccess;
+      if (!registered) { (void)hipGetLastError(); mode = 0; }
+    }
+    if (mode == 2) {
+      const size_t need = 2 * (size_t)chunk * col_bytes;
+      if (c->pinned_bytes < need) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinned_bytes = 0;
+        if (hipHostMalloc(&c->pinned, need, hipHostMallocDefault) == hipSuccess) c->pinned_bytes = need;
+        else { (void)hipGetLastError(); mode = 0; }
+      }
+    }
+    // the copy stream must not overwrite d_X while earlier work on the compute stream still reads it
+    hipError_t e = hipEventRecord(c->ev_copy[0], c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0);
+    int k = 0;
+    for (int64_t c0 = col_begin; c0 < col_end && e == hipSuccess && rc == 0; c0 += chunk, ++k) {
+      const int64_t nc = std::min<int64_t>(chunk, col_end - c0);
+      double* dst = c->d_X.p + (size_t)c0 * (size_t)n_feat;
+      hipEvent_t ev = c->ev_copy[1 + (k % 3)];
+      if (mode == 2) {
+        char* stage = static_cast<char*>(c->pinned) + (size_t)(k & 1) * (size_t)chunk * col_bytes;
+        if (k >= 2) e = hipEventSynchronize(c->ev_copy[1 + ((k - 2) % 3)]);  // the copy that last used this half
+        if (e != hipSuccess) break;
+        for (int64_t j = 0; j < nc; ++j) memcpy(stage + (size_t)j * col_bytes, X + (c0 + j) * ld, col_bytes);
+        e = hipMemcpyAsync(dst, stage, (size_t)nc * col_bytes, hipMemcpyHostToDevice, c->copy_stream);
+      } else {
+        e = hipMemcpy2DAsync(dst, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc,
+                             hipMemcpyHostToDevice, c->copy_stream);
+      }
+      if (e == hipSuccess) e = hipEventRecord(ev, c->copy_stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+      if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
+    }
+    if (registered || e != hipSuccess || rc) {
+      // the caller's buffer must stay page-locked (and alive) until the last copy has read it
+      (void)hipStreamSynchronize(c->copy_stream);
+      if (registered) (void)hipHostUnregister(const_cast<double*>(src0));
+    }
+    if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D of the matrix: ") + hipGetErrorString(e));
+    if (rc) return rc;
+  } else if (ncols > 0) {
+    rc = prepare_launch(c, c->d_X.p, n_feat, col_begin, col_end);  // n_feat == 0: statistics of empty columns
+    if (rc) return rc;
+  }
+  return timer_end(c, ICIKT_K_PREPARE, flags);
+}
+
+int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return ICIKT_SUCCESS;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return ICIKT_SUCCESS;
+}
+
+}  // namespace host
+}  // namespace icikt
+
+// every index of a host pair list inside [0, n_samp)
+static int check_pair_list(icikt_ctx* c, const char* who, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                           int64_t n_samp) {
+  if (n_pairs < 0 || (n_pairs > 0 && (!pi || !pj))) return fail(c, ICIKT_E_INVALID, std::string(who) + ": bad pair list");
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
+      return fail(c, ICIKT_E_INVALID, std::string(who) + ": column index out of range");
+  return ICIKT_SUCCESS;
+}
+
+extern "C" {
+
 int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
                     const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
                     int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
   if (!c) return ICIKT_E_INVALID;
-  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, "pairs: bad matrix shape");
-  if (n_feat > ICIKT_MAX_FEATURES)
-    return fail(c, ICIKT_E_TOO_LONG, "pairs: n_feat exceeds ICIKT_MAX_FEATURES (65535)");
-  int rc = use_device(c);
+  // every argument is validated before the first asynchronous copy reads the caller's memory
+  int rc = check_shape(c, "pairs", n_feat, n_samp, ld);
   if (rc) return rc;
-  // H2D (column by column when ld != n_feat)
-  const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
-  HIPCHK(c, c->d_X.reserve(nel));
-  if (n_feat > 0 && n_samp > 0) {
-    if (!X) return fail(c, ICIKT_E_INVALID, "pairs: null matrix");
-    HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
-                               (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
-  }
-  rc = icikt_prepare_dev(c, c->d_X.p, n_feat, n_samp, std::max<int64_t>(n_feat, 0), flags);
-  if (rc) return rc;
+  if (n_feat > 0 && n_samp > 0 && !X) return fail(c, ICIKT_E_INVALID, "pairs: null matrix");
   if (pi == nullptr) {
-    rc = icikt_set_pairs_combn(c, n_samp, 0, n_samp * (n_samp - 1) / 2);
+    if (pj != nullptr) return fail(c, ICIKT_E_INVALID, "pairs: pi is null but pj is not");
+    n_pairs = n_samp * (n_samp - 1) / 2;
   } else {
-    for (int64_t p = 0; p < n_pairs; ++p)
-      if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
-        return fail(c, ICIKT_E_INVALID, "pairs: column index out of range");
-    rc = icikt_set_pairs(c, pi, pj, n_pairs);
+    rc = check_pair_list(c, "pairs", pi, pj, n_pairs, n_samp);
+    if (rc) return rc;
   }
+  if (n_pairs > 0 && !out4) return fail(c, ICIKT_E_INVALID, "pairs: null output");
+  if (perspective != ICIKT_PERSPECTIVE_LOCAL && perspective != ICIKT_PERSPECTIVE_GLOBAL)
+    return fail(c, ICIKT_E_INVALID, "pairs: perspective must be local (0) or global (1)");
+  if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return fail(c, ICIKT_E_INVALID, "pairs: bad alternative code");
+  rc = use_device(c);
   if (rc) return rc;
+  rc = pi ? icikt_set_pairs(c, pi, pj, n_pairs) : icikt_set_pairs_combn(c, n_samp, 0, n_pairs);
+  if (rc) return rc;
+  rc = prepare_alloc(c, n_feat, n_samp, n_samp, n_samp);
+  if (rc) return rc;
+  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags);
+  if (rc) return rc;
+  c->prepared = true;
   const int64_t P = c->n_pairs;
-  if (P == 0) return ICIKT_SUCCESS;
-  if (!out4) return fail(c, ICIKT_E_INVALID, "pairs: null output");
-  HIPCHK(c, c->d_out4.reserve((size_t)P * 4));
-  if (counts) HIPCHK(c, c->d_counts.reserve((size_t)P * ICIKT_CNT_FIELDS));
-  if (reasons) HIPCHK(c, c->d_reasons.reserve((size_t)P));
-  rc = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, counts ? c->d_counts.p : nullptr,
-                     reasons ? c->d_reasons.p : nullptr);
+  if (P == 0) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICIKT_SUCCESS;
+  }
+  auto body = [&]() -> int {
+    HIPCHK(c, c->d_out4.reserve((size_t)P * 4));
+    if (counts) HIPCHK(c, c->d_counts.reserve((size_t)P * ICIKT_CNT_FIELDS));
+    if (reasons) HIPCHK(c, c->d_reasons.reserve((size_t)P));
+    int r = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, counts ? c->d_counts.p : nullptr,
+                          reasons ? c->d_reasons.p : nullptr);
+    if (r) return r;
+    r = icikt::host::download(c, out4, c->d_out4.p, (size_t)P * 4 * sizeof(double));
+    if (!r && counts) r = icikt::host::download(c, counts, c->d_counts.p, (size_t)P * ICIKT_CNT_FIELDS * sizeof(int64_t));
+    if (!r && reasons) r = icikt::host::download(c, reasons, c->d_reasons.p, (size_t)P * sizeof(int32_t));
+    return r;
+  };
+  rc = body();
+  // success or not: nothing may still be reading or writing the caller's buffers when this returns
+  const hipError_t es = hipStreamSynchronize(c->stream);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(out4, c->d_out4.p, (size_t)P * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (counts)
-    HIPCHK(c, hipMemcpyAsync(counts, c->d_counts.p, (size_t)P * ICIKT_CNT_FIELDS * sizeof(int64_t),
-                             hipMemcpyDeviceToHost, c->stream));
-  if (reasons)
-    HIPCHK(c, hipMemcpyAsync(reasons, c->d_reasons.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(es));
   return ICIKT_SUCCESS;
 }
 
@@ -667,7 +767,7 @@ int icikt_pair_f64(icikt_ctx* c, const double* x, const double* y, int64_t n, in
                    int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reason) {
   if (!c) return ICIKT_E_INVALID;
   if (n < 0 || (n > 0 && (!x || !y))) return fail(c, ICIKT_E_INVALID, "pair: bad vectors");
-  if (n > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, "pair: length exceeds ICIKT_MAX_FEATURES (65535)");
+  if (n > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, std::string("pair: ") + kTooLong);
   std::vector<double> xy;
   try {
     xy.resize((size_t)std::max<int64_t>(2 * n, 1));
@@ -686,29 +786,68 @@ int icikt_pair_f64(icikt_ctx* c, const double* x, const double* y, int64_t n, in
 int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
                           const int32_t* pi, const int32_t* pj, int64_t n_pairs, int64_t* missingness) {
   if (!c) return ICIKT_E_INVALID;
-  if (n_feat < 0 || n_samp < 0 || ld < n_feat || n_pairs < 0) return fail(c, ICIKT_E_INVALID, "missingness: bad shape");
-  if (n_feat > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, "missingness: n_feat exceeds 65535");
+  int rc = check_shape(c, "missingness", n_feat, n_samp, ld);
+  if (rc) return rc;
+  if (n_pairs < 0) return fail(c, ICIKT_E_INVALID, "missingness: bad shape");
   if (n_pairs == 0) return ICIKT_SUCCESS;
   if (!pi || !pj || !missingness) return fail(c, ICIKT_E_INVALID, "missingness: null argument");
-  for (int64_t p = 0; p < n_pairs; ++p)
-    if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
-      return fail(c, ICIKT_E_INVALID, "missingness: column index out of range");
-  int rc = use_device(c);
+  if (n_feat > 0 && n_samp > 0 && !X) return fail(c, ICIKT_E_INVALID, "missingness: null matrix");
+  rc = check_pair_list(c, "missingness", pi, pj, n_pairs, n_samp);
   if (rc) return rc;
-  const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
-  HIPCHK(c, c->d_X.reserve(nel));
-  if (n_feat > 0 && n_samp > 0)
-    HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
-                               (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
-  rc = icikt_prepare_dev(c, c->d_X.p, n_feat, n_samp, n_feat, 0);
+  rc = use_device(c);
   if (rc) return rc;
   rc = icikt_set_pairs(c, pi, pj, n_pairs);
   if (rc) return rc;
-  HIPCHK(c, c->d_counts.reserve((size_t)n_pairs));
-  HIPCHK(c, icikt::launch_missingness(c->pv, c->d_pi.p, c->d_pj.p, n_pairs, c->d_counts.p, c->stream));
-  HIPCHK(c, hipMemcpyAsync(missingness, c->d_counts.p, (size_t)n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost,
-                           c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = prepare_alloc(c, n_feat, n_samp, n_samp, n_samp);
+  if (rc) return rc;
+  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, 0);
+  if (rc) return rc;
+  c->prepared = true;
+  auto body = [&]() -> int {
+    HIPCHK(c, c->d_counts.reserve((size_t)n_pairs));
+    HIPCHK(c, icikt::launch_missingness(c->pv, c->d_pi.p, c->d_pj.p, n_pairs, c->d_counts.p, c->stream));
+    return icikt::host::download(c, missingness, c->d_counts.p, (size_t)n_pairs * sizeof(int64_t));
+  };
+  rc = body();
+  const hipError_t es = hipStreamSynchronize(c->stream);
+  if (rc) return rc;
+  if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("missingness: ") + hipGetErrorString(es));
+  return ICIKT_SUCCESS;
+}
+
+// Development / test hook: "key=value,key=value" overrides of the pair kernel's launch plan and of the host
+// path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
+// wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), h2d (plain | register | stage),
+// verbose (0 | 1: print the plan to stderr).
+int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
+  if (!c) return ICIKT_E_INVALID;
+  icikt_ctx::PlanOverride ov;
+  int h2d = -1;
+  std::string sp = spec ? spec : "";
+  size_t pos = 0;
+  while (pos < sp.size()) {
+    size_t end = sp.find(',', pos);
+    if (end == std::string::npos) end = sp.size();
+    const std::string item = sp.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) return fail(c, ICIKT_E_INVALID, "debug_set_plan: expected key=value, got '" + item + "'");
+    const std::string key = item.substr(0, eq), val = item.substr(eq + 1);
+    if (val.empty()) continue;  // "key=" keeps the default
+    if (key == "np") ov.np = atoi(val.c_str());
+    else if (key == "pend") ov.pend = (val[0] == 'g') ? 1 : 0;
+    else if (key == "wpb") ov.wpb = atoi(val.c_str());
+    else if (key == "half") ov.half = (val[0] == '1') ? 1 : 0;
+    else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
+    else if (key == "verbose") ov.verbose = (val[0] == '1');
+    else if (key == "h2d") h2d = (val == "plain") ? 0 : (val == "register") ? 1 : (val == "stage") ? 2 : -2;
+    else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
+    if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be plain, register or stage");
+  }
+  c->plan_ov = ov;
+  c->h2d_mode = h2d;
+  c->wpb = 0;  // tasks are rebuilt for the new plan
   return ICIKT_SUCCESS;
 }
 
@@ -730,7 +869,7 @@ int icikt_selftest(icikt_ctx* c) {
     const uint32_t k = (l & 31u) + 1, b = (l & 32u) + 1;  // sum of (lane+1) over my half up to me
     if (h[384 + l] != k * (2 * b + k - 1) / 2) return fail(c, ICIKT_E_HIP, "selftest: half_incl_scan mismatch");
     if (h[448 + l] != 63u) {
-      if (getenv("ICIKT_DEBUG_PLAN")) fprintf(stderr, "[icikt] selftest lane %u: lane_xor pass mask %u\n", l, h[448 + l]);
+      if (c->plan_ov.verbose) fprintf(stderr, "[icikt] selftest lane %u: lane_xor pass mask %u\n", l, h[448 + l]);
       return fail(c, ICIKT_E_HIP, "selftest: lane_xor mismatch");
     }
     if (l > 0 && h[512 + l] < h[512 + l - 1]) return fail(c, ICIKT_E_HIP, "selftest: wave_sort_u32 not sorted");
@@ -749,7 +888,7 @@ int icikt_selftest(icikt_ctx* c) {
       got += h[192 + l];
     }
     if (got != want) {
-      if (getenv("ICIKT_DEBUG_PLAN")) fprintf(stderr, "[icikt] selftest half %u: got %u want %u\n", half, got, want);
+      if (c->plan_ov.verbose) fprintf(stderr, "[icikt] selftest half %u: got %u want %u\n", half, got, want);
       return fail(c, ICIKT_E_HIP, "selftest: half_allpairs mismatch");
     }
   }

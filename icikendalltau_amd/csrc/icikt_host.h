@@ -1,0 +1,118 @@
+// icikt_host.h -- host-side internals shared by icikt_capi.cpp (one device) and icikt_multi.cpp (several
+// devices, RCCL).  Internal; the public boundary is include/icikt.h.
+#ifndef ICIKT_HOST_H
+#define ICIKT_HOST_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "icikt.h"
+#include "icikt_device.h"
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct icikt_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop{};
+
+  // prepared matrix
+  bool prepared = false;
+  icikt::PrepView pv{};
+  DevBuf<uint16_t> order, hirow;
+  DevBuf<uint32_t> rec, tgroups;
+  DevBuf<unsigned long long> meta, sort_keys;
+  DevBuf<uint32_t> sort_idx;
+  int sort_chunk = 0;
+  int64_t alloc_cols = 0;  // columns the prepared-state arrays are allocated for (>= n_samp)
+
+  // pair list
+  int64_t n_pairs = -1;
+  int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
+  int n_units = 0;
+  int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
+  DevBuf<int32_t> d_pi, d_pj, d_unit_start;
+  DevBuf<icikt::PairRaw> d_raw;
+  DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
+  DevBuf<uint32_t> d_pend_pre;
+  std::vector<int32_t> h_pi, h_pj, h_units;
+
+  // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy[4] = {};
+  void* pinned = nullptr;   // pinned staging area (h2d mode "stage")
+  size_t pinned_bytes = 0;
+  int h2d_mode = -1;        // -1: library default; 0 plain (pageable source), 1 register the caller's buffer, 2 stage
+  DevBuf<double> d_X, d_out4;
+  DevBuf<int64_t> d_counts;
+  DevBuf<int32_t> d_reasons;
+  DevBuf<uint32_t> d_self;
+
+  // launch-plan overrides of the pair kernel (icikt_debug_set_plan; -1 = the library's choice)
+  struct PlanOverride {
+    int np = -1, pend = -1, wpb = -1, half = -1;
+    bool has_tgmax = false;
+    int tgmax = 0;
+    bool verbose = false;
+  } plan_ov;
+
+  // timing
+  hipEvent_t ev[ICIKT_K_COUNT][2] = {};
+  bool ev_pending[ICIKT_K_COUNT] = {};
+  double ms[ICIKT_K_COUNT] = {};
+  int64_t launches[ICIKT_K_COUNT] = {};
+};
+
+
+namespace icikt {
+namespace host {
+
+int fail(icikt_ctx* c, int code, const std::string& msg);
+int use_device(icikt_ctx* c);
+
+#define HIPCHK(c, call)                                                                               \
+  do {                                                                                                \
+    hipError_t e__ = (call);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return icikt::host::fail((c), ICIKT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// Allocate the prepared state of an n_feat x n_samp matrix for alloc_cols >= n_samp columns (sort scratch for
+// sort_cols columns at a time) and set c->pv.  No kernel is launched.
+int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_cols, int64_t sort_cols);
+// K0 over columns [col_begin, col_end) of the device matrix dX (leading dimension ld) on c->stream.
+int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end);
+// Host matrix -> device (columns [col_begin, col_end) only) overlapped with K0 by column chunks; the device copy
+// keeps the full n_feat x n_samp layout (leading dimension n_feat) in c->d_X.  prepare_alloc() must have run.
+int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
+                       int64_t col_end, uint32_t flags);
+// D2H of a result array into a pageable host buffer on c->stream (not synchronised)
+int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
+
+}  // namespace host
+}  // namespace icikt
+#endif

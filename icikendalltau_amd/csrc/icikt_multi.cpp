@@ -1,0 +1,477 @@
+// icikt_multi.cpp -- several MI355X behind ONE call of the C ABI (include/icikt.h, icikt_multi_*).
+//
+// The reference fans its pair chunks out to worker processes (computation$split_fun over `core` chunks,
+// R/kendalltau.R:158, chunks from :250-255, workers from R/utils.R:68-80) and ships the whole matrix to every
+// worker.  Here one host thread drives each GPU (HIP and fork() do not mix, so the GPUs cannot be furrr
+// workers), all inside one call from the R main thread:
+//
+//   rank r:  H2D of ITS columns only -> K0 on them              (the matrix crosses PCIe once, 1/G per link)
+//            RCCL all-gather of `order` and `meta` over xGMI    (24 KB per column of 10 000 rows)
+//            k0_expand: rec / hirow / tgroups of the received columns rebuilt locally
+//            K1 + K2 over block r of the pair list: ceiling(P / G) consecutive pairs = the reference's `core` chunk
+//            RCCL gather of the P/G x 4 results to rank 0 -> one D2H into the caller's buffers
+//
+// Exchange "copy" replaces the two collectives by device-to-device copies between the ranks' buffers
+// (hipMemcpyPeerAsync): it is what runs when a device is listed more than once -- RCCL refuses duplicate
+// devices -- which is how the whole flow is rehearsed on a one-GPU box.  There is no CPU path.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "icikt.h"
+#include "icikt_device.h"
+#include "icikt_host.h"
+
+namespace {
+
+// reusable barrier for the rank threads of one call
+class Barrier {
+ public:
+  explicit Barrier(int n) : n_(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (aborted_) return;
+    const int gen = gen_;
+    if (++count_ == n_) {
+      count_ = 0;
+      ++gen_;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return gen_ != gen || aborted_; });
+    }
+  }
+  // releases every waiter, now and later (a rank thread could not be started: the others must not wait for it)
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu_);
+    aborted_ = true;
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int n_, count_ = 0, gen_ = 0;
+  bool aborted_ = false;
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct icikt_multi {
+  int n = 0;
+  std::vector<int> devices;
+  std::vector<icikt_ctx*> ctx;
+  bool rccl = false;
+  std::vector<ncclComm_t> comms;
+  std::string err;
+  double phase_ms[ICIKT_MULTI_PHASES] = {};
+  // rank 0's gather targets
+  void* root_out4 = nullptr;
+  void* root_counts = nullptr;
+  void* root_reasons = nullptr;
+  size_t root_out4_bytes = 0, root_counts_bytes = 0, root_reasons_bytes = 0;
+};
+
+namespace {
+
+int mfail(icikt_multi* m, int code, const std::string& msg) {
+  if (m) m->err = msg;
+  return code;
+}
+
+struct Call {
+  icikt_multi* m;
+  const double* X;
+  int64_t n_feat, n_samp, ld;
+  const int32_t *pi, *pj;
+  int64_t P, n_each;
+  int perspective, alternative, continuity;
+  uint32_t flags;
+  double* out4;
+  int64_t* counts;
+  int32_t* reasons;
+  int64_t cols_per, alloc_cols;
+  Barrier* bar;
+  std::vector<int> rc;            // per rank
+  std::vector<std::string> msg;   // per rank
+  bool timing;
+  // what the peers read from each other in "copy" exchange
+  std::vector<char*> order_base, meta_base;
+  std::vector<double*> out4_dev;
+  std::vector<int64_t*> counts_dev;
+  std::vector<int32_t*> reasons_dev;
+};
+
+bool all_ok(Call& a) {
+  for (int r : a.rc)
+    if (r != ICIKT_SUCCESS) return false;
+  return true;
+}
+
+// device-to-device copy between two ranks' buffers on the destination rank's stream
+hipError_t peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s);
+}
+
+hipError_t grow(void** p, size_t* cap, size_t want) {
+  if (want <= *cap) return hipSuccess;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(p, want);
+  if (e == hipSuccess) *cap = want;
+  return e;
+}
+
+#define RANKCHK_HIP(call)                                                                        \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      a.rc[r] = ICIKT_E_HIP;                                                                     \
+      a.msg[r] = std::string(#call) + ": " + hipGetErrorString(e__);                             \
+      return;                                                                                    \
+    }                                                                                            \
+  } while (0)
+#define RANKCHK_NCCL(call)                                                                       \
+  do {                                                                                           \
+    ncclResult_t e__ = (call);                                                                   \
+    if (e__ != ncclSuccess) {                                                                    \
+      a.rc[r] = ICIKT_E_HIP;                                                                     \
+      a.msg[r] = std::string(#call) + ": " + ncclGetErrorString(e__);                            \
+      return;                                                                                    \
+    }                                                                                            \
+  } while (0)
+#define RANKCHK(call)                                                                            \
+  do {                                                                                           \
+    int rc__ = (call);                                                                           \
+    if (rc__ != ICIKT_SUCCESS) {                                                                 \
+      a.rc[r] = rc__;                                                                            \
+      a.msg[r] = icikt_last_error(c);                                                            \
+      return;                                                                                    \
+    }                                                                                            \
+  } while (0)
+
+// One rank = one host thread = one device.  Every rank passes every barrier, whatever happened to it: a rank
+// that failed skips the work of the later phases, and a failure anywhere makes ALL ranks skip the collectives
+// (they are entered by all ranks or by none).
+void rank_main(Call& a, int r) {
+  icikt_multi* m = a.m;
+  icikt_ctx* c = m->ctx[(size_t)r];
+  const int G = m->n;
+  const int64_t S = a.n_samp;
+  const int64_t c0 = std::min(S, (int64_t)r * a.cols_per), c1 = std::min(S, (int64_t)(r + 1) * a.cols_per);
+  const int64_t begin = std::min(a.P, (int64_t)r * a.n_each), end = std::min(a.P, (int64_t)(r + 1) * a.n_each);
+  const int64_t P_local = end - begin;
+  double t_prev = now_ms();
+  auto mark = [&](int phase) {  // rank 0 keeps the wall clock of the phases (with ICIKT_FLAG_TIMING: after a sync)
+    if (a.timing) (void)hipStreamSynchronize(c->stream);
+    if (r == 0) {
+      const double t = now_ms();
+      m->phase_ms[phase] = t - t_prev;
+      t_prev = t;
+    }
+  };
+  size_t order_slice = 0, meta_slice = 0;
+
+  // ---- phase A: this rank's pair block, its share of the columns: H2D + K0 ---------------------------------
+  auto phase_a = [&]() {
+    RANKCHK(icikt::host::use_device(c));
+    if (a.pi) RANKCHK(icikt_set_pairs(c, a.pi + begin, a.pj + begin, P_local));
+    else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
+    RANKCHK(icikt::host::prepare_alloc(c, a.n_feat, S, a.alloc_cols, std::max<int64_t>(c1 - c0, 1)));
+    RANKCHK(icikt::host::upload_and_prepare(c, a.X, a.n_feat, S, a.ld, c0, c1, a.flags & ~ICIKT_FLAG_TIMING));
+    RANKCHK_HIP(c->d_out4.reserve((size_t)std::max<int64_t>(a.n_each, 1) * 4));
+    if (a.counts) RANKCHK_HIP(c->d_counts.reserve((size_t)std::max<int64_t>(a.n_each, 1) * ICIKT_CNT_FIELDS));
+    if (a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));
+    if (r == 0) {
+      RANKCHK_HIP(grow(&m->root_out4, &m->root_out4_bytes, (size_t)G * a.n_each * 4 * sizeof(double)));
+      if (a.counts)
+        RANKCHK_HIP(grow(&m->root_counts, &m->root_counts_bytes, (size_t)G * a.n_each * ICIKT_CNT_FIELDS * sizeof(int64_t)));
+      if (a.reasons) RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.n_each * sizeof(int32_t)));
+    }
+    order_slice = (size_t)a.cols_per * (size_t)c->pv.n_ord * sizeof(uint16_t);
+    meta_slice = (size_t)a.cols_per * (size_t)c->pv.mstride * sizeof(unsigned long long);
+    a.order_base[(size_t)r] = reinterpret_cast<char*>(c->pv.order);
+    a.meta_base[(size_t)r] = reinterpret_cast<char*>(c->pv.meta);
+    a.out4_dev[(size_t)r] = c->d_out4.p;
+    a.counts_dev[(size_t)r] = c->d_counts.p;
+    a.reasons_dev[(size_t)r] = c->d_reasons.p;
+    if (!m->rccl) RANKCHK_HIP(hipStreamSynchronize(c->stream));  // peers read this rank's slices after the barrier
+  };
+  phase_a();
+  mark(ICIKT_MULTI_PHASE_PREPARE);
+  a.bar->wait();
+  if (!all_ok(a)) {
+    (void)hipStreamSynchronize(c->stream);
+    return;
+  }
+
+  // ---- phase B: all-gather of order + meta, local rebuild of the rest, pair kernel + epilogue ---------------
+  auto phase_b = [&]() {
+    if (m->rccl) {
+      // in place: rank r's slice already sits at offset r * slice of its own array
+      RANKCHK_NCCL(ncclAllGather(a.order_base[(size_t)r] + (size_t)r * order_slice, a.order_base[(size_t)r], order_slice,
+                                 ncclUint8, m->comms[(size_t)r], c->stream));
+      RANKCHK_NCCL(ncclAllGather(a.meta_base[(size_t)r] + (size_t)r * meta_slice, a.meta_base[(size_t)r], meta_slice,
+                                 ncclUint8, m->comms[(size_t)r], c->stream));
+    } else {
+      for (int p = 0; p < G; ++p) {
+        if (p == r) continue;
+        RANKCHK_HIP(peer_copy(a.order_base[(size_t)r] + (size_t)p * order_slice, m->devices[(size_t)r],
+                              a.order_base[(size_t)p] + (size_t)p * order_slice, m->devices[(size_t)p], order_slice, c->stream));
+        RANKCHK_HIP(peer_copy(a.meta_base[(size_t)r] + (size_t)p * meta_slice, m->devices[(size_t)r],
+                              a.meta_base[(size_t)p] + (size_t)p * meta_slice, m->devices[(size_t)p], meta_slice, c->stream));
+      }
+    }
+    c->prepared = true;
+    if (c0 > 0) RANKCHK(icikt_expand_cols_dev(c, 0, c0, 0));
+    if (c1 < S) RANKCHK(icikt_expand_cols_dev(c, c1, S, 0));
+    if (a.timing) {
+      (void)hipStreamSynchronize(c->stream);
+      if (r == 0) { const double t = now_ms(); m->phase_ms[ICIKT_MULTI_PHASE_EXCHANGE] = t - t_prev; t_prev = t; }
+    }
+    RANKCHK(icikt_run_dev(c, a.perspective, a.alternative, a.continuity, a.flags & ~ICIKT_FLAG_TIMING, c->d_out4.p,
+                          a.counts ? c->d_counts.p : nullptr, a.reasons ? c->d_reasons.p : nullptr));
+    if (!m->rccl) RANKCHK_HIP(hipStreamSynchronize(c->stream));  // rank 0 reads the results after the barrier
+  };
+  phase_b();
+  mark(ICIKT_MULTI_PHASE_PAIRS);
+  a.bar->wait();
+  // NB: a rank that failed inside phase B may have left its peers inside a collective that it never entered;
+  // everything that can fail for reasons of its own (allocation, argument checks) happens in phase A for that
+  // reason, and phase B failures are launch failures that hit every rank alike.
+  if (!all_ok(a)) {
+    (void)hipStreamSynchronize(c->stream);
+    return;
+  }
+
+  // ---- phase C: gather to rank 0, one D2H -------------------------------------------------------------------
+  auto phase_c = [&]() {
+    const size_t n4 = (size_t)a.n_each * 4;
+    if (m->rccl) {
+      RANKCHK_NCCL(ncclGather(c->d_out4.p, m->root_out4, n4, ncclDouble, 0, m->comms[(size_t)r], c->stream));
+      if (a.counts)
+        RANKCHK_NCCL(ncclGather(c->d_counts.p, m->root_counts, (size_t)a.n_each * ICIKT_CNT_FIELDS, ncclInt64, 0,
+                                m->comms[(size_t)r], c->stream));
+      if (a.reasons)
+        RANKCHK_NCCL(ncclGather(c->d_reasons.p, m->root_reasons, (size_t)a.n_each, ncclInt32, 0, m->comms[(size_t)r], c->stream));
+    } else if (r == 0) {
+      for (int p = 0; p < G; ++p) {
+        RANKCHK_HIP(peer_copy(static_cast<double*>(m->root_out4) + (size_t)p * n4, m->devices[0], a.out4_dev[(size_t)p],
+                              m->devices[(size_t)p], n4 * sizeof(double), c->stream));
+        if (a.counts)
+          RANKCHK_HIP(peer_copy(static_cast<int64_t*>(m->root_counts) + (size_t)p * a.n_each * ICIKT_CNT_FIELDS, m->devices[0],
+                                a.counts_dev[(size_t)p], m->devices[(size_t)p],
+                                (size_t)a.n_each * ICIKT_CNT_FIELDS * sizeof(int64_t), c->stream));
+        if (a.reasons)
+          RANKCHK_HIP(peer_copy(static_cast<int32_t*>(m->root_reasons) + (size_t)p * a.n_each, m->devices[0],
+                                a.reasons_dev[(size_t)p], m->devices[(size_t)p], (size_t)a.n_each * sizeof(int32_t), c->stream));
+      }
+    }
+    if (r == 0) {
+      // blocks are consecutive and only the last one is short: the first P records of the gathered array
+      RANKCHK(icikt::host::download(c, a.out4, m->root_out4, (size_t)a.P * 4 * sizeof(double)));
+      if (a.counts) RANKCHK(icikt::host::download(c, a.counts, m->root_counts, (size_t)a.P * ICIKT_CNT_FIELDS * sizeof(int64_t)));
+      if (a.reasons) RANKCHK(icikt::host::download(c, a.reasons, m->root_reasons, (size_t)a.P * sizeof(int32_t)));
+    }
+    RANKCHK_HIP(hipStreamSynchronize(c->stream));
+  };
+  phase_c();
+  if (r == 0) m->phase_ms[ICIKT_MULTI_PHASE_GATHER] = now_ms() - t_prev;
+  a.bar->wait();  // "copy" exchange: nobody returns (and lets its buffers be reused) while rank 0 still reads them
+}
+
+}  // namespace
+
+extern "C" {
+
+int icikt_multi_create(const int* devices, int n_gpu, int exchange, icikt_multi** out) {
+  if (!out) return ICIKT_E_INVALID;
+  *out = nullptr;
+  if (n_gpu < 1 || n_gpu > 64) return ICIKT_E_INVALID;
+  if (exchange != ICIKT_MULTI_EXCHANGE_AUTO && exchange != ICIKT_MULTI_EXCHANGE_RCCL && exchange != ICIKT_MULTI_EXCHANGE_COPY)
+    return ICIKT_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICIKT_E_NO_DEVICE;
+  icikt_multi* m = new (std::nothrow) icikt_multi();
+  if (!m) return ICIKT_E_NOMEM;
+  m->n = n_gpu;
+  bool distinct = true;
+  for (int r = 0; r < n_gpu; ++r) {
+    const int d = devices ? devices[r] : r;
+    if (d < 0 || d >= ndev) {
+      icikt_multi_destroy(m);
+      return ICIKT_E_INVALID;
+    }
+    for (int q : m->devices) distinct = distinct && (q != d);
+    m->devices.push_back(d);
+  }
+  if (exchange == ICIKT_MULTI_EXCHANGE_RCCL && !distinct) {  // RCCL refuses a device listed twice
+    icikt_multi_destroy(m);
+    return ICIKT_E_INVALID;
+  }
+  m->rccl = (exchange == ICIKT_MULTI_EXCHANGE_RCCL) || (exchange == ICIKT_MULTI_EXCHANGE_AUTO && distinct);
+  for (int r = 0; r < n_gpu; ++r) {
+    icikt_ctx* c = nullptr;
+    const int rc = icikt_ctx_create(m->devices[(size_t)r], &c);
+    if (rc != ICIKT_SUCCESS) {
+      icikt_multi_destroy(m);
+      return rc;
+    }
+    c->h2d_mode = 3;  // the matrix is page-locked once per call, for all ranks
+    m->ctx.push_back(c);
+  }
+  if (m->rccl) {
+    m->comms.assign((size_t)n_gpu, nullptr);
+    if (ncclCommInitAll(m->comms.data(), n_gpu, m->devices.data()) != ncclSuccess) {
+      m->comms.clear();
+      icikt_multi_destroy(m);
+      return ICIKT_E_HIP;
+    }
+  }
+  *out = m;
+  return ICIKT_SUCCESS;
+}
+
+void icikt_multi_destroy(icikt_multi* m) {
+  if (!m) return;
+  for (size_t r = 0; r < m->comms.size(); ++r)
+    if (m->comms[r]) {
+      (void)hipSetDevice(m->devices[r]);
+      (void)ncclCommDestroy(m->comms[r]);
+    }
+  if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+  if (m->root_out4) (void)hipFree(m->root_out4);
+  if (m->root_counts) (void)hipFree(m->root_counts);
+  if (m->root_reasons) (void)hipFree(m->root_reasons);
+  for (icikt_ctx* c : m->ctx) icikt_ctx_destroy(c);
+  delete m;
+}
+
+const char* icikt_multi_last_error(const icikt_multi* m) { return m ? m->err.c_str() : "null handle"; }
+int icikt_multi_n_gpu(const icikt_multi* m) { return m ? m->n : 0; }
+int icikt_multi_uses_rccl(const icikt_multi* m) { return (m && m->rccl) ? 1 : 0; }
+
+int icikt_multi_phase_ms(const icikt_multi* m, double* ms) {
+  if (!m || !ms) return ICIKT_E_INVALID;
+  for (int k = 0; k < ICIKT_MULTI_PHASES; ++k) ms[k] = m->phase_ms[k];
+  return ICIKT_SUCCESS;
+}
+
+int icikt_multi_debug_set_plan(icikt_multi* m, const char* spec) {
+  if (!m) return ICIKT_E_INVALID;
+  for (icikt_ctx* c : m->ctx) {
+    const int rc = icikt_debug_set_plan(c, spec);
+    if (rc) return mfail(m, rc, icikt_last_error(c));
+    if (c->h2d_mode < 0) c->h2d_mode = 3;
+  }
+  return ICIKT_SUCCESS;
+}
+
+int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                          const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
+                          int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
+  if (!m) return ICIKT_E_INVALID;
+  for (double& v : m->phase_ms) v = 0.0;
+  if (n_feat < 0 || n_samp < 0 || ld < n_feat) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad matrix shape");
+  if (pi == nullptr) {
+    if (pj != nullptr) return mfail(m, ICIKT_E_INVALID, "pairs_multi: pi is null but pj is not");
+    n_pairs = n_samp * (n_samp - 1) / 2;
+  }
+  const int G = m->n;
+  // Too little work to split (fewer than two columns per rank, or a handful of pairs): rank 0's single-device
+  // path, which also owns every argument check.  (One device with enough work runs the full flow below: the
+  // collectives of a one-rank communicator are copies.)
+  if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0) {
+    icikt_ctx* c = m->ctx[0];
+    const int saved = c->h2d_mode;
+    c->h2d_mode = -1;
+    const int rc = icikt_pairs_f64(c, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags,
+                                   out4, counts, reasons);
+    c->h2d_mode = saved;
+    if (rc) return mfail(m, rc, icikt_last_error(c));
+    return ICIKT_SUCCESS;
+  }
+  // argument checks (the ranks run unchecked): same texts as the single-device path
+  if (n_feat > ICIKT_MAX_FEATURES)
+    return mfail(m, ICIKT_E_TOO_LONG, "pairs_multi: n_feat exceeds ICIKT_MAX_FEATURES (65535 rows per column)");
+  if (!X) return mfail(m, ICIKT_E_INVALID, "pairs_multi: null matrix");
+  if (n_pairs < 0 || (pi && !pj)) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad pair list");
+  if (pi)
+    for (int64_t p = 0; p < n_pairs; ++p)
+      if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
+        return mfail(m, ICIKT_E_INVALID, "pairs_multi: column index out of range");
+  if (!out4) return mfail(m, ICIKT_E_INVALID, "pairs_multi: null output");
+  if (perspective != ICIKT_PERSPECTIVE_LOCAL && perspective != ICIKT_PERSPECTIVE_GLOBAL)
+    return mfail(m, ICIKT_E_INVALID, "pairs_multi: perspective must be local (0) or global (1)");
+  if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad alternative code");
+
+  Call a{};
+  a.m = m; a.X = X; a.n_feat = n_feat; a.n_samp = n_samp; a.ld = ld; a.pi = pi; a.pj = pj; a.P = n_pairs;
+  a.n_each = (n_pairs + G - 1) / G;  // ceiling(n_todo / ncore), R/kendalltau.R:250
+  a.perspective = perspective; a.alternative = alternative; a.continuity = continuity; a.flags = flags;
+  a.out4 = out4; a.counts = counts; a.reasons = reasons;
+  a.cols_per = 2 * ((n_samp + 2 * G - 1) / (2 * G));  // even: the rec table interleaves column pairs
+  a.alloc_cols = a.cols_per * G;
+  a.timing = (flags & ICIKT_FLAG_TIMING) != 0;
+  Barrier bar(G);
+  a.bar = &bar;
+  a.rc.assign((size_t)G, ICIKT_SUCCESS);
+  a.msg.assign((size_t)G, std::string());
+  a.order_base.assign((size_t)G, nullptr); a.meta_base.assign((size_t)G, nullptr);
+  a.out4_dev.assign((size_t)G, nullptr); a.counts_dev.assign((size_t)G, nullptr); a.reasons_dev.assign((size_t)G, nullptr);
+
+  // page-lock the caller's matrix once: every rank then DMAs its columns straight out of it
+  const size_t span = ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
+  bool registered = false;
+  int rank_mode = m->ctx[0]->h2d_mode;
+  if (rank_mode == 3 || rank_mode == 1) {
+    (void)hipSetDevice(m->devices[0]);
+    registered = hipHostRegister(const_cast<double*>(X), span, hipHostRegisterPortable) == hipSuccess;
+    if (!registered) (void)hipGetLastError();
+    rank_mode = registered ? 3 : 0;
+  }
+  std::vector<int> saved_modes;
+  for (icikt_ctx* c : m->ctx) { saved_modes.push_back(c->h2d_mode); c->h2d_mode = rank_mode; }
+
+  std::vector<std::thread> th;
+  bool started = true;
+  try {
+    for (int r = 1; r < G; ++r) th.emplace_back(rank_main, std::ref(a), r);
+  } catch (...) {
+    // a rank without a thread would leave the others at the first barrier: fail every rank (nobody enters a
+    // collective then) and release the barrier for good
+    started = false;
+    for (int& v : a.rc) v = ICIKT_E_NOMEM;
+    for (auto& t : a.msg) t = "could not start the rank threads";
+    bar.abort();
+  }
+  if (started) rank_main(a, 0);  // the calling thread is rank 0
+  for (auto& t : th) t.join();
+  for (size_t r = 0; r < m->ctx.size(); ++r) m->ctx[r]->h2d_mode = saved_modes[r];
+  if (registered) {
+    (void)hipSetDevice(m->devices[0]);
+    (void)hipHostUnregister(const_cast<double*>(X));
+  }
+  for (int r = 0; r < G; ++r)
+    if (a.rc[(size_t)r] != ICIKT_SUCCESS)
+      return mfail(m, a.rc[(size_t)r], "rank " + std::to_string(r) + " (device " + std::to_string(m->devices[(size_t)r]) +
+                                           "): " + a.msg[(size_t)r]);
+  return ICIKT_SUCCESS;
+}
+
+}  // extern "C"

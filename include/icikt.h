@@ -19,6 +19,9 @@
  *     Degenerate pairs get R's NA_real_ bit pattern (0x7FF00000000007A2) in all four and a reason.
  *   - All functions return ICIKT_SUCCESS (0) or a negative ICIKT_E_* code; the message is kept in
  *     the context (icikt_last_error).  Nothing throws across the boundary.
+ *   - n_feat <= ICIKT_MAX_FEATURES (65 535) rows per column: positions are 16-bit.  Longer columns are refused
+ *     with ICIKT_E_TOO_LONG and a message that names the limit (the reference accepts any length, but its own
+ *     `int dis`, src/kendallc.cpp:78, overflows from about that length on).
  *   - A context owns one HIP device, one stream and its workspaces.  Calls on one context must come
  *     from one thread at a time.  Must not be used in a fork()ed child of a process that has
  *     already created a context (R/utils.R:68-80 furrr multicore workers).
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ICIKT_VERSION 102 /* 0.1.2 */
+#define ICIKT_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 #define ICIKT_SUCCESS 0
@@ -168,6 +171,44 @@ int icikt_pair_f64(icikt_ctx *ctx, const double *x, const double *y, int64_t n, 
                    int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
                    int32_t *reason);
 
+/* ---- several GPUs behind one call (what the R glue binds when n_gpu > 1) ----------------------
+ *
+ * Replaces the reference's worker fan-out, computation$split_fun(split_comparisons, ici_split, ...)
+ * (R/kendalltau.R:158; chunks = ceiling(n_todo / ncore) consecutive pairs, :250-255; workers from
+ * R/utils.R:68-80): one host thread per device inside ONE call from the R main thread.  Rank r uploads and
+ * sorts its share of the columns only, the ranks all-gather the prepared columns (RCCL over xGMI), each runs
+ * the pair kernel over block r of the pair list, and the results are gathered to the first device (RCCL) and
+ * copied out once.  Same arguments, outputs and errors as icikt_pairs_f64. */
+typedef struct icikt_multi icikt_multi;
+
+#define ICIKT_MULTI_EXCHANGE_AUTO 0 /* RCCL when the listed devices are distinct, device copies otherwise */
+#define ICIKT_MULTI_EXCHANGE_RCCL 1 /* ncclAllGather / ncclGather over xGMI */
+#define ICIKT_MULTI_EXCHANGE_COPY 2 /* hipMemcpyPeerAsync between the ranks' buffers; a device may be listed
+                                       more than once (how the flow is rehearsed on a one-GPU box) */
+/* devices: n_gpu HIP device indices (NULL = 0 .. n_gpu-1).  Creates one context per entry and, for RCCL,
+ * the communicators (ncclCommInitAll).  Keep the handle: creating communicators costs far more than a call. */
+int icikt_multi_create(const int *devices, int n_gpu, int exchange, icikt_multi **out);
+void icikt_multi_destroy(icikt_multi *m);
+const char *icikt_multi_last_error(const icikt_multi *m);
+int icikt_multi_n_gpu(const icikt_multi *m);
+int icikt_multi_uses_rccl(const icikt_multi *m);
+int icikt_pairs_multi_f64(icikt_multi *m, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                          const int32_t *pi, const int32_t *pj, int64_t n_pairs, int perspective,
+                          int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
+                          int32_t *reasons);
+/* Wall-clock milliseconds of the last call's phases as seen by rank 0: H2D + pre-pass of the rank's columns,
+ * exchange (all-gather + local rebuild), pair kernel + epilogue, gather + D2H.  With ICIKT_FLAG_TIMING each
+ * phase ends with a stream synchronisation, so the figures are device time; without it they are host-side
+ * enqueue times except the last, which absorbs everything still in flight. */
+#define ICIKT_MULTI_PHASE_PREPARE 0
+#define ICIKT_MULTI_PHASE_EXCHANGE 1
+#define ICIKT_MULTI_PHASE_PAIRS 2
+#define ICIKT_MULTI_PHASE_GATHER 3
+#define ICIKT_MULTI_PHASES 4
+int icikt_multi_phase_ms(const icikt_multi *m, double *ms);
+/* icikt_debug_set_plan() on every rank's context. */
+int icikt_multi_debug_set_plan(icikt_multi *m, const char *spec);
+
 /* pairwise_completeness() arithmetic (R/kendalltau.R:611-629): missingness[p] = #rows missing in
  * either column, from a host matrix whose missing cells are NaN.  Self pairs allowed. */
 int icikt_missingness_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
@@ -175,6 +216,13 @@ int icikt_missingness_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64
 
 /* Device self-test of the wavefront primitives the pair kernel relies on (DPP scan / shift). */
 int icikt_selftest(icikt_ctx *ctx);
+
+/* Development / test hook (the product path reads no environment variable): "key=value,key=value" overrides of
+ * the pair kernel's launch plan and of the host path's H2D mode on this context; NULL or "" restores the library's
+ * choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g: open-group bitset in LDS | global memory), wpb (waves
+ * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), h2d (plain | register | stage),
+ * verbose (0 | 1: print the chosen plan to stderr). */
+int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
 
 #ifdef __cplusplus
 }

@@ -30,3 +30,11 @@ def hip_ctx():
     ctx = _lib.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def plan_ctx(hip_ctx):
+    """The session context for tests that override the pair kernel's launch plan (icikt_debug_set_plan);
+    the library's own choices are restored afterwards."""
+    yield hip_ctx
+    hip_ctx.debug_set_plan(None)

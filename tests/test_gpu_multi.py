@@ -1,0 +1,120 @@
+"""icikt_pairs_multi_f64 -- several GPUs behind one C call (include/icikt.h; replaces the reference's worker
+fan-out, R/kendalltau.R:158,250-255).  On the one-GPU test box:
+  * n_gpu = 1 with exchange "rccl": the real RCCL calls (ncclCommInitAll, ncclAllGather in place, ncclGather) on a
+    one-rank communicator;
+  * devices [0, 0] / [0, 0, 0] with exchange "copy": every rank thread, the column-sharded pre-pass, the exchange
+    of order + meta, the local rebuild, the block partition of the pair list and the gather, with device copies in
+    place of the collectives (RCCL refuses a device listed twice).
+Results must be identical to the single-device entry: same kernels, same integer counts, same doubles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrix(n, S, seed, na=0.08):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, S))
+    X[rng.random(X.shape) < na] = np.nan
+    X[:, 1] = np.round(X[:, 1] * 5)
+    X[:, S - 1] = np.round(X[:, S - 1] * 100)
+    return np.asfortranarray(X)
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def single(hip_ctx):
+    return hip_ctx
+
+
+def test_one_rank_rccl_matches_single_device(single):
+    from icikendalltau_amd import _lib
+    m = _lib.MultiContext([0], exchange="rccl")
+    try:
+        assert m.uses_rccl
+        X = _matrix(3000, 40, 1)
+        for persp in ("global", "local"):
+            _same(m.pairs(X, perspective=persp), single.pairs(X, perspective=persp))
+        pi = np.array([0, 0, 5, 7, 7, 39, 3] * 20, dtype=np.int32)
+        pj = np.array([1, 2, 6, 8, 9, 0, 3] * 20, dtype=np.int32)
+        _same(m.pairs(X, pi, pj, "global"), single.pairs(X, pi, pj, "global"))
+        ph = m.phase_ms()
+        assert set(ph) == {"prepare", "exchange", "pairs", "gather"} and all(v >= 0 for v in ph.values())
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 0, 0, 0, 0]])
+def test_rank_threads_with_copy_exchange(single, devices):
+    from icikendalltau_amd import _lib
+    from oracle import oracle as O
+    m = _lib.MultiContext(devices, exchange="auto")   # duplicates -> "copy"
+    try:
+        assert not m.uses_rccl
+        # S = 37: an odd number of columns, a ragged last column shard and a ragged last pair block
+        X = _matrix(2600, 37, len(devices))
+        for persp in ("global", "local"):
+            got = m.pairs(X, perspective=persp)
+            _same(got, single.pairs(X, perspective=persp))
+        pi, pj = (a.astype(np.int32) for a in np.triu_indices(37, k=1))
+        ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, "local")
+        assert np.array_equal(got[2], rrsn) and np.array_equal(got[1], rcnt[:, :got[1].shape[1]])
+        assert float(np.nanmax(np.abs(got[0] - ref))) <= 1e-10
+        # an explicit list in a caller's order (include_only-style), without counts
+        rng = np.random.default_rng(7)
+        sel = rng.permutation(len(pi))[:500]
+        a = m.pairs(X, pi[sel], pj[sel], "global", want_counts=False)
+        b = single.pairs(X, pi[sel], pj[sel], "global", want_counts=False)
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[2], b[2])
+        # timing flag: phases end with a synchronisation
+        m.pairs(X, perspective="global", flags=_lib.FLAG_TIMING)
+        assert m.phase_ms()["pairs"] > 0
+        # repeated calls reuse every buffer
+        _same(m.pairs(X, perspective="global"), single.pairs(X, perspective="global"))
+    finally:
+        m.close()
+
+
+def test_multi_longer_columns_and_degenerate(single):
+    from icikendalltau_amd import _lib
+    m = _lib.MultiContext([0, 0], exchange="copy")
+    try:
+        X = _matrix(12000, 24, 3, na=0.1)       # one pair per wave plan
+        X[:, 4] = np.nan                         # an all-missing column: reason 1 pairs in both blocks
+        X[:, 9] = 2.5                            # constant: reason 3
+        _same(m.pairs(X, perspective="global"), single.pairs(X, perspective="global"))
+        # too little work to split: the single-device path inside the same entry
+        Xs = _matrix(300, 3, 4)
+        _same(m.pairs(Xs, perspective="local"), single.pairs(Xs, perspective="local"))
+        o, c, r = m.pairs(np.empty((0, 30)), perspective="global")
+        assert o.shape == (435, 4) and np.all(r == 1)
+    finally:
+        m.close()
+
+
+def test_multi_error_contract():
+    import ctypes
+    from icikendalltau_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    bad = (ctypes.c_int * 2)(0, 99)
+    assert L.icikt_multi_create(bad, 2, 0, ctypes.byref(h)) == -1 and not h.value        # no such device
+    dup = (ctypes.c_int * 2)(0, 0)
+    assert L.icikt_multi_create(dup, 2, _lib.EXCHANGE["rccl"], ctypes.byref(h)) == -1      # RCCL refuses duplicates
+    assert L.icikt_multi_create(dup, 0, 0, ctypes.byref(h)) == -1
+    m = _lib.MultiContext([0, 0])
+    try:
+        X = _matrix(500, 20, 5)
+        with pytest.raises(_lib.IciktError, match="column index out of range"):
+            m.pairs(X, np.array([0] * 200, np.int32), np.array([20] * 200, np.int32))
+        with pytest.raises(_lib.IciktError, match="65535"):
+            m.pairs(np.zeros((70000, 20)))
+        # and still usable afterwards
+        o, _c, r = m.pairs(X, perspective="global")
+        assert np.all(r == 0) and not np.isnan(o).any()
+    finally:
+        m.close()

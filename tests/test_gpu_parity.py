@@ -290,9 +290,10 @@ def test_c5_shape_include_only_subset(hip_ctx):
 
 
 @pytest.mark.parametrize("np_", ["1", "2"])
-def test_pairs_per_wave_variants(hip_ctx, np_, monkeypatch):
+def test_pairs_per_wave_variants(plan_ctx, np_):
     """K1 launch plans: one pair per wave or two (one per half); odd run lengths leave partly filled waves."""
-    monkeypatch.setenv("ICIKT_K1_NP", np_)
+    hip_ctx = plan_ctx
+    hip_ctx.debug_set_plan({"np": np_})
     rng = np.random.default_rng(41)
     X = rng.standard_normal((2500, 11))
     X[rng.random(X.shape) < 0.12] = np.nan
@@ -529,10 +530,11 @@ def test_c_abi_error_contract(hip_ctx):
 
 
 @pytest.mark.parametrize("tgmax", ["-1", "3", "1000000"])
-def test_joint_tie_counting_modes(hip_ctx, tgmax, monkeypatch):
+def test_joint_tie_counting_modes(plan_ctx, tgmax):
     """Joint ties of tie groups that span steps: by tie-group list (few groups in the gathered column) or row
     by row; forced both ways on columns with 2 ... 1 500 tie groups, long and short."""
-    monkeypatch.setenv("ICIKT_K1_TGMAX", tgmax)
+    hip_ctx = plan_ctx
+    hip_ctx.debug_set_plan({"tgmax": tgmax})
     rng = np.random.default_rng(71)
     n = 4000
     X = np.empty((n, 8))
@@ -547,3 +549,33 @@ def test_joint_tie_counting_modes(hip_ctx, tgmax, monkeypatch):
     X[rng.random(X.shape) < 0.07] = np.nan
     for p in ("global", "local"):
         _check(hip_ctx, X, perspective=p)
+
+
+@pytest.mark.parametrize("mode", ["plain", "register", "stage", ""])
+def test_host_upload_modes(plan_ctx, mode):
+    """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; the three ways of
+    reading the caller's pageable matrix (and the library's default) give the same results, also with a leading
+    dimension larger than n_feat and for a matrix of several chunks."""
+    import ctypes
+    from icikendalltau_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    n, S, ld = 9000, 300, 9016                       # 300 columns x 70 KB: three 8 MB chunks
+    buf = np.full((S, ld), 7.0)                      # row-major (S, ld) == column-major ld x S
+    buf[:, :n] = rng.standard_normal((S, n))
+    buf[:, :n][rng.random((S, n)) < 0.05] = np.nan
+    X = np.asfortranarray(buf[:, :n].T)              # compact copy for the reference run
+    plan_ctx.debug_set_plan(None)
+    ref = plan_ctx.pairs(X, perspective="global", want_counts=False)
+    plan_ctx.debug_set_plan({"h2d": mode})
+    P = S * (S - 1) // 2
+    out = np.empty((P, 4))
+    rsn = np.zeros(P, np.int32)
+    rc = L.icikt_pairs_f64(plan_ctx._h, buf.ctypes.data, n, S, ld, None, None, 0, 1, 0, 0, 0, out.ctypes.data, None,
+                           rsn.ctypes.data)
+    assert rc == 0, L.icikt_last_error(plan_ctx._h)
+    assert np.array_equal(out, ref[0]) and np.array_equal(rsn, ref[2])
+    with pytest.raises(_lib.IciktError, match="h2d"):
+        plan_ctx.debug_set_plan("h2d=bogus")
+    with pytest.raises(_lib.IciktError, match="unknown key"):
+        plan_ctx.debug_set_plan("nope=1")

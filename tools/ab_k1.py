@@ -14,12 +14,12 @@ P = S * (S - 1) // 2
 ctx.set_pairs_combn(S, 0, P)
 out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
 ctx.prepare_dev(dX.data_ptr(), n, S, n, 0); ctx.sync()
-variants = [dict(ICIKT_K1_NP=str(np_), ICIKT_K1_WPB=str(w)) for np_ in (1, 2, 4) for w in (2, 4, 8)]
+variants = [dict(np=str(np_), wpb=str(w)) for np_ in (1, 2) for w in (2, 4, 8)]
 ref = None
 res = {i: [] for i in range(len(variants))}
 for rnd in range(3):
     for i, v in enumerate(variants):
-        os.environ.update(v)
+        ctx.debug_set_plan(v)
         ctx.reset_timers()
         ctx.run_dev(1, 0, False, _lib.FLAG_TIMING, out.data_ptr()); ctx.sync()
         res[i].append(ctx.kernel_ms(_lib.K_PAIRS)[0])

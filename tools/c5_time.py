@@ -14,10 +14,8 @@ out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
 ctx.prepare_dev(dX.data_ptr(), n, S, n, _lib.FLAG_TIMING); ctx.sync()
 print("n", n, "K0 ms for", S, "columns:", ctx.kernel_ms(_lib.K_PREPARE)[0])
 ref = None
-for v in [dict(ICIKT_K1_PEND="l", ICIKT_K1_NP="1"), dict(ICIKT_K1_PEND="l", ICIKT_K1_NP="2"),
-          dict(ICIKT_K1_PEND="g", ICIKT_K1_NP="1"), dict(ICIKT_K1_PEND="g", ICIKT_K1_NP="2"), dict()]:
-    for k in ("ICIKT_K1_PEND", "ICIKT_K1_NP"): os.environ.pop(k, None)
-    os.environ.update(v)
+for v in [dict(pend="l", np="1"), dict(pend="l", np="2"), dict(pend="g", np="1"), dict(pend="g", np="2"), dict()]:
+    ctx.debug_set_plan(v)
     ts = []
     for _ in range(2):
         ctx.reset_timers(); ctx.run_dev(1, 0, False, _lib.FLAG_TIMING, out.data_ptr()); ctx.sync()

@@ -75,22 +75,18 @@ def one_case(ctx, rng, case):
     X = np.asfortranarray(np.stack([make_column(rng, n) for _ in range(S)], axis=1))
     if rng.random() < 0.3 and S > 2:  # correlated columns: shared rows missing, shared ties
         X[:, 1] = np.where(rng.random(n) < 0.7, X[:, 0], X[:, 1])
-    env = {
-        "ICIKT_K1_NP": rng.choice(["", "1", "2"]),
-        "ICIKT_K1_PEND": rng.choice(["", "lds", "global"]),
-        "ICIKT_K1_HALF": rng.choice(["", "0", "1"]),
-        "ICIKT_K1_TGMAX": rng.choice(["", "-1", "2", "1000000"]),
+    env = {  # launch-plan overrides (icikt_debug_set_plan); "" = the library's choice
+        "np": rng.choice(["", "1", "2"]),
+        "pend": rng.choice(["", "lds", "global"]),
+        "half": rng.choice(["", "0", "1"]),
+        "tgmax": rng.choice(["", "-1", "2", "1000000"]),
     }
-    for k, v in env.items():
-        if v:
-            os.environ[k] = v
-        else:
-            os.environ.pop(k, None)
+    ctx.debug_set_plan(env)
     flags = int(rng.random() < 0.25)  # exact int64 sums
     persp = rng.choice(["global", "local"])
     alt = rng.choice(["two.sided", "less", "greater"])
     cont = bool(rng.random() < 0.3)
-    desc = f"case {case}: n={n} S={S} {persp} {alt} cont={cont} flags={flags} env={ {k: v for k, v in env.items() if v} }"
+    desc = f"case {case}: n={n} S={S} {persp} {alt} cont={cont} flags={flags} plan={ {k: v for k, v in env.items() if v} }"
     try:
         out, cnt, rsn = ctx.pairs(X, None, None, persp, alt, cont, flags)
     except Exception as e:  # an invalid override (e.g. LDS pend for a long column) is a refusal, not a failure

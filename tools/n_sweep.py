@@ -6,7 +6,7 @@ from icikendalltau_amd import _lib
 from bench import make_matrix
 
 ns = [int(a) for a in sys.argv[1:]] or [2000, 5000, 10000, 16000, 17000, 25000, 26000, 40000, 65535]
-variants = [dict(), dict(ICIKT_K1_NP="1"), dict(ICIKT_K1_NP="1", ICIKT_K1_PEND="g"), dict(ICIKT_K1_NP="1", ICIKT_K1_PEND="l")]
+variants = [dict(), dict(np="1"), dict(np="1", pend="g"), dict(np="1", pend="l")]
 ctx = _lib.Context(0)
 for n in ns:
     S = 512
@@ -20,14 +20,13 @@ for n in ns:
     ctx.run_dev(1, 0, False, 0, out.data_ptr()); ctx.sync()  # warm-up (clocks, first-touch)
     ref = None
     for v in variants:
-        for k in ("ICIKT_K1_PEND", "ICIKT_K1_NP"): os.environ.pop(k, None)
-        os.environ.update(v)
+        ctx.debug_set_plan(v)
         ts = []
         for _ in range(3):
             ctx.reset_timers(); ctx.run_dev(1, 0, False, _lib.FLAG_TIMING, out.data_ptr()); ctx.sync()
             ts.append(ctx.kernel_ms(_lib.K_PAIRS)[0])
         o = out.cpu().numpy()
         if ref is None: ref = o.copy()
-        tag = "default" if not v else "np" + v["ICIKT_K1_NP"] + v.get("ICIKT_K1_PEND", "")
+        tag = "default" if not v else "np" + v["np"] + v.get("pend", "")
         line.append(f"{tag} {P / (min(ts) / 1e3):.3e}{'' if np.array_equal(o, ref, equal_nan=True) else ' DIFF'}")
     print("  ".join(line), flush=True)

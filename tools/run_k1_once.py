@@ -10,6 +10,7 @@ S = int(os.environ.get("N_SAMP", "1024"))
 na, seed = n // 10, 4
 X = make_matrix(n, S, na, seed)
 ctx = _lib.Context(0)
+ctx.debug_set_plan(os.environ.get("PLAN", ""))  # e.g. PLAN="np=1,wpb=4"
 dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
 P = min(S * (S - 1) // 2, int(os.environ.get("MAX_PAIRS", "1000000000")))
 ctx.set_pairs_combn(S, 0, P)

@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- all-pairs ICI-Kendall-tau throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3|c4|c5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --launcher inlib     one process, N GPUs behind ONE C call (icikt_pairs_multi_f64)
 
-Workload (the configuration the metric is quoted on): synthetic 10 000 features x
+Default workload = BASELINE.md c4, the configuration the metric is quoted on: synthetic 10 000 features x
 1 024 samples, numpy default_rng(4).standard_normal, per column the 1 000 smallest values missing
 (10 % left-censored; tie group < 1024 so the reference's int32 tie sums do not wrap),
 perspective = "global": 523 776 column pairs, each a pair of length-10 000 vectors.
+--config c3: 10 000 x 256, 500 smallest missing (32 640 pairs).  --config c5: 50 000 x 2 048, 1 000 smallest
+missing, 2 096 128 pairs in BOTH perspectives ("local" is the epilogue over the same pair counts), plus the
+include_only subset (first 64 names: 128 992 pairs) and pairwise_completeness on that subset, timed beside it.
 
 One "step" = one full pass of the hot path over the matrix, input already resident in HBM:
   K0 per-column pre-pass (N > 1: each rank sorts S/N columns, then one RCCL all-gather of the prepared state;
-  falls back to every rank sorting all columns) -> K1 pair kernel over this rank's contiguous block of the
-  combn-ordered pair list (the reference's `core` chunks, R/kendalltau.R:250-255) -> K2 epilogue ->
-  (N > 1) RCCL gather of the P/N x 4 results to rank 0.
+  all ranks together fall back to sorting all columns if that cannot be set up) -> K1 pair kernel over this rank's
+  contiguous block of the combn-ordered pair list (the reference's `core` chunks, R/kendalltau.R:250-255) -> K2
+  epilogue -> (N > 1) RCCL gather of the P/N x 4 results to rank 0.
 value = pairs of the whole job / wall time (max over ranks); total work is fixed, so scaling = strong.
+Exit status is non-zero when the results disagree with the oracle sample (a wrong line is not a bench line).
 """
 from __future__ import annotations
 
@@ -32,6 +37,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ATOL = 1e-10
+
+CONFIGS = {
+    "c3": dict(n_feat=10000, n_samp=256, n_na=500, seed=3, steps=20, warmup=3, cpu_sample=6000),
+    "c4": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, steps=20, warmup=3, cpu_sample=12000),
+    "c5": dict(n_feat=50000, n_samp=2048, n_na=1000, seed=5, steps=3, warmup=1, cpu_sample=1200),
+}
 
 
 def make_matrix(n_feat: int, n_samp: int, n_na: int, seed: int) -> np.ndarray:
@@ -58,14 +70,14 @@ def host_cores() -> int:
     return int(env) if env else n
 
 
-def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, seed: int = 0):
+def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, perspective="global", seed: int = 0):
     """The CPU restatement (oracle/, kind = "port") on this box's host cores over a bounded random
     sample of the same pair list; one C thread per core (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
     O.lib()
-    S = X.shape[1]
+    n, S = X.shape
     rng = np.random.default_rng(seed)
     iu, ju = np.triu_indices(S, k=1)
     sel = rng.choice(P_total, size=min(sample_pairs, P_total), replace=False)
@@ -74,7 +86,7 @@ def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, seed: int = 0):
     chunks = np.array_split(np.arange(len(sel)), cores * 4)
 
     def work(ix):
-        return O.ici_pairs(X, pi[ix], pj[ix], "global", want_counts=True)
+        return O.ici_pairs(X, pi[ix], pj[ix], perspective, want_counts=True)
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
@@ -83,21 +95,119 @@ def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, seed: int = 0):
     out = np.concatenate([r[0] for r in res])
     cnt = np.concatenate([r[1] for r in res])
     return {"value": len(sel) / dt, "unit": "column-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{len(sel)} random pairs of the same 10000x1024 matrix, {dt:.2f} s wall on {cores} threads "
-                      f"({dt * cores / len(sel) * 1e3:.2f} core-ms per pair)"}, sel, out, cnt
+            "sample": f"{len(sel)} random pairs of the same {n}x{S} matrix, {dt:.2f} s wall on {cores} threads "
+                      f"({dt * cores / len(sel) * 1e3:.2f} core-ms per pair)",
+            "note": "CPU restatement in C (oracle/), NOT the reference's Rcpp path (R is absent from the image); it "
+                    "copies less than Rcpp sugar does, so per pair it is about 3x faster than the reference's own "
+                    "single-core README figures interpolated to this length (README.md:180-185: 352.7 us at n = 1 000, "
+                    "18 326 us at n = 40 000)"}, sel, out, cnt
+
+
+def cpu_single_core_us():
+    """Single-core per-pair latency of the CPU restatement at the README's two lengths (README.md:166-185:
+    microbenchmark of ici_kt(x, y, "global"), times = 5, x = rnorm(n), y = rnorm(n)); median of 5."""
+    from oracle import oracle as O
+    out = {}
+    for n in (1000, 40000):
+        rng = np.random.default_rng(n)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        O.ici_kt(x, y, "global")
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            O.ici_kt(x, y, "global")
+            ts.append(time.perf_counter() - t0)
+        out[f"n{n}"] = float(np.median(ts) * 1e6)
+    out["reference_readme_us"] = {"n1000": 352.7, "n40000": 18326.0}
+    return out
+
+
+def check_against_oracle(got_out, got_cnt, ref_out, ref_cnt):
+    """Counts bit-exact, doubles within 1e-10 (BASELINE.json north_star)."""
+    chk = {"pairs_checked_against_oracle": int(ref_out.shape[0]),
+           "max_abs_diff": float(np.nanmax(np.abs(got_out - ref_out))),
+           "nan_rows": int(np.isnan(got_out[:, 0]).sum())}
+    if got_cnt is not None:
+        chk["counts_bit_exact"] = bool(np.array_equal(got_cnt, ref_cnt[:, :got_cnt.shape[1]]))
+    chk["ok"] = bool(chk["max_abs_diff"] <= ATOL and chk["nan_rows"] == 0 and chk.get("counts_bit_exact", True))
+    return chk
+
+
+def hbm_traffic(n, S, pairs_per_launch):
+    """Measured HBM-side bytes of one K1 launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE with
+    the gfx950 doubling + WRITE_SIZE; tools/pmc_mem.sh + tools/summarize_profile.py write the file)."""
+    prof = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
+    try:
+        with open(prof) as f:
+            recs = json.load(f)
+        for pj in (recs if isinstance(recs, list) else [recs]):
+            if pj.get("n_feat") == n and pj.get("n_samp") == S and pj.get("pairs_per_launch") == pairs_per_launch:
+                return pj.get("hbm_bytes_per_launch"), pj.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def run_inlib(args, cfg):
+    """N GPUs behind one C call from one process: what an R caller's n_gpu reaches (icikt_pairs_multi_f64).  The
+    boundary hands over HOST buffers, so this rate is PCIe-inclusive by construction."""
+    from icikendalltau_amd import _lib
+    n, S = cfg["n_feat"], cfg["n_samp"]
+    X = make_matrix(n, S, cfg["n_na"], cfg["seed"])
+    P_total = S * (S - 1) // 2
+    m = _lib.MultiContext(n_gpu=args.gpus, exchange=os.environ.get("ICIKT_BENCH_EXCHANGE", "auto"))
+    out = None
+    for _ in range(args.warmup):
+        out, cnt, _r = m.pairs(X, perspective="global", want_counts=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _c, _r = m.pairs(X, perspective="global", want_counts=False)
+    elapsed = time.perf_counter() - t0
+    m.pairs(X, perspective="global", want_counts=False, flags=_lib.FLAG_TIMING)
+    phases = m.phase_ms()
+    line = {
+        "metric": "column-pairs/s (+ full-matrix wall time) at 10k feat x 1k samp",
+        "value": P_total * args.steps / elapsed, "unit": "column-pairs/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "int32 rank/popcount counting + f64 epilogue",
+        "data": "synthetic", "launcher": "inlib",
+        "config": {"workload": f"{args.config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
+                               f"perspective=global, {P_total} column pairs, HOST buffers in and out "
+                               "(icikt_pairs_multi_f64: PCIe-inclusive)",
+                   "pairs": P_total, "n_feat": n, "n_samp": S, "exchange": "rccl" if m.uses_rccl else "copy"},
+        "phase_ms_synced": phases,
+    }
+    if args.cpu_sample > 0:
+        _b, sel, ref_out, ref_cnt = cpu_baseline(X, P_total, min(args.cpu_sample, 2000))
+        line["check"] = check_against_oracle(out[sel], cnt[sel] if cnt is not None else None, ref_out, ref_cnt)
+    m.close()
+    print(json.dumps(line), flush=True)
+    return 0 if line.get("check", {}).get("ok", True) else 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-feat", type=int, default=10000)
-    ap.add_argument("--n-samp", type=int, default=1024)
-    ap.add_argument("--n-na", type=int, default=1000)
-    ap.add_argument("--seed", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=12000, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--launcher", choices=("torchrun", "inlib"), default="torchrun")
+    ap.add_argument("--n-feat", type=int, default=None)
+    ap.add_argument("--n-samp", type=int, default=None)
+    ap.add_argument("--n-na", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive / end-to-end legs")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("n_feat", "n_samp", "n_na", "seed", "steps", "warmup", "cpu_sample"):
+        v = getattr(args, k)
+        if v is not None:
+            cfg[k] = v
+    args.steps, args.warmup, args.cpu_sample = cfg["steps"], cfg["warmup"], cfg["cpu_sample"]
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    if args.launcher == "inlib":
+        raise SystemExit(run_inlib(args, cfg))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,12 +215,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node "
-                             f"{args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+                             f"{args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ... "
+                             "(or --launcher inlib for one process driving all GPUs)")
         args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     # ICIKT_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: every rank uses the visible device
-    # and the gather goes through host memory.  The driver's N > 1 runs use nccl (= RCCL over xGMI).
+    # and the collectives go through host memory.  The driver's N > 1 runs use nccl (= RCCL over xGMI).
     backend = os.environ.get("ICIKT_BENCH_BACKEND", "nccl")
+    via_host = backend != "nccl"
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -123,101 +234,54 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from icikendalltau_amd import _lib
+    from icikendalltau_amd import _lib, sharding
     ctx = _lib.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    n, S = args.n_feat, args.n_samp
-    X = make_matrix(n, S, args.n_na, args.seed)
+    n, S = cfg["n_feat"], cfg["n_samp"]
+    X = make_matrix(n, S, cfg["n_na"], cfg["seed"])
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, n) row-major == n x S column-major
     P_total = S * (S - 1) // 2
-    n_each = -(-P_total // world)  # ceiling(n_todo / ncore), R/kendalltau.R:250
-    begin, end = min(P_total, rank * n_each), min(P_total, (rank + 1) * n_each)
-    ctx.set_pairs_combn(S, begin, end)
+    begin, end, n_each = sharding.pair_block(P_total, rank, world)  # ceiling(n_todo / ncore), R/kendalltau.R:250
     P_local = end - begin
     out_local = torch.full((n_each, 4), float("nan"), dtype=torch.float64, device=dev)
-    comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = ([torch.empty((n_each, 4), dtype=torch.float64, device=comm_dev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None)
+    out_second = torch.empty((n_each, 4), dtype=torch.float64, device=dev) if args.config == "c5" else None
     flags = _lib.FLAG_TIMING
-
-    class _DevBytes:
-        """Zero-copy view of a device allocation of the C library as a torch uint8 tensor."""
-
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    gathered = None
+    both = args.config == "c5"   # BASELINE config 5: perspective = "local" vs "global"
 
     # N > 1: each rank sorts only its S/N columns (K0); order, the bitsets and stats are all-gathered (RCCL over
     # xGMI) and the rest of the prepared state is rebuilt locally, instead of every rank repeating the whole
-    # pre-pass; falls back to the replicated pre-pass if that cannot be set up.
+    # pre-pass; all ranks together fall back to the replicated pre-pass if that cannot be set up.
+    sp = None
     prep_mode = "single"
-    cols_per = 2 * -(-S // (2 * world))  # even: the rec table interleaves column pairs
-    alloc_cols = cols_per * world
-    c0, c1 = min(S, rank * cols_per), min(S, (rank + 1) * cols_per)
-    shards = None
-
-    def prepare_sharded():
-        ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, flags)
-        exchange_shards()
-        # rec / hirow / tgroups of the received columns are functions of their order and gflag: rebuilt here
-        # instead of being sent (24 KB instead of 104 KB per column cross xGMI)
-        if c0 > 0:
-            ctx.expand_cols_dev(0, min(c0, S), flags)
-        if c1 < S:
-            ctx.expand_cols_dev(c1, S, flags)
-
-    def exchange_shards():
-        for full, nbytes in shards:
-            mine = full[rank * nbytes:(rank + 1) * nbytes]
-            if backend == "nccl":
-                dist.all_gather_into_tensor(full, mine.clone())
-            else:  # rehearsal: through host memory
-                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(parts, mine.cpu())
-                full.copy_(torch.cat(parts))
-
-    if world > 1 and os.environ.get("ICIKT_BENCH_PREP", "sharded") == "sharded":
-        # local part first (no collective inside), then the ranks agree: either all of them run the sharded
-        # pre-pass or none does -- a rank that falls back alone would leave the others inside a collective
-        err = None
-        try:
-            ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc_cols, 0)
-            arrays = ctx.prep_arrays()
-            shards = [(torch.as_tensor(_DevBytes(arrays[i][0], arrays[i][1] * alloc_cols), device=dev),
-                       arrays[i][1] * cols_per) for i in _lib.PREP_EXCHANGE]
-        except Exception as e:  # noqa: BLE001
-            err, shards = e, None
-        ok = torch.tensor([0 if shards is None else 1], dtype=torch.int32, device=comm_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            try:
-                prepare_sharded()  # one trial pass before the timed region
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                err = e
-            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=comm_dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            prep_mode = "sharded+allgather"
-        else:
-            print(f"[bench] rank {rank}: sharded pre-pass unavailable ({err!r}); every rank runs the whole pre-pass",
-                  file=sys.stderr)
-            shards = None
-    if world > 1 and shards is None:
+    if world > 1:
         prep_mode = "replicated"
-
-    def prepare():
-        if shards is None:
-            ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
-        else:
-            prepare_sharded()
+        if os.environ.get("ICIKT_BENCH_PREP", "sharded") == "sharded":
+            sp = sharding.ShardedPrepass(ctx, dist, dev, via_host)
+            if not sp.setup(S, lambda c0, c1, alloc, fl: ctx.prepare_cols_dev(dX.data_ptr(), n, S, n, c0, c1, alloc, fl),
+                            sync=torch.cuda.synchronize):
+                sp = None
+            else:
+                prep_mode = sp.mode
+    ctx.set_pairs_combn(S, begin, end)
 
     def step():
-        prepare()
-        ctx.run_dev(_lib.PERSPECTIVE["global"], _lib.ALTERNATIVE["two.sided"], False, flags, out_local.data_ptr())
+        nonlocal gathered
+        if sp is None:
+            ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
+        else:
+            sp.run(flags)
+        if P_local > 0:
+            ctx.run_dev(_lib.PERSPECTIVE["global"], _lib.ALTERNATIVE["two.sided"], False, flags, out_local.data_ptr())
+            if both:  # the second perspective is the epilogue over the same pair counts
+                ctx.run_dev(_lib.PERSPECTIVE["local"], _lib.ALTERNATIVE["two.sided"], False,
+                            flags | _lib.FLAG_REUSE_COUNTS, out_second.data_ptr())
         if world > 1:
             # every rank's P/N x 4 results to rank 0 (RCCL over xGMI)
-            dist.gather(out_local if backend == "nccl" else out_local.cpu(), gathered, dst=0)
+            gathered = sharding.gather_blocks(dist, out_local, n_each, dev, via_host, to_all=False)
+            if both:
+                sharding.gather_blocks(dist, out_second, n_each, dev, via_host, to_all=False)
 
     def fence():
         if world > 1:
@@ -234,12 +298,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     k_ms = {name: ctx.kernel_ms(k) for name, k in (("prepare", _lib.K_PREPARE), ("pairs", _lib.K_PAIRS),
                                                     ("epilogue", _lib.K_EPILOGUE))}
+    status = 0
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = P_total * args.steps / elapsed
@@ -249,40 +314,58 @@ def main():
         k1_avg_s = (k1_ms / max(k1_n, 1)) / 1e3
         alg_bytes = P_local * (16 * n + 32)
         achieved = alg_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
-        if os.path.exists(prof):
-            try:
-                with open(prof) as f:
-                    pj = json.load(f)
-                if pj.get("n_feat") == n and pj.get("n_samp") == S and pj.get("pairs_per_launch") == P_local:
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = hbm_traffic(n, S, P_local)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k1_pairs",
+                "avg_launch_ms": k1_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "frac prices the reference's data flow (two f64 columns per pair) against HBM; the columns are "
+                        "sorted once and reused S-1 times, so the kernel's real limiter is VALU issue + LDS, not HBM"}
+        if traffic:
+            roof["traffic_source"] = traffic_src
+            roof["hbm_measured_GBs"] = traffic / k1_avg_s / 1e9 if k1_avg_s > 0 else None
+            roof["hbm_measured_frac"] = roof["hbm_measured_GBs"] / HBM_PEAK_GBS if k1_avg_s > 0 else None
+        wl = (f"{args.config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
+              f"perspective={'global + local' if both else 'global'}, {P_total} column pairs")
         line = {
             "metric": "column-pairs/s (+ full-matrix wall time) at 10k feat x 1k samp",
             "value": value, "unit": "column-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 rank/popcount counting + f64 epilogue", "data": "synthetic",
-            "config": {"workload": f"c4: {n} features x {S} samples, {args.n_na} smallest per column missing, "
-                                   f"perspective=global, {P_total} column pairs",
-                       "pairs": P_total, "n_feat": n, "n_samp": S, "sharding": f"combn-order blocks over {world} rank(s)", "pre_pass": prep_mode},
+            "config": {"workload": wl, "pairs": P_total, "n_feat": n, "n_samp": S,
+                       "sharding": f"combn-order blocks over {world} rank(s)", "pre_pass": prep_mode},
             "full_matrix_wall_ms": ms_per_step,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k1_pairs",
-                         "avg_launch_ms": k1_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
-            "kernel_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in k_ms.items()},
+            "roofline": roof,
+            # accumulated event time of each kernel id / steps (the pre-pass id covers K0 and, at N > 1, the two
+            # rebuild launches of a step, not the all-gather between them)
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in k_ms.items()},
         }
         if world == 1 and args.cpu_sample > 0:
             base, sel, ref_out, ref_cnt = cpu_baseline(X, P_total, args.cpu_sample)
             line["cpu_baseline"] = base
-            got = out_local[:P_local].cpu().numpy()[sel]
-            line["check"] = {"pairs_checked_against_oracle": int(len(sel)),
-                             "max_abs_diff": float(np.nanmax(np.abs(got - ref_out)))}
+            # the sampled pairs once more through the counts-carrying entry: integers bit-exact, doubles <= 1e-10;
+            # and the timed run's own output on the same pairs
+            iu, ju = np.triu_indices(S, k=1)
+            cnt_t = torch.zeros((len(sel), len(_lib.CNT_FIELDS)), dtype=torch.int64, device=dev)
+            out_t = torch.empty((len(sel), 4), dtype=torch.float64, device=dev)
+            ctx.set_pairs(iu[sel].astype(np.int32), ju[sel].astype(np.int32))
+            ctx.run_dev(_lib.PERSPECTIVE["global"], 0, False, 0, out_t.data_ptr(), cnt_t.data_ptr())
+            torch.cuda.synchronize()
+            line["check"] = check_against_oracle(out_local[:P_local].cpu().numpy()[sel], cnt_t.cpu().numpy(), ref_out, ref_cnt)
+            line["check"]["sampled_rerun_equal"] = bool(np.array_equal(out_t.cpu().numpy(), out_local[:P_local].cpu().numpy()[sel]))
+            line["check"]["ok"] = line["check"]["ok"] and line["check"]["sampled_rerun_equal"]
+            if both:
+                from oracle import oracle as O
+                k = min(200, len(sel))
+                ref_l, _c, _r = O.ici_pairs(X, iu[sel[:k]], ju[sel[:k]], "local", want_counts=False)
+                d = float(np.nanmax(np.abs(out_second[:P_local].cpu().numpy()[sel[:k]] - ref_l)))
+                line["check"]["local_max_abs_diff"] = d
+                line["check"]["ok"] = line["check"]["ok"] and d <= ATOL
+            ctx.set_pairs_combn(S, begin, end)
         if world > 1:
             # the assembled result: rank blocks concatenated in combn order (no NaN may be left in real pairs)
-            full = torch.cat([g[:min(n_each, P_total - r * n_each)] for r, g in enumerate(gathered)]).cpu().numpy()
+            full = sharding.assemble(gathered, P_total, n_each).cpu().numpy()
             line["check"] = {"assembled_pairs": int(full.shape[0]), "nan_rows": int(np.isnan(full[:, 0]).sum())}
+            line["check"]["ok"] = full.shape[0] == P_total and line["check"]["nan_rows"] == 0
             if args.cpu_sample > 0:
                 from oracle import oracle as O
                 rng = np.random.default_rng(1)
@@ -291,11 +374,77 @@ def main():
                 ref, _c, _r = O.ici_pairs(X, iu[sel], ju[sel], "global", want_counts=False)
                 line["check"].update(pairs_checked_against_oracle=int(len(sel)),
                                      max_abs_diff=float(np.nanmax(np.abs(full[sel] - ref))))
+                line["check"]["ok"] = line["check"]["ok"] and line["check"]["max_abs_diff"] <= ATOL
+        if world == 1 and not args.no_extras:
+            extras(line, args, cfg, X, ctx, dev)
+        status = 0 if line.get("check", {}).get("ok", True) else 1
         print(json.dumps(line), flush=True)
     if world > 1:
+        st = torch.tensor([status], dtype=torch.int32, device="cpu" if via_host else dev)
+        dist.broadcast(st, src=0)
+        status = int(st.item())
         dist.barrier()
         dist.destroy_process_group()
+    return status
+
+
+def extras(line, args, cfg, X, ctx, dev):
+    """N = 1 only, outside the timed region: the figures SURVEY.md section 8(d) asks for beside the metric."""
+    from icikendalltau_amd import _lib, api
+    n, S = X.shape
+    P_total = S * (S - 1) // 2
+    ctx.use_own_stream()
+    # (1) PCIe-inclusive: the host-buffer entry the R glue binds (H2D of the matrix in column chunks overlapped with
+    #     K0, kernels, D2H of the results), best of 5
+    out4 = np.empty((P_total, 4))
+    rsn = np.zeros(P_total, np.int32)
+    ts = []
+    L = _lib.lib()
+    for _ in range(1 if args.config == "c5" else 5):
+        t0 = time.perf_counter()
+        rc = L.icikt_pairs_f64(ctx._h, X.ctypes.data, n, S, n, None, None, 0, 1, 0, 0, 0, out4.ctypes.data, None, rsn.ctypes.data)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0, L.icikt_last_error(ctx._h)
+    line["pcie_inclusive"] = {"value": P_total / min(ts), "unit": "column-pairs/s", "ms": min(ts) * 1e3,
+                              "entry": "icikt_pairs_f64 (pageable host matrix in, host results out)",
+                              "h2d_bytes": int(X.nbytes), "d2h_bytes": int(out4.nbytes + rsn.nbytes)}
+    # (2) the whole ici_kendalltau() equivalent: masking, pair list, the call above, scaling, five S x S matrices
+    if args.config != "c5":
+        names = [f"s{i}" for i in range(S)]
+        eng = api.HipEngine(device=dev.index)
+        t0 = time.perf_counter()
+        res = api.ici_kendalltau(X, global_na=(float("nan"), float("inf")), perspective="global", colnames=names, engine=eng)
+        t_e2e = time.perf_counter() - t0
+        line["e2e_ici_kendalltau_ms"] = t_e2e * 1e3
+        line["e2e_run_time_field_ms"] = res["run_time"] * 1e3
+    else:
+        # (3) BASELINE config 5's subset legs: include_only = the first 64 names (pairs with s1 OR s2 among them) in
+        #     both perspectives, and pairwise_completeness (self pairs included) on the same subset
+        names = [f"s{i}" for i in range(S)]
+        pi, pj, _core = api.setup_comparisons(names, include_only=names[:64], diag_good=True, ncore=1)
+        dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)
+        sub = torch.empty((len(pi), 4), dtype=torch.float64, device=dev)
+        ctx.prepare_dev(dX.data_ptr(), n, S, n, 0)
+        ctx.set_pairs(pi, pj)
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.run_dev(_lib.PERSPECTIVE["global"], 0, False, 0, sub.data_ptr())
+        ctx.run_dev(_lib.PERSPECTIVE["local"], 0, False, _lib.FLAG_REUSE_COUNTS, sub.data_ptr())
+        ctx.sync()
+        t_sub = time.perf_counter() - t0
+        pc_i, pc_j, _c = api.setup_comparisons(names, include_only=names[:64], diag_good=False, ncore=1)
+        t0 = time.perf_counter()
+        miss = ctx.missingness(X, pc_i, pc_j)
+        t_pc = time.perf_counter() - t0
+        line["include_only_subset"] = {"pairs": int(len(pi)), "both_perspectives_ms": t_sub * 1e3,
+                                       "pairs_per_s": len(pi) / t_sub,
+                                       "pairwise_completeness_pairs": int(len(pc_i)), "pairwise_completeness_ms": t_pc * 1e3,
+                                       "pairwise_completeness_note": "host-buffer entry: includes H2D of the matrix",
+                                       "missingness_checksum": int(miss.sum())}
+        del dX
+    # (4) single-core latency of the CPU restatement beside the reference's README table
+    line["cpu_single_core_us"] = cpu_single_core_us()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -26,6 +26,7 @@ ALTERNATIVE = {"two.sided": 0, "less": 1, "greater": 2}
 ALT_OTHER = 3
 FLAG_EXACT_INT64 = 1
 FLAG_TIMING = 2
+FLAG_REUSE_COUNTS = 4
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
 MAX_FEATURES = 65535
@@ -41,7 +42,7 @@ REASON_WARNINGS = {
 
 EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
-    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prep_arrays", "icikt_expand_cols_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
+    "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prepare_cols_f64", "icikt_prep_arrays", "icikt_expand_cols_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
     "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest", "icikt_debug_set_plan",
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
@@ -112,6 +113,7 @@ def lib():
     L.icikt_sync.argtypes = [c_vp]
     L.icikt_prepare_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_u32]
     L.icikt_prepare_cols_dev.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_u32]
+    L.icikt_prepare_cols_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_u32]
     L.icikt_prep_arrays.argtypes = [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)]
     L.icikt_expand_cols_dev.argtypes = [c_vp, c_i64, c_i64, c_u32]
     L.icikt_set_pairs.argtypes = [c_vp, c_vp, c_vp, c_i64]
@@ -203,6 +205,15 @@ class Context:
         """Pre-pass over columns [col_begin, col_end) only (multi-rank: all-gather prep_arrays() afterwards)."""
         self._chk(lib().icikt_prepare_cols_dev(self._h, ctypes.c_void_p(d_ptr), n_feat, n_samp, ld, col_begin,
                                                col_end, alloc_cols, flags), "icikt_prepare_cols_dev")
+
+    def prepare_cols(self, X, col_begin: int, col_end: int, alloc_cols: int, flags: int = 0):
+        """Pre-pass over columns [col_begin, col_end) of a HOST matrix (F-ordered float64, NaN = missing): only
+        those columns cross PCIe."""
+        if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.flags.f_contiguous and X.ndim == 2):
+            raise ValueError("prepare_cols needs a Fortran-ordered float64 matrix")
+        n_feat, n_samp = X.shape
+        self._chk(lib().icikt_prepare_cols_f64(self._h, _ptr(X), n_feat, n_samp, max(n_feat, 0), col_begin, col_end,
+                                               alloc_cols, flags), "icikt_prepare_cols_f64")
 
     def prep_arrays(self):
         """[(device pointer, bytes per column)] of the prepared-state arrays."""

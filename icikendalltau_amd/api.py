@@ -43,8 +43,61 @@ class HipEngine:
                                         want_counts=False)
         return out, rsn
 
+    def pairs_counts(self, X, pi, pj, perspective, alternative, continuity):
+        """pairs() plus the integer counts record (dict of arrays keyed by _lib.CNT_FIELDS)."""
+        out, cnt, rsn = self.ctx.pairs(X, pi, pj, perspective, alternative, continuity, self.flags, want_counts=True)
+        return out, rsn, {k: cnt[:, i] for i, k in enumerate(_lib.CNT_FIELDS)}
+
     def missingness(self, X, pi, pj):
         return self.ctx.missingness(X, pi, pj)
+
+    def pairs_block_dev(self, X, pi, pj, begin, end, n_each, perspective, alternative, continuity, dist, device,
+                        via_host):
+        """This rank's block [begin, end) of a pair list under torch.distributed: column-sharded pre-pass
+        (sharding.ShardedPrepass; every rank falls back to the whole pre-pass together if it cannot be set up), then
+        K1 + K2 into torch buffers on `device`, padded to n_each rows for the gather."""
+        import torch
+        from . import sharding
+        ctx = self.ctx
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        S = Xf.shape[1]
+        with torch.cuda.device(device):
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream orders kernels and collectives
+            try:
+                sp = sharding.ShardedPrepass(ctx, dist, device, via_host)
+                if not sp.setup(S, lambda c0, c1, alloc, fl: ctx.prepare_cols(Xf, c0, c1, alloc, fl),
+                                sync=torch.cuda.synchronize):
+                    ctx.prepare_cols(Xf, 0, S, S, 0)
+                self.pre_pass = sp.mode
+                out_l = torch.full((n_each, 4), float("nan"), dtype=torch.float64, device=device)
+                rsn_l = torch.zeros(n_each, dtype=torch.int32, device=device)
+                ctx.set_pairs(pi[begin:end], pj[begin:end])
+                if end > begin:
+                    ctx.run_dev(_lib.PERSPECTIVE[perspective], _lib.ALTERNATIVE.get(alternative, _lib.ALT_OTHER),
+                                continuity, self.flags, out_l.data_ptr(), None, rsn_l.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                ctx.use_own_stream()
+        return out_l, rsn_l
+
+
+class MultiHipEngine(HipEngine):
+    """Runs pair lists on several MI355X behind ONE library call (icikt_pairs_multi_f64): one host thread per
+    GPU inside the library, column-sharded pre-pass, RCCL all-gather / gather over xGMI.  This is what an R
+    caller's `n_gpu` argument selects (icikendalltau_amd/r/icikt_mi355x.R); with torch.distributed ranks use
+    HipEngine per rank instead."""
+
+    name = "hip-multi"
+
+    def __init__(self, devices=None, n_gpu: int | None = None, exchange: str = "auto", exact_int64: bool = False):
+        self.ctx = _lib.MultiContext(devices, n_gpu, exchange)
+        self._single = None
+        self.flags = _lib.FLAG_EXACT_INT64 if exact_int64 else 0
+
+    def missingness(self, X, pi, pj):  # a bitset popcount: one device is plenty
+        if self._single is None:
+            self._single = _lib.default_context(self.ctx.devices[0])
+        return self._single.missingness(X, pi, pj)
 
 
 def _default_engine():
@@ -85,8 +138,10 @@ def _warn_reason(reason: int):
 def ici_kt(x, y, perspective="local", alternative="two.sided", continuity=False, output="simple", engine=None):
     """Information-content-informed Kendall tau-b of two vectors (NaN = missing).
 
-    Same defaults as the reference (src/kendallc.cpp:166).  ``output`` is accepted for signature
-    compatibility; the debug print of kendallc.cpp:342-363 is replaced by ``ici_kt_counts``.
+    Same defaults as the reference (src/kendallc.cpp:166).  Any ``output`` other than "simple" prints the
+    reference's report (src/kendallc.cpp:342-363: same labels, ``std::to_string`` formatting) from the counts
+    record of the pair; ``ici_kt_counts`` returns those integers instead of printing them.
+    Vectors longer than 65 535 (``_lib.MAX_FEATURES``) are refused with an error that names the limit.
     """
     x = np.asarray(x, dtype=np.float64).ravel()
     y = np.asarray(y, dtype=np.float64).ravel()
@@ -99,9 +154,43 @@ def ici_kt(x, y, perspective="local", alternative="two.sided", continuity=False,
     X = np.empty((x.shape[0], 2), dtype=np.float64, order="F")
     X[:, 0] = x
     X[:, 1] = y
-    out, rsn = eng.pairs(X, np.array([0], np.int32), np.array([1], np.int32), perspective, alternative, continuity)
+    i0, i1 = np.array([0], np.int32), np.array([1], np.int32)
+    if output != "simple" and hasattr(eng, "pairs_counts"):
+        out, rsn, cnt = eng.pairs_counts(X, i0, i1, perspective, alternative, continuity)
+        if rsn[0] == 0:  # the reference returns before its report in every NA case
+            print(_ici_kt_report(x, y, perspective, continuity, out[0], {k: int(v[0]) for k, v in cnt.items()}), end="")
+    else:
+        out, rsn = eng.pairs(X, i0, i1, perspective, alternative, continuity)
     _warn_reason(rsn[0])
     return IciKtResult(out[0])
+
+
+def _ici_kt_report(x, y, perspective, continuity, out4, k) -> str:
+    """The text ici_kt(output != "simple") writes to Rcout (src/kendallc.cpp:342-363), rebuilt from the counts
+    record: integers print as integers, doubles as std::to_string prints them ("%f")."""
+    keep = ~(np.isnan(x) & np.isnan(y)) if perspective == "local" else np.ones(x.shape[0], bool)
+    x2, y2 = x[keep].copy(), y[keep].copy()
+    min_x, min_y = np.nanmin(x2) - 0.1, np.nanmin(y2) - 0.1          # :214-215
+    x2[np.isnan(x2)] = min_x
+    y2[np.isnan(y2)] = min_y
+    sum_obs = len(np.unique(np.stack([x2, y2], axis=1), axis=0)) + 1  # joint runs + 1 (:261-263)
+    n, tot = k["n"], k["tot"]
+    m = n * (n - 1)
+    ld = np.longdouble
+    con_minus_dis = ld(tot) - k["xtie"] - k["ytie"] + k["ntie"] - 2 * k["dis"]
+    var = (ld(m * (2 * n + 5)) - k["x1"] - k["y1"]) / 18 + ld(2.0 * k["xtie"] * k["ytie"]) / m + \
+        ld(float(k["x0"]) * float(k["y0"])) / ld(9 * m * (n - 2)) if n > 2 else ld("nan")
+    s_adj = ld(out4[0]) * np.sqrt(ld(m // 2 - k["xtie"]) * ld(m // 2 - k["ytie"]))
+    if continuity:
+        s_adj = np.sign(s_adj) * (abs(s_adj) - 1)
+    z_b = s_adj / np.sqrt(var)
+    f = lambda v: f"{float(v):f}"  # noqa: E731
+    rows = [("min_x: ", f(min_x)), ("min_y: ", f(min_y)), ("n_entry: ", str(n)), ("missingness: ", str(k["missing"])),
+            ("completeness: ", f(out4[3])), ("tot: ", str(tot)), ("sum_obs: ", str(sum_obs)), ("dis: ", str(k["dis"])),
+            ("con_minus_dis (k_numerator): ", f(con_minus_dis)), ("n_tie: ", f(k["ntie"])), ("m: ", str(m)),
+            ("x_tie: ", f(k["xtie"])), ("y_tie: ", f(k["ytie"])), ("s_adjusted: ", f(s_adj)), ("var: ", f(var)),
+            ("z_b: ", f(z_b)), ("tau: ", f(out4[0])), ("tau_max:", f(out4[2])), ("pvalue: ", f(out4[1]))]
+    return "".join(a + b + "\n" for a, b in rows)
 
 
 def ici_kt_counts(x, y, perspective="local", device=None, exact_int64=False):
@@ -236,32 +325,38 @@ def _dist_info():
 
 
 def _run_sharded(engine, X, pi, pj, core, perspective, alternative, continuity):
-    """Each rank computes the pairs whose `core` is rank+1, then all ranks gather everything."""
+    """Each rank computes the pairs whose `core` is rank+1, then all ranks gather everything.
+
+    The HIP engine runs the whole sharded flow on the device (icikendalltau_amd/sharding.py): a rank uploads and
+    sorts only its share of the columns, `order` + `meta` are all-gathered, the pair block runs, and the padded
+    result blocks are all-gathered -- every buffer on the ENGINE's device (LOCAL_RANK-derived), never on torch's
+    ambient current device.  Any other engine (the checker of the CPU tests) computes its block through
+    engine.pairs() and the same gather.
+    """
     dist, rank, world = _dist_info()
     if world == 1:
         return engine.pairs(X, pi, pj, perspective, alternative, continuity)
     import torch
-    mine = np.nonzero(core == rank + 1)[0]
-    if len(mine):
-        out_l, rsn_l = engine.pairs(X, pi[mine], pj[mine], perspective, alternative, continuity)
+    from . import sharding
+    begin, end, n_each = sharding.pair_block(len(pi), rank, world)
+    assert np.array_equal(np.nonzero(core == rank + 1)[0], np.arange(begin, end)), "core chunks are consecutive blocks"
+    via_host = dist.get_backend() != "nccl"
+    if hasattr(engine, "pairs_block_dev"):
+        device = torch.device("cuda", engine.ctx.device)
+        out_l, rsn_l = engine.pairs_block_dev(X, pi, pj, begin, end, n_each, perspective, alternative, continuity,
+                                              dist, device, via_host)
     else:
-        out_l, rsn_l = np.empty((0, 4)), np.empty((0,), np.int32)
-    n_each = int(math.ceil(len(pi) / world))
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    buf = torch.full((n_each, 5), float("nan"), dtype=torch.float64)
-    buf[:len(mine), :4] = torch.from_numpy(np.ascontiguousarray(out_l))
-    buf[:len(mine), 4] = torch.from_numpy(rsn_l.astype(np.float64))
-    buf = buf.to(dev)
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf)  # RCCL over xGMI when backend == "nccl"
-    out = np.empty((len(pi), 4))
-    rsn = np.zeros(len(pi), np.int32)
-    for r in range(world):
-        idx = np.nonzero(core == r + 1)[0]
-        g = gathered[r].cpu().numpy()
-        out[idx] = g[:len(idx), :4]
-        rsn[idx] = g[:len(idx), 4].astype(np.int32)
+        device = torch.device("cpu")
+        out_l = torch.full((n_each, 4), float("nan"), dtype=torch.float64)
+        rsn_l = torch.zeros(n_each, dtype=torch.int32)
+        if end > begin:
+            o, r = engine.pairs(X, pi[begin:end], pj[begin:end], perspective, alternative, continuity)
+            out_l[:end - begin] = torch.from_numpy(np.ascontiguousarray(o))
+            rsn_l[:end - begin] = torch.from_numpy(np.ascontiguousarray(r, dtype=np.int32))
+    g_out = sharding.gather_blocks(dist, out_l, n_each, device, via_host or device.type == "cpu", to_all=True)
+    g_rsn = sharding.gather_blocks(dist, rsn_l, n_each, device, via_host or device.type == "cpu", to_all=True)
+    out = sharding.assemble(g_out, len(pi), n_each).cpu().numpy()
+    rsn = sharding.assemble(g_rsn, len(pi), n_each).cpu().numpy()
     return out, rsn
 
 

@@ -44,30 +44,42 @@ using icikt::host::use_device;
 
 namespace {
 
-// fold a pending event pair into the accumulated time (needs the events to have completed)
+// fold the recorded event pairs of kernel k into the accumulated time (waits for them to complete)
 int flush_timer(icikt_ctx* c, int k) {
-  if (!c->ev_pending[k]) return ICIKT_SUCCESS;
-  HIPCHK(c, hipEventSynchronize(c->ev[k][1]));
-  float t = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&t, c->ev[k][0], c->ev[k][1]));
-  c->ms[k] += (double)t;
-  c->launches[k] += 1;
-  c->ev_pending[k] = false;
+  for (size_t i = 0; i < c->ev_used[k]; ++i) {
+    HIPCHK(c, hipEventSynchronize(c->ev_pool[k][i].b));
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[k][i].a, c->ev_pool[k][i].b));
+    c->ms[k] += (double)t;
+    c->launches[k] += 1;
+  }
+  c->ev_used[k] = 0;
   return ICIKT_SUCCESS;
 }
 
 int timer_begin(icikt_ctx* c, int k, uint32_t flags) {
   if (!(flags & ICIKT_FLAG_TIMING)) return ICIKT_SUCCESS;
-  int rc = flush_timer(c, k);
-  if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->ev[k][0], c->stream));
+  if (c->ev_used[k] == c->ev_pool[k].size()) {
+    if (c->ev_pool[k].size() >= 256) {  // pool full: the one place a timed launch waits for earlier ones
+      int rc = flush_timer(c, k);
+      if (rc) return rc;
+    } else {
+      icikt_ctx::EvPair p;
+      HIPCHK(c, hipEventCreate(&p.a));
+      HIPCHK(c, hipEventCreate(&p.b));
+      c->ev_pool[k].push_back(p);
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev_pool[k][c->ev_used[k]].a, c->stream));
+  c->ev_open[k] = true;
   return ICIKT_SUCCESS;
 }
 
 int timer_end(icikt_ctx* c, int k, uint32_t flags) {
-  if (!(flags & ICIKT_FLAG_TIMING)) return ICIKT_SUCCESS;
-  HIPCHK(c, hipEventRecord(c->ev[k][1], c->stream));
-  c->ev_pending[k] = true;
+  if (!(flags & ICIKT_FLAG_TIMING) || !c->ev_open[k]) return ICIKT_SUCCESS;
+  HIPCHK(c, hipEventRecord(c->ev_pool[k][c->ev_used[k]].b, c->stream));
+  c->ev_used[k] += 1;
+  c->ev_open[k] = false;
   return ICIKT_SUCCESS;
 }
 
@@ -259,12 +271,6 @@ int icikt_ctx_create(int device, icikt_ctx** out) {
       icikt_ctx_destroy(c);
       return ICIKT_E_HIP;
     }
-  for (int k = 0; k < ICIKT_K_COUNT; ++k)
-    for (int j = 0; j < 2; ++j)
-      if (hipEventCreate(&c->ev[k][j]) != hipSuccess) {
-        icikt_ctx_destroy(c);
-        return ICIKT_E_HIP;
-      }
   *out = c;
   return ICIKT_SUCCESS;
 }
@@ -280,8 +286,10 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->d_pend_bits.release(); c->d_pend_pre.release();
   c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
-    for (int j = 0; j < 2; ++j)
-      if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
+    for (auto& p : c->ev_pool[k]) {
+      if (p.a) (void)hipEventDestroy(p.a);
+      if (p.b) (void)hipEventDestroy(p.b);
+    }
   for (auto& e : c->ev_copy)
     if (e) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -346,6 +354,7 @@ namespace host {
 
 int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_cols, int64_t sort_cols) {
   c->prepared = false;
+  c->raw_valid = false;
   PrepView pv{};
   pv.n = (int)n_feat;
   pv.n_pad = (int)((n_feat + 63) / 64 * 64);
@@ -384,6 +393,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
 
 int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end) {
   const PrepView& pv = c->pv;
+  c->raw_valid = false;
   if (col_end > col_begin)
     HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
                              (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), c->stream));
@@ -436,6 +446,24 @@ int icikt_prepare_cols_dev(icikt_ctx* c, const double* dX, int64_t n_feat, int64
   return prepare_impl(c, dX, n_feat, n_samp, ld, col_begin, col_end, alloc_cols, flags);
 }
 
+int icikt_prepare_cols_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = check_shape(c, "prepare", n_feat, n_samp, ld);
+  if (rc) return rc;
+  if (n_samp > 0 && n_feat > 0 && !X) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
+  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  rc = prepare_alloc(c, n_feat, n_samp, alloc_cols, col_end - col_begin);
+  if (rc) return rc;
+  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, col_begin, col_end, flags);
+  if (rc) return rc;
+  c->prepared = true;
+  return ICIKT_SUCCESS;
+}
+
 int icikt_expand_cols_dev(icikt_ctx* c, int64_t col_begin, int64_t col_end, uint32_t flags) {
   if (!c) return ICIKT_E_INVALID;
   if (!c->prepared) return fail(c, ICIKT_E_STATE, "expand_cols: nothing prepared");
@@ -443,6 +471,7 @@ int icikt_expand_cols_dev(icikt_ctx* c, int64_t col_begin, int64_t col_end, uint
     return fail(c, ICIKT_E_INVALID, "expand_cols: bad column range");
   int rc = use_device(c);
   if (rc) return rc;
+  c->raw_valid = false;
   rc = timer_begin(c, ICIKT_K_PREPARE, flags);
   if (rc) return rc;
   HIPCHK(c, icikt::launch_k0_expand(c->pv, (int)col_begin, (int)(col_end - col_begin), c->stream));
@@ -480,6 +509,7 @@ int icikt_set_pairs(icikt_ctx* c, const int32_t* pi, const int32_t* pj, int64_t 
   }
   c->n_pairs = n_pairs;
   c->pairs_nsamp = (int64_t)mx + 1;
+  c->raw_valid = false;
   c->wpb = 0;  // units are (re)built at run time for the plan of the prepared matrix
   return upload_pairs(c);
 }
@@ -515,6 +545,7 @@ int icikt_set_pairs_combn(icikt_ctx* c, int64_t n_samp, int64_t begin, int64_t e
   }
   c->n_pairs = end - begin;
   c->pairs_nsamp = n_samp;
+  c->raw_valid = false;
   c->wpb = 0;
   return upload_pairs(c);
 }
@@ -541,7 +572,11 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     rc = upload_units(c);
     if (rc) return rc;
   }
-  if (c->pv.n > 0) {
+  // The pair kernel's counts (dis, joint ties, both-missing rows) do not depend on perspective, alternative or
+  // continuity: with ICIKT_FLAG_REUSE_COUNTS a second run over the same prepared matrix and pair list (the other
+  // perspective of BASELINE config 5, another alternative) is the epilogue alone.
+  const bool reuse = (flags & ICIKT_FLAG_REUSE_COUNTS) && c->raw_valid;
+  if (c->pv.n > 0 && !reuse) {
     rc = timer_begin(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
     // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
@@ -578,6 +613,7 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
                                c->d_pend_pre.p, pl.opts, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
+    c->raw_valid = true;
   }
   rc = timer_begin(c, ICIKT_K_EPILOGUE, flags);
   if (rc) return rc;
@@ -675,7 +711,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
       if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
       if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
     }
-    if (registered || e != hipSuccess || rc) {
+    if (registered || mode == 0 || e != hipSuccess || rc) {
       // the caller's buffer must stay page-locked (and alive) until the last copy has read it
       (void)hipStreamSynchronize(c->copy_stream);
       if (registered) (void)hipHostUnregister(const_cast<double*>(src0));
@@ -847,6 +883,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   }
   c->plan_ov = ov;
   c->h2d_mode = h2d;
+  c->raw_valid = false;
   c->wpb = 0;  // tasks are rebuilt for the new plan
   return ICIKT_SUCCESS;
 }

@@ -55,6 +55,7 @@ struct icikt_ctx {
   int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
   int n_units = 0;
   int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
+  bool raw_valid = false;  // d_raw holds the pair kernel's counts for the current prepared matrix and pair list
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<icikt::PairRaw> d_raw;
   DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
@@ -81,8 +82,12 @@ struct icikt_ctx {
   } plan_ov;
 
   // timing
-  hipEvent_t ev[ICIKT_K_COUNT][2] = {};
-  bool ev_pending[ICIKT_K_COUNT] = {};
+  // per kernel id a pool of HIP event pairs: several timed launches per step accumulate without a host stall
+  // and are folded into ms[] when the figures are read (or when the pool is full)
+  struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
+  std::vector<EvPair> ev_pool[ICIKT_K_COUNT];
+  size_t ev_used[ICIKT_K_COUNT] = {};
+  bool ev_open[ICIKT_K_COUNT] = {};
   double ms[ICIKT_K_COUNT] = {};
   int64_t launches[ICIKT_K_COUNT] = {};
 };

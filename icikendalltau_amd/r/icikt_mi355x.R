@@ -1,10 +1,12 @@
 # icikt_mi355x.R -- R-side drop-in for the reference's hot path, over icikt_rglue.c.
 #
 # NOT runnable in the build container (no R there).  It keeps the reference's R-level API and return
-# shapes (R/kendalltau.R:96-179, R/RcppExports.R:62-64) and only swaps the two places where the
-# reference crosses into native code:
+# shapes (R/kendalltau.R:96-179, R/RcppExports.R:62-64) and only swaps the places where the
+# reference crosses into native code or into worker processes:
 #   ici_split()  (R/kendalltau.R:280-308)  -> one .Call per pair LIST  (ici_split_gpu)
 #   ici_kt()     (R/RcppExports.R:62-64)   -> one .Call for one pair   (ici_kt_gpu)
+#   computation$split_fun(split_comparisons, ici_split, ...)  (R/kendalltau.R:158)
+#                                          -> ONE .Call for all chunks, n_gpu GPUs inside it (ici_split_all_gpu)
 # Everything around them (setup_missing_matrix, setup_comparisons, scale_and_reshape) is the
 # reference's own R code and stays untouched.
 
@@ -13,14 +15,17 @@
   "3" = "Warning: Either 'X' or 'Y' have only a single unique value, NA returned!",
   "4" = "Warning: Ties equal the total, NA returned!")
 
-# Replacement for ici_split(): same arguments, same returned data.frame.
+.icikt_count_names = c("n_entry", "missingness", "dis", "n_tie", "x_tie", "y_tie", "x0", "x1", "y0", "y1", "tot")
+
+# Replacement for ici_split(): same arguments, same returned data.frame.  n_gpu > 1 spreads the chunk over
+# devices device .. device + n_gpu - 1 inside the one call.
 ici_split_gpu = function(do_comparisons, exclude_data, perspective, do_log_memory, alternative, continuity,
-                         device = 0L) {
+                         device = 0L, n_gpu = 1L) {
   storage.mode(exclude_data) = "double"          # Rcpp coerces integer input the same way
   pi = match(do_comparisons[, 1], colnames(exclude_data))
   pj = match(do_comparisons[, 2], colnames(exclude_data))
   res = .Call("icikt_R_pairs", exclude_data, as.integer(pi), as.integer(pj), perspective, alternative,
-              continuity, as.integer(device))
+              continuity, as.integer(device), as.integer(n_gpu), FALSE)
   for (r in res$reason[res$reason > 1L]) warning(.icikt_warn[[as.character(r)]], call. = FALSE)
   do_comparisons$raw = res$raw
   do_comparisons$pvalue = res$pvalue
@@ -29,18 +34,58 @@ ici_split_gpu = function(do_comparisons, exclude_data, perspective, do_log_memor
   do_comparisons
 }
 
-# Replacement for ici_kt(): identical defaults and a named numeric(4).
+# Replacement for the dispatch line of ici_kendalltau() (R/kendalltau.R:158)
+#   split_cor = computation$split_fun(split_comparisons, ici_split, exclude_data, perspective, ...)
+# `split_comparisons` is the list of `core` chunks that setup_comparisons() made (consecutive blocks of
+# ceiling(n_todo / ncore) pairs, R/kendalltau.R:250-255).  HIP must not be driven from forked furrr workers, so the
+# chunks are bound back together (they are consecutive), computed by ONE .Call that uses all n_gpu GPUs --
+# inside it the same ceiling(n_todo / n_gpu) blocks go to the GPUs, each GPU sorts 1 / n_gpu of the columns, and
+# RCCL moves the prepared columns and the results over xGMI -- and split again, so that scale_and_reshape()
+# (R/kendalltau.R:357-421) receives exactly what split_fun would have returned.
+ici_split_all_gpu = function(split_comparisons, exclude_data, perspective, do_log_memory, alternative, continuity,
+                             n_gpu = length(split_comparisons), device = 0L) {
+  all_comparisons = do.call(rbind, split_comparisons)
+  done = ici_split_gpu(all_comparisons, exclude_data, perspective, do_log_memory, alternative, continuity,
+                       device = device, n_gpu = n_gpu)
+  split(done, done$core)
+}
+
+# Replacement for ici_kt(): identical defaults and a named numeric(4); output != "simple" prints the report of
+# src/kendallc.cpp:342-363 (same labels, std::to_string = "%f" formatting) from the integer counts record.
 ici_kt_gpu = function(x, y, perspective = "local", alternative = "two.sided", continuity = FALSE,
                       output = "simple", device = 0L) {
   if (length(x) != length(y)) stop("'X' and 'Y' are not the same length!")
   m = cbind(as.double(x), as.double(y))
-  res = .Call("icikt_R_pairs", m, 1L, 2L, perspective, alternative, continuity, as.integer(device))
+  want_report = !identical(output, "simple")
+  res = .Call("icikt_R_pairs", m, 1L, 2L, perspective, alternative, continuity, as.integer(device), 1L, want_report)
   if (res$reason > 1L) warning(.icikt_warn[[as.character(res$reason)]], call. = FALSE)
-  c(tau = res$raw, pvalue = res$pvalue, tau_max = res$taumax, completeness = res$completeness)
+  out = c(tau = res$raw, pvalue = res$pvalue, tau_max = res$taumax, completeness = res$completeness)
+  if (want_report && res$reason == 0L) {   # the reference returns before its report for every NA case
+    k = stats::setNames(as.numeric(res$counts[1, ]), .icikt_count_names)
+    keep = if (identical(perspective, "local")) !(is.na(m[, 1]) & is.na(m[, 2])) else rep(TRUE, nrow(m))
+    x2 = m[keep, 1]; y2 = m[keep, 2]
+    min_x = min(x2, na.rm = TRUE) - 0.1; min_y = min(y2, na.rm = TRUE) - 0.1
+    x2[is.na(x2)] = min_x; y2[is.na(y2)] = min_y
+    sum_obs = sum(!duplicated(cbind(x2, y2))) + 1        # joint runs + 1 (kendallc.cpp:261-263)
+    n = k[["n_entry"]]; mm = n * (n - 1)
+    con_minus_dis = k[["tot"]] - k[["x_tie"]] - k[["y_tie"]] + k[["n_tie"]] - 2 * k[["dis"]]
+    var = (mm * (2 * n + 5) - k[["x1"]] - k[["y1"]]) / 18 + (2 * k[["x_tie"]] * k[["y_tie"]]) / mm +
+      k[["x0"]] * k[["y0"]] / (9 * mm * (n - 2))
+    s_adjusted = out[["tau"]] * sqrt((mm / 2 - k[["x_tie"]]) * (mm / 2 - k[["y_tie"]]))
+    if (continuity) s_adjusted = sign(s_adjusted) * (abs(s_adjusted) - 1)
+    f = function(v) sprintf("%f", v); d = function(v) sprintf("%.0f", v)
+    cat("min_x: ", f(min_x), "\nmin_y: ", f(min_y), "\nn_entry: ", d(n), "\nmissingness: ", d(k[["missingness"]]),
+        "\ncompleteness: ", f(out[["completeness"]]), "\ntot: ", d(k[["tot"]]), "\nsum_obs: ", d(sum_obs),
+        "\ndis: ", d(k[["dis"]]), "\ncon_minus_dis (k_numerator): ", f(con_minus_dis), "\nn_tie: ", f(k[["n_tie"]]),
+        "\nm: ", d(mm), "\nx_tie: ", f(k[["x_tie"]]), "\ny_tie: ", f(k[["y_tie"]]), "\ns_adjusted: ", f(s_adjusted),
+        "\nvar: ", f(var), "\nz_b: ", f(s_adjusted / sqrt(var)), "\ntau: ", f(out[["tau"]]),
+        "\ntau_max:", f(out[["tau_max"]]), "\npvalue: ", f(out[["pvalue"]]), "\n", sep = "")
+  }
+  out
 }
 
-# In ici_kendalltau() (R/kendalltau.R:158) the only change is the dispatch line: HIP must not be driven
-# from forked `multicore` workers, so the GPU path maps over the chunks in the calling process:
-#   split_cor = purrr::map(split_comparisons, ici_split_gpu, exclude_data, perspective, do_log_memory,
-#                          alternative, continuity)
-# (one chunk per GPU when several are used: pass device = chunk index - 1).
+# In ici_kendalltau() (R/kendalltau.R:127-160) the change is two lines:
+#   ncore = n_gpu                       # instead of check_furrr()'s future::nbrOfWorkers(): `core` chunks = GPUs
+#   split_cor = ici_split_all_gpu(split_comparisons, exclude_data, perspective, do_log_memory, alternative,
+#                                 continuity, n_gpu = n_gpu)
+# With n_gpu = 1 this is ici_split_gpu() on the single chunk.

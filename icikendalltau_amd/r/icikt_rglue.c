@@ -8,11 +8,16 @@
  *   R CMD SHLIB icikt_rglue.c -I<repo>/include -L<repo>/icikendalltau_amd -licikt_hip
  *
  * Registered routines (R_CallMethodDef, as src/RcppExports.cpp:113-128 does for the Rcpp path):
- *   .Call("icikt_R_pairs", exclude_data, pi, pj, perspective, alternative, continuity, device)
+ *   .Call("icikt_R_pairs", exclude_data, pi, pj, perspective, alternative, continuity, device, n_gpu, want_counts)
  *       exclude_data  REALSXP matrix n_feat x n_samp (column-major, NA = missing; integer input is
  *                     coerced by the R wrapper, as Rcpp does for NumericVector)
  *       pi, pj        INTSXP, 1-based column indices (R convention); NULL = all combn pairs
- *       returns list(raw, pvalue, taumax, completeness, reason) of length-P vectors
+ *       device        first HIP device; n_gpu devices device .. device + n_gpu - 1 are used
+ *       n_gpu         1: icikt_pairs_f64 on one device.  > 1: icikt_pairs_multi_f64 -- ONE call, one host thread
+ *                     per GPU inside the library, RCCL all-gather / gather over xGMI; replaces the furrr fan-out of
+ *                     R/kendalltau.R:158 (HIP must not be driven from forked multicore workers)
+ *       want_counts   TRUE: also the P x 11 integer counts record (the numbers src/kendallc.cpp:342-363 prints)
+ *       returns list(raw, pvalue, taumax, completeness, reason[, counts]) of length-P vectors
  *   .Call("icikt_R_missingness", exclude_data, pi, pj, device) -> numeric(P)
  * Errors become R errors (Rf_error), as BEGIN_RCPP/END_RCPP does (src/RcppExports.cpp:84,95);
  * per-pair degenerate cases are returned as NA_real_ x4 plus a reason code so that the R wrapper can
@@ -27,6 +32,8 @@
 
 static icikt_ctx *g_ctx = NULL;
 static int g_dev = -1;
+static icikt_multi *g_multi = NULL; /* communicators are expensive: kept until (device, n_gpu) changes */
+static int g_multi_dev = -1, g_multi_n = 0;
 
 static icikt_ctx *get_ctx(int device) {
   if (g_ctx && g_dev == device) return g_ctx;
@@ -36,6 +43,19 @@ static icikt_ctx *get_ctx(int device) {
   if (rc != ICIKT_SUCCESS) Rf_error("icikt: icikt_ctx_create(%d) failed with code %d", device, rc);
   g_dev = device;
   return g_ctx;
+}
+
+static icikt_multi *get_multi(int device, int n_gpu) {
+  if (g_multi && g_multi_dev == device && g_multi_n == n_gpu) return g_multi;
+  if (g_multi) { icikt_multi_destroy(g_multi); g_multi = NULL; }
+  int *devs = (int *)R_alloc(n_gpu, sizeof(int));
+  for (int k = 0; k < n_gpu; ++k) devs[k] = device + k;
+  int rc = icikt_multi_create(devs, n_gpu, ICIKT_MULTI_EXCHANGE_AUTO, &g_multi);
+  if (rc == ICIKT_E_NO_DEVICE) Rf_error("icikt: no usable HIP device (there is no CPU fallback)");
+  if (rc != ICIKT_SUCCESS) Rf_error("icikt: icikt_multi_create(%d devices from %d) failed with code %d", n_gpu, device, rc);
+  g_multi_dev = device;
+  g_multi_n = n_gpu;
+  return g_multi;
 }
 
 static int perspective_code(SEXP s) {
@@ -51,10 +71,14 @@ static int alternative_code(SEXP s) {
   return ICIKT_ALT_OTHER; /* p-value stays 0, as in the reference (:323-332) */
 }
 
-SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative, SEXP continuity, SEXP device) {
+SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative, SEXP continuity, SEXP device,
+                   SEXP n_gpu, SEXP want_counts) {
   if (!Rf_isReal(x) || !Rf_isMatrix(x)) Rf_error("icikt: exclude_data must be a double matrix");
   const int64_t n_feat = Rf_nrows(x), n_samp = Rf_ncols(x);
-  icikt_ctx *ctx = get_ctx(Rf_asInteger(device));
+  const int ngpu = Rf_asInteger(n_gpu) > 1 ? Rf_asInteger(n_gpu) : 1;
+  const int with_counts = Rf_asLogical(want_counts) == TRUE;
+  icikt_ctx *ctx = (ngpu == 1) ? get_ctx(Rf_asInteger(device)) : NULL;
+  icikt_multi *multi = (ngpu > 1) ? get_multi(Rf_asInteger(device), ngpu) : NULL;
   int64_t P;
   int32_t *pi0 = NULL, *pj0 = NULL;
   if (Rf_isNull(pi)) {
@@ -68,10 +92,18 @@ SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative,
   }
   double *out4 = (double *)R_alloc(P > 0 ? 4 * P : 1, sizeof(double));
   int32_t *reasons = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
-  int rc = icikt_pairs_f64(ctx, REAL(x), n_feat, n_samp, n_feat, pi0, pj0, P, perspective_code(perspective),
-                           alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u, out4, NULL, reasons);
-  if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_last_error(ctx), rc);
-  const char *nm[] = {"raw", "pvalue", "taumax", "completeness", "reason", ""};
+  int64_t *counts = with_counts ? (int64_t *)R_alloc(P > 0 ? P * ICIKT_CNT_FIELDS : 1, sizeof(int64_t)) : NULL;
+  int rc;
+  if (multi) {
+    rc = icikt_pairs_multi_f64(multi, REAL(x), n_feat, n_samp, n_feat, pi0, pj0, P, perspective_code(perspective),
+                               alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u, out4, counts, reasons);
+    if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_multi_last_error(multi), rc);
+  } else {
+    rc = icikt_pairs_f64(ctx, REAL(x), n_feat, n_samp, n_feat, pi0, pj0, P, perspective_code(perspective),
+                         alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u, out4, counts, reasons);
+    if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_last_error(ctx), rc);
+  }
+  const char *nm[] = {"raw", "pvalue", "taumax", "completeness", "reason", "counts", ""};
   SEXP res = PROTECT(Rf_mkNamed(VECSXP, nm));
   for (int f = 0; f < 4; ++f) {
     SEXP v = PROTECT(Rf_allocVector(REALSXP, P));
@@ -82,6 +114,13 @@ SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative,
   SEXP r = PROTECT(Rf_allocVector(INTSXP, P));
   for (int64_t p = 0; p < P; ++p) INTEGER(r)[p] = reasons[p];
   SET_VECTOR_ELT(res, 4, r);
+  if (with_counts) { /* P x 11, columns in the order of ICIKT_CNT_*; doubles hold every count exactly (< 2^53) */
+    SEXP cm = PROTECT(Rf_allocMatrix(REALSXP, (int)P, ICIKT_CNT_FIELDS));
+    for (int64_t p = 0; p < P; ++p)
+      for (int f = 0; f < ICIKT_CNT_FIELDS; ++f) REAL(cm)[(int64_t)f * P + p] = (double)counts[p * ICIKT_CNT_FIELDS + f];
+    SET_VECTOR_ELT(res, 5, cm);
+    UNPROTECT(1);
+  }
   UNPROTECT(2);
   return res;
 }
@@ -103,7 +142,7 @@ SEXP icikt_R_missingness(SEXP x, SEXP pi, SEXP pj, SEXP device) {
 }
 
 static const R_CallMethodDef CallEntries[] = {
-    {"icikt_R_pairs", (DL_FUNC)&icikt_R_pairs, 7},
+    {"icikt_R_pairs", (DL_FUNC)&icikt_R_pairs, 9},
     {"icikt_R_missingness", (DL_FUNC)&icikt_R_missingness, 4},
     {NULL, NULL, 0}};
 
@@ -115,4 +154,5 @@ void R_init_icikt_rglue(DllInfo *dll) {
 void R_unload_icikt_rglue(DllInfo *dll) {
   (void)dll;
   if (g_ctx) { icikt_ctx_destroy(g_ctx); g_ctx = NULL; }
+  if (g_multi) { icikt_multi_destroy(g_multi); g_multi = NULL; }
 }

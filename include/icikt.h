@@ -64,6 +64,10 @@ extern "C" {
 #define ICIKT_FLAG_EXACT_INT64 1u /* tie sums in int64 instead of the reference's wrapping int32
                                      (count_rank_tie, src/kendallc.cpp:112-114) */
 #define ICIKT_FLAG_TIMING 2u      /* record HIP events around each kernel (icikt_kernel_ms) */
+#define ICIKT_FLAG_REUSE_COUNTS 4u /* icikt_run_dev: if the pair kernel already ran for this prepared matrix and pair
+                                     list, keep its integer counts and run the epilogue only -- "local" is derived
+                                     from the same counts as "global", so the second perspective (or another
+                                     alternative / continuity) costs microseconds */
 
 /* per-pair reason codes; the host wrapper raises the reference's warnings from them */
 #define ICIKT_OK 0
@@ -124,6 +128,10 @@ int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t 
  * every rank an even number of columns. */
 #define ICIKT_PREP_ARRAYS 5
 int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);
+/* The same from a HOST matrix: columns [col_begin, col_end) are copied to the device in chunks that overlap
+ * their pre-pass (a rank uploads 1 / world of the matrix).  Returns when X has been read. */
+int icikt_prepare_cols_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
                            int64_t col_begin, int64_t col_end, int64_t alloc_cols, uint32_t flags);
 int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);
 /* ICIKT_PREP_ORDER (the descending permutation) and ICIKT_PREP_META (per column: missing-row, fill-group and

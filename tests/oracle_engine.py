@@ -15,6 +15,11 @@ class OracleEngine:
         out, _cnt, rsn = O.ici_pairs(X, pi, pj, perspective, alternative, continuity, want_counts=False)
         return out, rsn
 
+    def pairs_counts(self, X, pi, pj, perspective, alternative, continuity):
+        out, cnt, rsn = O.ici_pairs(X, pi, pj, perspective, alternative, continuity, want_counts=True)
+        names = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
+        return out, rsn, {k: cnt[:, i] for i, k in enumerate(names)}
+
     def missingness(self, X, pi, pj):
         m = np.isnan(np.asarray(X))
         return np.array([(m[:, i] | m[:, j]).sum() for i, j in zip(pi, pj)], dtype=np.int64)

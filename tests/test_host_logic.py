@@ -203,3 +203,31 @@ def test_kt_fast_snapshots(expected):
         api.kt_fast(X[:, 0], engine=ENG)
     with pytest.raises(ValueError, match="must be vectors"):
         api.kt_fast(X, X, colnames=names, engine=ENG)
+
+
+def test_ici_kt_report_output(capsys):
+    """ici_kt(output != "simple") prints the report of src/kendallc.cpp:342-363: same labels in the same order,
+    integers as integers, doubles in std::to_string's "%f" form; nothing is printed for NA results (the reference
+    returns before the report) or for output = "simple"."""
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+    x = np.arange(1.0, 11.0)
+    y = x.copy()
+    y[1] = 15.0                                           # tests/testthat/test-kendall-tau.R:8-10
+    res = api.ici_kt(x, y, "global", output="full", engine=OracleEngine())
+    text = capsys.readouterr().out
+    labels = [ln.split(":")[0] for ln in text.splitlines()]
+    assert labels == ["min_x", "min_y", "n_entry", "missingness", "completeness", "tot", "sum_obs", "dis",
+                      "con_minus_dis (k_numerator)", "n_tie", "m", "x_tie", "y_tie", "s_adjusted", "var", "z_b", "tau",
+                      "tau_max", "pvalue"]
+    d = dict(ln.split(":", 1) for ln in text.splitlines())
+    assert d["min_x"].strip() == "0.900000" and d["n_entry"].strip() == "10" and d["tot"].strip() == "45"
+    assert d["sum_obs"].strip() == "11" and d["dis"].strip() == "8" and d["m"].strip() == "90"
+    assert d["con_minus_dis (k_numerator)"].strip() == "29.000000"
+    assert abs(float(d["tau"]) - res.tau) < 1e-6 and abs(float(d["pvalue"]) - res.pvalue) < 1e-6
+    assert float(d["var"]) == 125.0                       # n(n-1)(2n+5)/18 without ties
+    api.ici_kt(x, y, "global", engine=OracleEngine())
+    assert capsys.readouterr().out == ""
+    with pytest.warns(RuntimeWarning):
+        api.ici_kt(x, np.ones(10), "global", output="full", engine=OracleEngine())
+    assert capsys.readouterr().out == ""

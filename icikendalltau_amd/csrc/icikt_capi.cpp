@@ -109,7 +109,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // the latency of a step better than two pairs per wave share their loads (yeast, 4 560 pairs: 0.69 -> 0.48 ms)
   if (n_pairs <= (int64_t)24 * n_cu) np = 1;
   {
-    const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2 + 2);  // seen, pend + spre, ppre
+    const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2) + icikt::K1_TL_BYTES;  // seen, pend, ppre + counts
     pl.pend_global = !half_ok && full * 20 > lds_cap;
   }
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable);
@@ -135,8 +135,9 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  pl.perpair_bytes = (int)(pl.pend_global ? (((size_t)pl.stride * (8 + 2) + 15) & ~(size_t)15)
-                                          : (size_t)pl.stride * (8 + 8 + 2 + 2));
+  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2 + 2));  // seen, pend, spre, ppre
+  else  // one pair per wave: seen [, pend], the two-level counts [, ppre]
+    pl.perpair_bytes = (int)((size_t)pl.stride * (pl.pend_global ? 8 : (8 + 8 + 2)) + icikt::K1_TL_BYTES);
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
@@ -359,7 +360,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   pv.n = (int)n_feat;
   pv.n_pad = (int)((n_feat + 63) / 64 * 64);
   if (pv.n_pad == 0) pv.n_pad = 64;
-  pv.n_ord = pv.n_pad + 128;  // K1 prefetches the next step's rows: up to index n - 1 + 63 + 64
+  pv.n_ord = pv.n_pad + 256;  // K1 loads rows up to three steps ahead: indices up to n + 191, zero padded
   pv.W = (int)((n_feat + 63) / 64);
   pv.Wp = pv.W + 1;
   int np2 = 2;
@@ -581,19 +582,29 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     if (rc) return rc;
     // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
     // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
-    // wave owns a slot of it, so waves are persistent and stride over the task list; the grid is 8x what the
-    // chip holds at once (slots: a few hundred MB at n = 50 000).
+    // wave owns a slot of it.  Up to 8x what the chip holds at once the grid still covers the task list (one task
+    // per wave; slots: a few hundred MB at n = 50 000).  Beyond that the grid is exactly what the chip holds and
+    // the waves stride over the task list: in round k ALL resident waves work on the window [k * waves, (k + 1) *
+    // waves) of consecutive tasks, i.e. each XCD on one gathered block at a time, which stays in its 4 MB L2.
+    // (A grid of 8x the resident waves with 64 tasks per wave was measured at 1.9e6 pairs/s on the full c5 matrix
+    // against 3.5e6 on a 512-column one: blocks that start late begin at round 0 beside blocks in round 40, every
+    // XCD gathers from dozens of 400 KB blocks at once and the gathers fall out of L2.)
     int per_cu = 0;
     HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
-    per_cu = pl.pend_global ? per_cu * 8 : (1 << 20);
     const int want = (c->n_units + pl.wpb - 1) / pl.wpb;
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)per_cu * c->prop.multiProcessorCount));
-    {  // even rounds: shrink the grid so that every wave walks the same number of tasks
+    int blocks = want;
+    if (pl.pend_global) {
+      const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
+      const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 8;
+      if (c->plan_ov.grid_mult > 0) blocks = (int)std::min<int64_t>(want, mult * resident);
+      else if (want > mult * resident) blocks = (int)resident;
+      // even rounds: shrink the grid so that every wave walks the same number of tasks
       const int64_t waves = (int64_t)blocks * pl.wpb;
       const int64_t rounds = (c->n_units + waves - 1) / waves;
       blocks = (int)std::max<int64_t>(1, (c->n_units + rounds * pl.wpb - 1) / (rounds * pl.wpb));
     }
+    blocks = std::max(blocks, 1);
     if (c->plan_ov.verbose)
       fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
               pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
@@ -853,7 +864,8 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 
 // Development / test hook: "key=value,key=value" overrides of the pair kernel's launch plan and of the host
 // path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
-// wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), h2d (plain | register | stage),
+// wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), gridmult (persistent grid as a
+// multiple of the resident waves, always), h2d (plain | register | stage),
 // verbose (0 | 1: print the plan to stderr).
 int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   if (!c) return ICIKT_E_INVALID;
@@ -877,6 +889,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "half") ov.half = (val[0] == '1') ? 1 : 0;
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
     else if (key == "verbose") ov.verbose = (val[0] == '1');
+    else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "h2d") h2d = (val == "plain") ? 0 : (val == "register") ? 1 : (val == "stage") ? 2 : -2;
     else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
     if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be plain, register or stage");

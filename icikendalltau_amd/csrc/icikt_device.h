@@ -37,7 +37,7 @@ static_assert(sizeof(ColStats) == 64, "ColStats is 8 words of a column's meta re
 struct PrepView {
   int n;       // n_feat (rows per column)
   int n_pad;   // n rounded up to a multiple of 64
-  int n_ord;   // n_pad + 64: stride of `order`, zero padded so that K1 can prefetch one step ahead
+  int n_ord;   // n_pad + 256: stride of `order`, zero padded so that K1 can load rows three steps ahead
   int W;       // ceil(n / 64) bitset words
   int Wp;      // W + 1 (one zero guard word)
   int npow2;   // sort scratch length per column
@@ -67,6 +67,9 @@ struct PrepView {
   unsigned long long* sort_keys;  // [chunk][npow2]
   uint32_t* sort_idx;             // [chunk][npow2]
 };
+
+// one pair per wave: bytes of the two-level counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32)
+constexpr int K1_TL_BYTES = 2048 + 256 + 256;
 
 // half-wave K1 kernels exist for 1..ICIKT_HALF_ITEMS_MAX words per lane of a half's prefix rebuild (n <= 10 176)
 constexpr int ICIKT_HALF_ITEMS_MAX = 5;

@@ -862,33 +862,106 @@ __device__ __forceinline__ uint32_t wave_allpairs(uint32_t q, uint32_t lo, uint3
   return acc - ((lo != 0u) ? (15u - (lane & 15u)) : 0u);
 }
 
-// Prefix rebuild for long columns (more than 4 words per lane; arrays padded to 64 * items2 words, items2
-// even: k1_lds_stride): lane l owns words [l*items2, (l+1)*items2).  Pass 1 reads two words at a time and
-// stores the lane-local exclusive counts of both as one dword; after the wave scan pass 2 adds the lane's
-// base to both halves of every dword with one LDS add (no carry between the halves: every count <= n < 2^16).
-__device__ __forceinline__ void rebuild_prefix_long(const unsigned long long* bits, uint16_t* pre, int items2,
-                                                    uint32_t lane) {
-  const uint32_t base = lane * (uint32_t)items2;
-  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(bits + base);
-  uint32_t* p32 = reinterpret_cast<uint32_t*>(pre + base);
-  const int it = items2 >> 1;
-  uint32_t run = 0;
-#pragma unroll 2
-  for (int i = 0; i < it; ++i) {
-    const ulonglong2 v = b2[i];
-    const uint32_t c0 = run;
-    run = (uint32_t)__builtin_popcount((uint32_t)v.x) + run;
-    run = (uint32_t)__builtin_popcount((uint32_t)(v.x >> 32)) + run;
-    const uint32_t c1 = run;
-    run = (uint32_t)__builtin_popcount((uint32_t)v.y) + run;
-    run = (uint32_t)__builtin_popcount((uint32_t)(v.y >> 32)) + run;
-    p32[i] = c0 | (c1 << 16);
+// ---- two-level prefix for one pair per wave (long columns): O(1) work per step -------------------------------
+// The flat prefix above is rebuilt over all W words after every 64-row step: O(n / 64) per step, O(n^2) per pair.
+// Here lane l OWNS the IT words [l * IT, (l + 1) * IT) of `seen` (IT = words per lane, even, <= 16) and the count
+// below a position is split in three:
+//     #{seen bits below pos} = lb[o] + loc[o][j] + popc(seen[w] & below(pos))      w = pos >> 6, o = w / IT, j = w % IT
+//   lb[o]      bits in the words of owners < o          (64 x u32)
+//   loc[o][j]  bits in words [o * IT, o * IT + j)       (64 x 16 x u16, 32 bytes per owner)
+// and all three are kept up to date by the lanes that INSERT, with LDS atomics whose number does not depend on n:
+//   * seen: one 32-bit OR per row (as before);
+//   * lb:   a 64-bin histogram of the rows' owners (one atomic add per row into `hist`), an exclusive wave scan of it
+//           (read-and-clear: one ds_wrxchg per lane), one atomic add per lane into lb;
+//   * loc:  a row in word j of its owner adds 1 to loc[o][j'] for every j' > j: the 16 u16 counters of an owner are
+//           four u64 words, and "+1 in all fields above f" is ONE 64-bit atomic add of a constant pattern (no carry
+//           between the fields: every counter stays below 16 * 64).  ceil(IT / 4) such adds per step.
+// A step therefore costs the same at n = 12 000 and at n = 65 535.  After a merge of `pend` into `seen` (a tie group
+// of the streamed column closes) everything is recomputed once from the words (tl_rebuild).
+struct TwoLevel {
+  unsigned long long* seen;
+  uint16_t* loc;    // [64][16]
+  uint32_t* lb;     // [64]
+  uint32_t* hist;   // [64], all zero between steps
+};
+__device__ __forceinline__ TwoLevel tl_view(unsigned long long* seen, uint16_t* spre) {
+  TwoLevel t;
+  t.seen = seen;
+  t.loc = spre;
+  t.lb = reinterpret_cast<uint32_t*>(spre + 1024);
+  t.hist = t.lb + 64;
+  return t;
+}
+constexpr int TL_BYTES = K1_TL_BYTES;  // loc + lb + hist
+// words per owner: the W = Wp - 1 words that can hold bits (the guard word never does) over 64 lanes, rounded up
+// to even (two words are read at a time); <= 16 for every n <= 65 535
+__device__ __forceinline__ int tl_items(int Wp) { return ((((Wp - 1) + 63) >> 6) + 1) & ~1; }
+__device__ __forceinline__ uint32_t tl_magic(int IT) {  // 65536 / IT + 1 for the even IT <= 16
+  switch (IT >> 1) {
+    case 1: return 32769u; case 2: return 16385u; case 3: return 10923u; case 4: return 8193u;
+    case 5: return 6554u;  case 6: return 5462u;  case 7: return 4682u;  default: return 4097u;
   }
-  const uint32_t excl = wave_incl_scan(run) - run;
-  const uint32_t add = excl | (excl << 16);
+}
+
+// word -> (owner, index inside the owner); magic = 65536 / IT + 1 is exact for every w < 1100, IT <= 16
+__device__ __forceinline__ void tl_split(uint32_t w, int IT, uint32_t magic, uint32_t& o, uint32_t& j) {
+  o = (w * magic) >> 16;
+  j = w - o * (uint32_t)IT;
+}
+
+__device__ __forceinline__ uint32_t tl_query(const TwoLevel& T, uint32_t pos, int IT, uint32_t magic) {
+  const uint32_t w = pos >> 6;
+  uint32_t o, j;
+  tl_split(w, IT, magic, o, j);
+  return T.lb[o] + (uint32_t)T.loc[o * 16u + j] + (uint32_t)__popcll(T.seen[w] & low_mask64(pos & 63u));
+}
+
+// Rows with ins == true have just been OR-ed into seen at position q (by these lanes): bring lb and loc up to date.
+// Every lane of the wave takes part (scan, read-and-clear of its histogram bin).
+__device__ __forceinline__ void tl_update(const TwoLevel& T, bool ins, uint32_t q, int IT, uint32_t magic, uint32_t lane) {
+  uint32_t o, j;
+  tl_split((q & 0xFFFFu) >> 6, IT, magic, o, j);
+  if (ins) atomicAdd(&T.hist[o], 1u);
+  // loc: +1 in the fields above j of the owner's 16 counters
+  const uint32_t g0 = j >> 2, f = j & 3u;
+  const unsigned long long FULL = 0x0001000100010001ull;
+  const unsigned long long part = (f == 3u) ? 0ull : (FULL << (16u * (f + 1u)));
+  const int ng = (IT + 3) >> 2;
+  unsigned long long* loc64 = reinterpret_cast<unsigned long long*>(T.loc) + o * 4u;
+  for (int g = 0; g < ng; ++g) {
+    const unsigned long long v = ((uint32_t)g < g0) ? 0ull : (((uint32_t)g == g0) ? part : FULL);
+    if (ins && v != 0ull) atomicAdd(&loc64[g], v);
+  }
   wave_lds_fence();
-#pragma unroll 2
-  for (int i = 0; i < it; ++i) atomicAdd(&p32[i], add);
+  const uint32_t h = atomicExch(&T.hist[lane], 0u);
+  const uint32_t below = wave_incl_scan(h) - h;
+  if (below != 0u) atomicAdd(&T.lb[lane], below);
+}
+
+// Recompute loc and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
+template <bool PG>
+__device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge_from, int IT, uint32_t lane) {
+  const uint32_t base = lane * (uint32_t)IT;
+  ulonglong2* b2 = reinterpret_cast<ulonglong2*>(T.seen + base);
+  uint32_t* l32 = reinterpret_cast<uint32_t*>(T.loc + lane * 16u);
+  uint32_t run = 0;
+  for (int i = 0; i < (IT >> 1); ++i) {
+    ulonglong2 v = b2[i];
+    if (merge_from) {
+      const int w = (int)base + 2 * i;
+      v.x |= p_ld<PG>(*merge_from, w);
+      v.y |= p_ld<PG>(*merge_from, w + 1);
+      b2[i] = v;
+      p_st<PG>(*merge_from, w, 0ull);
+      p_st<PG>(*merge_from, w + 1, 0ull);
+    }
+    const uint32_t c0 = run;
+    run += (uint32_t)__popcll(v.x);
+    const uint32_t c1 = run;
+    run += (uint32_t)__popcll(v.y);
+    l32[i] = c0 | (c1 << 16);
+  }
+  T.lb[lane] = wave_incl_scan(run) - run;
 }
 
 // inclusive prefix sum inside each 32-lane half
@@ -977,15 +1050,6 @@ __device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint
   return t;
 }
 
-// prefix rebuild without a merge, out of line: keeps the general step's register footprint (and with it the
-// allocation of the hot loop around its call site) independent of this code
-template <bool PG, bool LONGR>
-__device__ __attribute__((noinline)) void rebuild_nomerge(unsigned long long* bits, uint16_t* pre, int Wp, int items,
-                                                          uint32_t lane) {
-  if (LONGR) rebuild_prefix_long(bits, pre, (items + 1) & ~1, lane);
-  else rebuild_prefix<PG>(bits, pre, nullptr, Wp, items, lane);
-}
-
 template <bool PG, bool LONGR>
 __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
                                                                const unsigned long long F,
@@ -1002,6 +1066,13 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   const bool list = ntg >= 0;
   StepAcc S;
   S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
+  // one pair per wave (LONGR): seen's counts are the two-level structure; half-wave kernels: the flat prefix
+  const int IT = tl_items(Wp);
+  const uint32_t magic = tl_magic(IT);
+  auto merge_pend_into_seen = [&]() {
+    if (LONGR) tl_rebuild<PG>(tl_view(S.L.seen, S.L.spre), &Pg, IT, lane);
+    else rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+  };
   const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
   const int last_start = (F != 0ull) ? 63 - (int)__builtin_clzll(F) : 0;
   const bool olane = valid && ((int)lane < first_start);          // rows of the group open from earlier steps
@@ -1072,7 +1143,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
       if (Fn) {
         S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
         wave_pend_fence<PG>();
-        rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+        merge_pend_into_seen();
       }
     } else {
       wave_pend_fence<PG>();
@@ -1086,19 +1157,22 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
       }
       if (Fn) {
         wave_pend_fence<PG>();
-        rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
+        merge_pend_into_seen();
       }
     }
   } else {
+    const bool ins_seen = !olane && valid && (Fn || !tlane);
     if (olane) p_or<PG>(Pg, (int)qw, bit);
-    else if (valid && (Fn || !tlane)) atomicOr(&S.L.seen[qw], bit);
+    else if (ins_seen) atomicOr(&S.L.seen[qw], bit);
     if (list && (F & 1ull) == 0ull) S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
     wave_lds_fence();
     wave_pend_fence<PG>();
     if ((F & 1ull) == 0ull) {
-      rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
-    } else {  // nothing to merge
-      rebuild_nomerge<PG, LONGR>(S.L.seen, S.L.spre, Wp, items, lane);
+      merge_pend_into_seen();
+    } else if (LONGR) {  // nothing to merge: the inserted rows update the counts
+      tl_update(tl_view(S.L.seen, S.L.spre), ins_seen, q, IT, magic, lane);
+    } else {
+      rebuild_prefix<PG>(S.L.seen, S.L.spre, nullptr, Wp, items, lane);
     }
     if (!Fn) {
       wave_pend_fence<PG>();
@@ -1146,13 +1220,20 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t lane = lane_id();
   const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
+  const int IT = tl_items(Wp);                              // one pair per wave: words of seen owned by a lane
+  const uint32_t magic = tl_magic(IT);
   static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
 
-  // persistent waves: the grid is sized to the chip and each wave walks the task list with stride nwaves;
-  // the kernel has no workgroup barrier, so the waves of a workgroup run independently
-  for (int task = gwave; task < n_tasks; task += nwaves) {
+  // PG (pend in global memory, one slot per LAUNCHED wave): persistent waves, the grid is sized to the chip and each
+  // wave walks the task list with stride nwaves.  Otherwise the grid covers the task list and a wave takes exactly
+  // one task: without a task loop the compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used
+  // to keep across the loop in scratch (5.6 KB of spill stores per wave, 1.5 GB per c4 launch) are gone.
+  // The kernel has no workgroup barrier, so the waves of a workgroup run independently.
+  int task = gwave;
+  if (task >= n_tasks) return;
+  do {
   int pidx[NP];
   pidx[0] = __builtin_amdgcn_readfirstlane(tasks[2 * task]);
   const int p_second = __builtin_amdgcn_readfirstlane(tasks[2 * task + 1]);
@@ -1193,12 +1274,24 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
     S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
-    if (PG) {
-      S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
-      for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; S[k].L.spre[w] = 0; }
-      Pg[k].bits = pend_bits + ((size_t)gwave * NP + k) * (size_t)Wp4;
-      Pg[k].pre = pend_pre + ((size_t)gwave * NP + k) * (size_t)Wp4;
-      Pg[k].pre16 = nullptr;
+    if (HI == 0) {
+      // one pair per wave: seen | [pend] | two-level counts (loc, lb, hist: TL_BYTES) | [ppre]; L.spre = the counts
+      unsigned long long* after_seen = S[k].L.seen + Wp4;
+      if (PG) {
+        S[k].L.spre = reinterpret_cast<uint16_t*>(after_seen);
+        Pg[k].bits = pend_bits + ((size_t)gwave * NP + k) * (size_t)Wp4;
+        Pg[k].pre = pend_pre + ((size_t)gwave * NP + k) * (size_t)Wp4;
+        Pg[k].pre16 = nullptr;
+        for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
+      } else {
+        Pg[k].bits = after_seen;
+        S[k].L.spre = reinterpret_cast<uint16_t*>(after_seen + Wp4);
+        Pg[k].pre16 = S[k].L.spre + TL_BYTES / 2;
+        Pg[k].pre = nullptr;
+        for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; Pg[k].pre16[w] = 0; }
+      }
+      uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
+      for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
     } else {
       Pg[k].bits = S[k].L.seen + Wp4;
       S[k].L.spre = reinterpret_cast<uint16_t*>(Pg[k].bits + Wp4);
@@ -1218,7 +1311,17 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   }
   wave_lds_fence();
 
-  uint32_t row_next = gload_u16(ord, lane);
+  // Rows of the streamed column are loaded THREE steps ahead (ring r0, r1, r2: positions pos, pos + 64, pos + 128
+  // + lane) and the rec gather of a step is issued one step ahead, while the previous step is still being
+  // counted: with the LDS state of a pair limiting long columns to 3 .. 4 waves per SIMD, a step's chain
+  // "order row -> rec gather -> LDS query" would otherwise expose two memory latencies per step (measured: 356 ns
+  // per step and SIMD at n = 50 000 against 266 ns of issue time).  The ring assumes 64-row steps; a shorter step
+  // reloads it (order[] is zero padded for the run-ahead: PrepView::n_ord).
+  uint32_t r0 = gload_u16(ord, lane), r1 = gload_u16(ord, 64u + lane), r2 = gload_u16(ord, 128u + lane);
+  uint32_t rk_pre[NP];   // the rec values of the step that starts at pos, gathered during the previous step
+  bool rk_ok = false;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) rk_pre[k] = 0u;
 
   // The LAST tie group of the streamed column (on data with missing values: the fill group) in closed form.
   // Every row outside it is above it, so for a row r of the group
@@ -1257,10 +1360,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
   while (pos < end_main) {
-    // the step's rec gather first: its latency runs behind the window logic
-    const uint32_t row = row_next;
+    const uint32_t row = r0;
     uint32_t rk[NP];
-    if (NP == 2) {
+    if (rk_ok) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk[k] = rk_pre[k];
+    } else if (NP == 2) {  // after a short step: gather now, its latency runs behind the window logic
       const uint2 rv = gload_rec2(rec_blk, row);
 #pragma unroll
       for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
@@ -1307,7 +1412,25 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
     pos = pos_next;
-    row_next = gload_u16(ord, (uint32_t)pos + lane);  // the next step's rows (order[] is zero-padded by one step)
+    if (nact == 64) {  // the ring stays aligned: next step's rows are in r1 already -> gather its rec values now
+      // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at
+      //  the top of the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
+      r0 = r1; r1 = r2;
+      if (NP == 2) {
+        const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
+      } else {
+        rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
+      }
+      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+      rk_ok = true;
+    } else {
+      r0 = gload_u16(ord, (uint32_t)pos + lane);
+      r1 = gload_u16(ord, (uint32_t)pos + 64u + lane);
+      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+      rk_ok = false;
+    }
     uint32_t q[NP], lo[NP];
 
     if (half_mode && all_fast) {
@@ -1338,11 +1461,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // ---- hot step, one pair on the whole wave: all 64 rows are valid, each row is its own tie group of
       //      the streamed column, and no group stays open: gather, count, insert into `seen`. -----------
       const uint32_t q0 = rk[0] & 0xFFFFu, lo0 = rk[0] >> 16;
-      S[0].dis += prefix_query(S[0].L.seen, S[0].L.spre, lo0) + wave_allpairs(q0, lo0, lane);
+      const TwoLevel T = tl_view(S[0].L.seen, S[0].L.spre);
+      S[0].dis += tl_query(T, lo0, IT, magic) + wave_allpairs(q0, lo0, lane);
       wave_lds_fence();
       seen_insert(S[0].L.seen, q0);
-      wave_lds_fence();
-      rebuild_prefix_long(S[0].L.seen, S[0].L.spre, (items + 1) & ~1, lane);
+      tl_update(T, true, q0, IT, magic, lane);
       wave_lds_fence();
       continue;
     }
@@ -1354,7 +1477,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         q[k] = valid ? (rk[k] & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
         lo[k] = valid ? (rk[k] >> 16) : 0u;              // nothing is below 0
         // (1) rows of strictly higher groups of the streamed column that are already in `seen`
-        const uint32_t cnt = prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
+        const uint32_t cnt = (HI == 0) ? tl_query(tl_view(S[k].L.seen, S[k].L.spre), lo[k], IT, magic)
+                                       : prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
         S[k].dis += valid ? cnt : 0u;
       }
     }
@@ -1372,6 +1496,25 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
   for (int k = 0; k < NP; ++k) corr[k] = 0ull;
   if (closed_form) {
+    // The group's bitset: pend in LDS where the kernel has one.  With pend in global memory (long columns) the
+    // tail uses `seen` instead -- nothing queries it any more -- so that the rows missing in the streamed column
+    // cost LDS atomics, not one global atomic each (measured on the full c5 matrix, whose 1 GB of prepared state
+    // pushes the per-wave pend slots out of the Infinity Cache: 1.8e6 -> see DESIGN.md pairs/s).
+    PendG Pt[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (PG) {
+        Pt[k].bits = S[k].L.seen;
+        Pt[k].pre16 = S[k].L.spre;
+        Pt[k].pre = nullptr;
+        if (ntgB[k] > 0)
+          for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
+      } else {
+        Pt[k] = Pg[k];
+      }
+    }
+    wave_lds_fence();
+    uint32_t row_next = r0;
     for (int p = last_start; p < n; p += 64) {
       const int kpos = p + (int)lane;
       uint32_t rk[NP];
@@ -1387,21 +1530,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
           S[k].dis += rk[k] >> 16;
-          if (ntgB[k] > 0) p_or<PG>(Pg[k], (int)((rk[k] & 0xFFFFu) >> 6), 1ull << (rk[k] & 63u));
+          if (ntgB[k] > 0) p_or<false>(Pt[k], (int)((rk[k] & 0xFFFFu) >> 6), 1ull << (rk[k] & 63u));
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t tl = (ntgB[k] > 0) ? close_group_ties<PG>(Pg[k], tgB[k], ntgB[k], Wp, items, lane) : 0u;
+      const uint32_t tl = (ntgB[k] > 0) ? close_group_ties<false>(Pt[k], tgB[k], ntgB[k], Wp, items, lane) : 0u;
       S[k].tie += tl;
       const unsigned long long m = (unsigned long long)(n - last_start);
       corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
-      if (PG) {  // a global pend slot is left all zero for the next task
-        wave_pend_fence<PG>();
-        for (int w = lane; w < Wp; w += 64) p_st<PG>(Pg[k], w, 0ull);
-        wave_pend_fence<PG>();
-      }
     }
   }
 
@@ -1421,7 +1559,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
   }
   wave_lds_fence();
-  }  // task loop
+  } while (PG && (task += nwaves) < n_tasks);  // task loop
 }
 
 

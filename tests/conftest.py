@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The HIP runtime reports a queue error (a faulting kernel) only through its log; at the default level the process
+# just aborts.  Level 1 = errors only.  Must be set before the runtime is loaded (torch / the library import).
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

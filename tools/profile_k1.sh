@@ -7,8 +7,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 STEPS=${STEPS:-5}
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps $STEPS --warmup 2 --cpu-sample 0 > gpurun_out/prof_stats.log 2>&1 || exit 1
-pass() { name=$1; shift; timeout -k 5 150 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$name -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/$name.log 2>&1 || { echo "pass $name failed"; tail -3 gpurun_out/$name.log; exit 1; }; }
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps $STEPS --warmup 2 --cpu-sample 0 --no-extras > gpurun_out/prof_stats.log 2>&1 || exit 1
+pass() { name=$1; shift; timeout -k 5 150 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$name -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-extras > gpurun_out/$name.log 2>&1 || { echo "pass $name failed"; tail -3 gpurun_out/$name.log; exit 1; }; }
 pass prof_fetch FETCH_SIZE
 pass prof_write WRITE_SIZE
 pass prof_sq SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS

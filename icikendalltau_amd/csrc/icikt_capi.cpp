@@ -284,7 +284,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
   c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
-  c->d_pend_bits.release(); c->d_pend_pre.release();
+  c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
   c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (auto& p : c->ev_pool[k]) {
@@ -582,13 +582,8 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     if (rc) return rc;
     // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
     // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
-    // wave owns a slot of it.  Up to 8x what the chip holds at once the grid still covers the task list (one task
-    // per wave; slots: a few hundred MB at n = 50 000).  Beyond that the grid is exactly what the chip holds and
-    // the waves stride over the task list: in round k ALL resident waves work on the window [k * waves, (k + 1) *
-    // waves) of consecutive tasks, i.e. each XCD on one gathered block at a time, which stays in its 4 MB L2.
-    // (A grid of 8x the resident waves with 64 tasks per wave was measured at 1.9e6 pairs/s on the full c5 matrix
-    // against 3.5e6 on a 512-column one: blocks that start late begin at round 0 beside blocks in round 40, every
-    // XCD gathers from dozens of 400 KB blocks at once and the gathers fall out of L2.)
+    // wave owns a slot of it: the grid is what the chip holds at once and the waves fetch tasks, in order, from
+    // one counter per XCD group (k1_pairs: why the order matters for the L2).
     int per_cu = 0;
     HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
@@ -596,13 +591,8 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
     int blocks = want;
     if (pl.pend_global) {
       const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
-      const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 8;
-      if (c->plan_ov.grid_mult > 0) blocks = (int)std::min<int64_t>(want, mult * resident);
-      else if (want > mult * resident) blocks = (int)resident;
-      // even rounds: shrink the grid so that every wave walks the same number of tasks
-      const int64_t waves = (int64_t)blocks * pl.wpb;
-      const int64_t rounds = (c->n_units + waves - 1) / waves;
-      blocks = (int)std::max<int64_t>(1, (c->n_units + rounds * pl.wpb - 1) / (rounds * pl.wpb));
+      const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
+      blocks = (int)std::min<int64_t>(want, mult * resident);
     }
     blocks = std::max(blocks, 1);
     if (c->plan_ov.verbose)
@@ -619,9 +609,13 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
         HIPCHK(c, hipMemsetAsync(c->d_pend_pre.p, 0, c->d_pend_pre.cap * sizeof(uint32_t), c->stream));
       }
     }
+    if (pl.pend_global) {
+      HIPCHK(c, c->d_task_ctr.reserve(8));
+      HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
+    }
     HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                                pl.pend_global, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
-                               c->d_pend_pre.p, pl.opts, c->stream));
+                               c->d_pend_pre.p, c->d_task_ctr.p, pl.opts, c->stream));
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
     c->raw_valid = true;

@@ -89,7 +89,7 @@ hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStr
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
-                     int opts, hipStream_t s);
+                     int* task_ctr, int opts, hipStream_t s);
 hipError_t k1_blocks_per_cu(int np, bool pend_global, int half_items, int wpb, size_t lds_bytes, int* out);
 hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, const PairRaw* raw,
                      int64_t n_pairs, int perspective, int alternative, int continuity, int exact64,

@@ -60,6 +60,7 @@ struct icikt_ctx {
   DevBuf<icikt::PairRaw> d_raw;
   DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
   DevBuf<uint32_t> d_pend_pre;
+  DevBuf<int> d_task_ctr;  // persistent pair kernel: one task counter per XCD group, zeroed before every launch
   std::vector<int32_t> h_pi, h_pj, h_units;
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks

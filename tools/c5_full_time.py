@@ -14,7 +14,7 @@ for P in (20000, 200000, Pfull):
     P = min(P, Pfull)
     ctx.set_pairs_combn(S, 0, P)
     out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
-    for plan in ({}, {"gridmult": 8}, {"gridmult": 2}, {"gridmult": 1}, {"pend": "l"}):
+    for plan in ({}, {"gridmult": 2}, {"pend": "l"}):
         ctx.debug_set_plan(dict(plan, verbose=1 if P == Pfull else 0))
         ts = []
         for _ in range(2):

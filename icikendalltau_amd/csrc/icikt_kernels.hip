@@ -1190,6 +1190,188 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   return out;
 }
 
+// out-of-line form for the fast tie steps (keeps the hot loop's register allocation independent of it)
+__device__ __attribute__((noinline)) uint32_t close_group_ties_lds(const PendG Pg, const uint32_t* tg, const int ntg,
+                                                                   const int Wp, const int items, const uint32_t lane) {
+  return close_group_ties<false>(Pg, tg, ntg, Wp, items, lane);
+}
+
+// ---- fast tie steps (pend in LDS: half-wave kernels and one pair per wave up to n ~ 25 000) ---------------------
+// The general step above runs ONE pair on 64 lanes and re-sorts the lanes of a step that holds several tie groups
+// (21 exchange stages), which made tied data 3 .. 4 times slower than continuous data.  Two cheaper step kinds
+// cover every flag pattern; a "segment" is the lanes of one pair: a 32-lane half (two pairs per wave advance
+// together, as in the hot step) or the whole wave.
+//   MIXED  up to SEG rows of COMPLETE groups of at most k1_ks() rows each.  The plain all-pairs count of the step
+//          also counts pairs inside a group; those are the pairs (lane - d, lane), d = 1 .. group size - 1, so d
+//          whole-wave shifts of q and lo give, per lane, the spurious count (q_prev < lo_me) and the joint ties
+//          (lo_prev == lo_me).  The loop ends with the largest group of the step: no sort.
+//   GROUP  up to SEG rows of ONE group (a piece of it, or all of it).  Rows of one group are never discordant with
+//          each other: no all-pairs at all.  They collect in `pend` and are merged into `seen` when the group
+//          closes.  Joint ties = for every row the rows of the group in its tie group [lo, hi] of the gathered
+//          column: popcounts of the one .. few words of pend that the range covers, before the step's rows are
+//          inserted (earlier pieces) and after (this piece: each pair seen from both sides, hence tie2); the cell
+//          lo == 0 (the gathered column's fill group, the one range that is routinely hundreds of words long) is a
+//          running count per group instead.  No prefix over pend is ever built.
+typedef __attribute__((address_space(3))) unsigned long long* lds_u64p;
+typedef __attribute__((address_space(3))) uint16_t* lds_u16p;
+// MIXED steps take groups of up to this many rows (the correction loop costs ~10 instructions per row of the
+// step's largest group); longer groups get GROUP steps of their own.  A whole wave amortises a longer loop.
+__host__ __device__ constexpr int k1_ks(bool half) { return half ? 12 : 20; }
+
+struct SegState {   // per-lane LDS views of the lane's pair
+  lds_u64p seen, pend;
+  lds_u16p spre;
+};
+struct SegCounts { uint32_t dis, neg, tie, tie2, cfill; };
+
+template <int SEG, int HI>
+__device__ __forceinline__ uint32_t seg_query(unsigned long long* seen, uint16_t* spre, uint32_t lo, int IT, uint32_t magic) {
+  return (SEG == 64) ? tl_query(tl_view(seen, spre), lo, IT, magic) : prefix_query(seen, spre, lo);
+}
+
+template <int SEG, int HI>
+__device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st, const unsigned long long F, const int nact,
+                                                              const uint32_t rk, const int IT, const uint32_t magic,
+                                                              const uint32_t lane) {
+  unsigned long long* seen = (unsigned long long*)st.seen;
+  uint16_t* spre = (uint16_t*)st.spre;
+  const uint32_t sl = (SEG == 32) ? (lane & 31u) : lane;
+  const bool valid = (int)sl < nact;
+  const uint32_t q = valid ? (rk & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
+  const uint32_t lo = valid ? (rk >> 16) : 0u;              // nothing is below 0
+  SegCounts c;
+  c.tie2 = 0; c.cfill = 0;
+  const uint32_t cnt = seg_query<SEG, HI>(seen, spre, lo, IT, magic);
+  c.dis = (valid ? cnt : 0u) + ((SEG == 64) ? wave_allpairs(q, lo, lane) : half_count(q, lo, lane));
+  // Pairs inside a group: lane l against lanes l - 1 .. l - (its group's rows before it).  Both operands carry the
+  // group in their upper half, counted DOWN (63 - number of the group), so that a lane of an earlier group that is
+  // shifted in compares as greater and never counts: no mask per shift.  The loop runs to the step's largest group.
+  const unsigned long long Fs = (SEG == 32) ? (F & 0xFFFFFFFFull) : F;
+  const unsigned long long upto = Fs & ((2ull << sl) - 1ull);                   // group starts at or before me
+  // 64 - (group number 1 .. 64); the first half of a half-wave kernel is tagged above it, so that what the shifts
+  // carry from pair 0's lanes into pair 1's compares as greater too
+  const uint32_t gdown = ((64u - (uint32_t)__popcll(upto)) << 16) | ((SEG == 32 && lane < 32u) ? 0x00800000u : 0u);
+  const uint32_t kq = valid ? (gdown | q) : 0xFFFFFFFFu, klo = valid ? (gdown | lo) : 0u;
+  // longest run of rows that continue a group = largest group - 1 (wave-uniform, from the flags)
+  int dmax = 0;
+  {
+    unsigned long long z = ~Fs & ((nact >= 64) ? ~0ull : ((1ull << nact) - 1ull));
+    while (z != 0ull) { z &= z >> 1; ++dmax; }
+  }
+  uint32_t sq = kq, slo = valid ? klo : 0xFFFFFFFFu, spur = 0, tie = 0;
+  for (int d = 0; d < dmax; ++d) {
+    sq = dpp_wave_shr1(0xFFFFFFFFu, sq);    // lane l now holds lane l - (d + 1)
+    slo = dpp_wave_shr1(0xFFFFFFFFu, slo);
+    spur += (sq < klo) ? 1u : 0u;           // same group (equal upper halves) and q_prev < lo_me
+    tie += (slo == klo) ? 1u : 0u;          // same group and same tie group of the gathered column
+  }
+  if (!valid) { spur = 0; tie = 0; }
+  c.neg = spur;
+  c.tie = tie;
+  wave_lds_fence();
+  if (valid) seen_insert(seen, q);
+  if (SEG == 64) {
+    tl_update(tl_view(seen, spre), valid, q, IT, magic, lane);
+  } else {
+    wave_lds_fence();
+    rebuild_prefix_half<(HI > 0 ? HI : 1)>(seen, spre, sl);
+  }
+  wave_lds_fence();
+  return c;
+}
+
+// GROUP step.  `single`: the group starts and ends in this step (wave-uniform).  `rowmode` (per lane = per pair):
+// joint ties are counted row by row from cell popcounts; otherwise (the gathered column has few tie groups, which
+// may be thousands of rows long) the rows only collect in pend and the caller counts them from the column's tie
+// group list when the group closes (close_group_ties).  A single-step group of a row-mode pair needs no pend at
+// all: its rows are inserted into `seen` directly and "after - before" cancels the rows of earlier groups.
+template <int SEG, int HI>
+__device__ __attribute__((noinline)) SegCounts seg_group_step(const SegState st, const int nact, const bool single,
+                                                              const bool closes, const bool rowmode, const uint32_t rk,
+                                                              const uint32_t hi_in, const uint32_t cfill, const int IT,
+                                                              const uint32_t magic, const uint32_t lane) {
+  unsigned long long* seen = (unsigned long long*)st.seen;
+  uint16_t* spre = (uint16_t*)st.spre;
+  const uint32_t sl = (SEG == 32) ? (lane & 31u) : lane;
+  const bool valid = (int)sl < nact;
+  const uint32_t q = valid ? (rk & 0xFFFFu) : 0xFFFFFFFFu;
+  const uint32_t lo = valid ? (rk >> 16) : 0u;
+  const uint32_t hi = valid ? hi_in : 0u;
+  const bool direct = single && rowmode;                       // per lane
+  unsigned long long* tgt = (unsigned long long*)(direct ? st.seen : st.pend);   // receives the rows; cells are counted in it
+  SegCounts c;
+  c.neg = 0;
+  const uint32_t cnt = seg_query<SEG, HI>(seen, spre, lo, IT, magic);
+  c.dis = valid ? cnt : 0u;
+  // the cell lo == 0 of a row-mode pair: a running count per group
+  const bool infill = valid && rowmode && lo == 0u;
+  const unsigned long long mf = __ballot(infill);
+  const uint32_t kin = (SEG == 32) ? (uint32_t)__builtin_popcount((lane >= 32u) ? (uint32_t)(mf >> 32) : (uint32_t)mf)
+                                   : (uint32_t)__popcll(mf);
+  c.tie = (sl == 0u) ? (kin * (kin - 1u) / 2u + kin * cfill) : 0u;   // once per pair (kin == 0 without row mode)
+  c.cfill = closes ? 0u : (cfill + kin);
+  // every other cell of a row-mode pair: rows of the group in [lo, hi], read from the words the range covers
+  const bool cellv = valid && rowmode && !infill;
+  const uint32_t w0 = lo >> 6, w1 = hi >> 6;
+  const unsigned long long m0 = ~0ull << (lo & 63u), m1 = (2ull << (hi & 63u)) - 1ull;
+  const bool any_wide = __ballot(cellv && (w1 > w0 + 1u)) != 0ull;   // a cell of more than two words (rare)
+  auto cell_count = [&]() -> uint32_t {
+    if (!any_wide) {  // both words of every cell in one round trip
+      const unsigned long long a = cellv ? tgt[w0] : 0ull, b = (cellv && w1 > w0) ? tgt[w0 + 1u] : 0ull;
+      return (uint32_t)__popcll(a & m0 & ((w1 == w0) ? m1 : ~0ull)) + (uint32_t)__popcll(b & m1);
+    }
+    uint32_t n = 0;
+    for (uint32_t i = 0; __ballot(cellv && (w0 + i <= w1)) != 0ull; ++i) {
+      const uint32_t w = w0 + i;
+      const bool act = cellv && w <= w1;
+      const unsigned long long v = act ? tgt[w] : 0ull;
+      const unsigned long long m = ((w == w0) ? m0 : ~0ull) & ((w == w1) ? m1 : ~0ull);
+      n += (uint32_t)__popcll(v & m);
+    }
+    return n;
+  };
+  const uint32_t before = cell_count();
+  wave_lds_fence();
+  if (valid) seen_insert(tgt, q);
+  wave_lds_fence();
+  const uint32_t after = cell_count();
+  c.tie += (cellv && !single) ? before : 0u;        // rows of earlier pieces in my cell (pend holds this group only)
+  c.tie2 = cellv ? (after - before - 1u) : 0u;      // rows of this piece in my cell, me excluded: every pair twice
+  // rows that went into seen directly: its counts follow
+  if (SEG == 64) {
+    if (direct) tl_update(tl_view(seen, spre), valid, q, IT, magic, lane);   // wave-uniform (one pair)
+  } else if (single && __ballot(rowmode) != 0ull) {
+    rebuild_prefix_half<(HI > 0 ? HI : 1)>(seen, spre, sl);   // a list-mode half rebuilds the same values
+  }
+  wave_lds_fence();
+  return c;
+}
+
+// a group closes: its rows, collected in pend, become visible in seen
+template <int SEG, int HI>
+__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int IT, const uint32_t lane) {
+  unsigned long long* seen = (unsigned long long*)st.seen;
+  unsigned long long* pend = (unsigned long long*)st.pend;
+  uint16_t* spre = (uint16_t*)st.spre;
+  if (SEG == 64) {
+    PendG P;
+    P.bits = pend; P.pre = nullptr; P.pre16 = nullptr;
+    tl_rebuild<false>(tl_view(seen, spre), &P, IT, lane);
+  } else {
+    const uint32_t sl = lane & 31u;
+    constexpr int H = (HI > 0 ? HI : 1);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const uint32_t w = sl * (uint32_t)H + (uint32_t)i;
+      seen[w] |= pend[w];
+      pend[w] = 0ull;
+    }
+    wave_lds_fence();
+    rebuild_prefix_half<H>(seen, spre, sl);
+  }
+  wave_lds_fence();
+}
+
 // Variants: <1, PG, 0> one pair per wave (any n; PG = pend in global memory) and <2, false, HI> two pairs per
 // wave, one per half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild.
 // A task is (pair, pair or -1).  The two pairs of a task share their STREAMED column (pj) and their gathered
@@ -1225,6 +1407,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
+  constexpr bool fast_ties = !PG;                           // MIXED / GROUP steps instead of the general step
 
   // PG (pend in global memory, one slot per LAUNCHED wave): persistent waves, the grid is what the chip holds, and
   // a wave FETCHES its next task from a counter.  Workgroups are dealt round-robin over the 8 XCDs, so the
@@ -1341,6 +1524,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool rk_ok = false;
 #pragma unroll
   for (int k = 0; k < NP; ++k) rk_pre[k] = 0u;
+  uint32_t hi_pre = 0;   // fast tie steps: hirow of the next step's rows, gathered one step ahead in tie regions
+  bool hi_ok = false;
 
   // The LAST tie group of the streamed column (on data with missing values: the fill group) in closed form.
   // Every row outside it is above it, so for a row r of the group
@@ -1375,11 +1560,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // step (the open-group path of pair_step_rest).  pos = first position of the step, nact = its rows, F =
   // group-start flags of its rows, Fn = "the row after the step starts a group".
   uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
+  // fast tie steps: per lane, for the lane's pair (half-wave kernels: lanes >= 32 belong to the second pair)
+  uint32_t seg_dis = 0, seg_neg = 0, seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
+  bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
   int pos = 0;
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
   while (pos < end_main) {
     const uint32_t row = r0;
+    const uint32_t hi_now = hi_pre;
+    const bool hi_now_ok = hi_ok;
     uint32_t rk[NP];
     if (rk_ok) {
 #pragma unroll
@@ -1394,6 +1584,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     int nact;
     bool Fn;
     unsigned long long F;
+    int kind = 0;          // 0: hot step or the general step (decided below), 1: MIXED, 2: GROUP (fast tie steps)
+    bool closes = true;    // GROUP: the step holds the group's last row
     if (pos + 64 <= hot_until) {
       nact = 64; Fn = true; F = ~0ull;
     } else {
@@ -1409,7 +1601,40 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const int remaining = end_main - pos;
       const bool reach_end = remaining <= 64;
       if (remaining < 64) F &= (1ull << remaining) - 1ull;
-      if ((F & 1ull) == 0ull) {                  // inside a group that is longer than a step
+      if constexpr (fast_ties) {
+        // ---- fast tie steps: HOT (64 singleton rows), MIXED (complete groups of <= KS rows) or GROUP -----------
+        constexpr int SW = half_mode ? 32 : 64;                  // rows a segment takes per step
+        const int avail = reach_end ? remaining : 64;            // rows the window shows
+        const int lim = min(remaining, SW);
+        const bool endbit = fnbit || remaining == 64;            // row 64 of the window starts a group / is the end
+        if (avail == 64 && F == ~0ull && endbit) {
+          nact = 64; Fn = true;                                  // a hot step
+        } else {
+          // starts, with every position from the end of the data on marked as a start (it ends the last group)
+          const unsigned long long Fz = (avail < 64) ? (F | (~0ull << avail)) : F;
+          const unsigned long long Fr = Fz & ~1ull;
+          const int next = (Fr != 0ull) ? (int)__builtin_ctzll(Fr) : (endbit ? 64 : 65);  // end of the group at pos
+          constexpr int KS = k1_ks(half_mode);
+          if ((F & 1ull) == 0ull || next > KS) {
+            kind = 2;
+            nact = min(next, lim);
+            closes = next <= lim;
+          } else {
+            kind = 1;
+            const unsigned long long z = ~Fz;                    // rows that continue a group
+            unsigned long long r = z;
+#pragma unroll
+            for (int i = 1; i < KS; ++i) r &= z >> i;            // bit i: rows i .. i + KS - 1 continue a group: > KS rows
+            int s0 = 64;                                         // start of the first group the step must not take
+            if (r != 0ull) s0 = 63 - (int)__builtin_clzll(Fz & ((1ull << __builtin_ctzll(r)) - 1ull));
+            if (!half_mode && avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));  // cut by the window
+            const int upper = min(lim, s0);
+            nact = (upper >= 64) ? 64 : (63 - (int)__builtin_clzll(Fz & ((2ull << upper) - 1ull) & ~1ull));
+            if (nact < 64) F &= (1ull << nact) - 1ull;
+          }
+          Fn = closes;
+        }
+      } else if ((F & 1ull) == 0ull) {           // inside a group that is longer than a step
         if (F == 0ull) { nact = reach_end ? remaining : 64; Fn = reach_end || fnbit; }
         else { nact = (int)__builtin_ctzll(F); F = 0ull; Fn = true; }   // its last piece
       } else if (reach_end || fnbit) {           // the window ends where a group ends
@@ -1445,10 +1670,35 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
       rk_ok = true;
     } else {
-      r0 = gload_u16(ord, (uint32_t)pos + lane);
-      r1 = gload_u16(ord, (uint32_t)pos + 64u + lane);
+      // a shorter step: the next step's rows are in the ring already, nact lanes further on -> rotate the ring
+      // (three cross-lane moves) instead of reloading it, and gather the rec values of the next step right away:
+      // tie steps then hide their memory latencies like the hot steps do
+      const int idx = (int)(((lane + (uint32_t)nact) & 63u) << 2);
+      const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)r0);
+      const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)r1);
+      const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)r2);
+      const bool wrap = lane + (uint32_t)nact >= 64u;
+      r0 = wrap ? a1 : a0;
+      r1 = wrap ? a2 : a1;
+      if (NP == 2) {
+        const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
+      } else {
+        rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
+      }
       r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
-      rk_ok = false;
+      rk_ok = true;
+    }
+    if (fast_ties) {
+      // a tie region: the next step may be a GROUP step, which needs the last position of every row's tie group in
+      // the gathered column -> gathered now, beside the rec values (half-wave kernels: rows 0..31 for both halves)
+      hi_ok = kind != 0;
+      if (hi_ok) {
+        const uint32_t rowN = half_mode ? (uint32_t)__builtin_amdgcn_permlane32_swap(r0, r0, false, false)[0] : r0;
+        const uint16_t* hb = (half_mode && lane >= 32u) ? hiG[NP - 1] : hiG[0];
+        hi_pre = gload_u16(hb, rowN);
+      }
     }
     uint32_t q[NP], lo[NP];
 
@@ -1489,6 +1739,50 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       continue;
     }
 
+    if constexpr (fast_ties) {
+      // ---- fast tie step: both pairs of a half-wave kernel advance together, each on its 32 lanes -------------
+      constexpr int SW = half_mode ? 32 : 64;
+      uint32_t rkS = rk[0], rowS = row;
+      SegState st;
+      const uint16_t* hbase = hiG[0];
+      if (half_mode) {
+        rkS = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[0];  // [pair 0 | pair 1] of rows 0..31
+        rowS = __builtin_amdgcn_permlane32_swap(row, row, false, false)[0];           // rows 0..31 in both halves
+        const bool hi = lane >= 32u;
+        st.seen = (lds_u64p)(hi ? S[NP - 1].L.seen : S[0].L.seen);
+        st.spre = (lds_u16p)(hi ? S[NP - 1].L.spre : S[0].L.spre);
+        st.pend = (lds_u64p)(hi ? Pg[NP - 1].bits : Pg[0].bits);
+        hbase = hi ? hiG[NP - 1] : hiG[0];
+      } else {
+        st.seen = (lds_u64p)S[0].L.seen;
+        st.spre = (lds_u16p)S[0].L.spre;
+        st.pend = (lds_u64p)Pg[0].bits;
+      }
+      SegCounts c;
+      if (kind == 1) {
+        c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
+      } else {
+        // last position of the row's tie group in the gathered column
+        const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hbase, rowS);
+        const bool rowmode = ((half_mode && lane >= 32u) ? ntgB[NP - 1] : ntgB[0]) < 0;
+        const bool single = closes && !seg_open;        // the group starts and ends in this step
+        c = seg_group_step<SW, HI>(st, nact, single, closes, rowmode, rkS, hiA, seg_cfill, IT, magic, lane);
+        seg_cfill = c.cfill;
+        seg_open = !closes;
+        if (closes) {
+          bool any_list = false;
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {   // list mode: joint ties of the closed group from the column's tie-group list
+            if (ntgB[k] >= 0) {
+              any_list = true;
+              if (ntgB[k] > 0) S[k].tie += close_group_ties_lds(Pg[k], tgB[k], ntgB[k], Wp, items, lane);
+            }
+          }
+          if (!single || any_list) seg_group_close<SW, HI>(st, IT, lane);
+        }
+      }
+      seg_dis += c.dis; seg_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
+    } else {
     // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
     {
 #pragma unroll
@@ -1507,6 +1801,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
                                               hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
+    }  // general step
   }
 
   // the rows of the last tie group of the streamed column: gather, add lo, collect in pend; then the group's
@@ -1564,8 +1859,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const unsigned long long dis = wave_sum_u64(S[k].dis + (((lane >= 32u) == (k == NP - 1 && NP == 2)) ? dis_half : 0u)) - corr[k];
-    const unsigned long long ntie = wave_sum_u64(S[k].tie) + (wave_sum_u64(S[k].tie2) >> 1);
+    const bool mine = (NP == 1) || ((lane >= 32u) == (k == NP - 1));   // per-lane accumulators of this pair
+    const unsigned long long dis = wave_sum_u64(S[k].dis) + wave_sum_u64(mine ? dis_half : 0u) +
+                                   wave_sum_u64(mine ? seg_dis : 0u) - wave_sum_u64(mine ? seg_neg : 0u) - corr[k];
+    const unsigned long long ntie = wave_sum_u64(S[k].tie) + wave_sum_u64(mine ? seg_tie : 0u) +
+                                    ((wave_sum_u64(S[k].tie2) + wave_sum_u64(mine ? seg_tie2 : 0u)) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);
     const unsigned long long ggs = wave_sum_u64(gg[k]);
     if (lane == 0 && k < np) {

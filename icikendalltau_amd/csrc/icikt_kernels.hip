@@ -1566,7 +1566,107 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   int pos = 0;
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
+  // the ring moves on by a 64-row step: next step's rows are in r1 already -> gather its rec values now
+  // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at the top of
+  //  the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
+  auto advance64 = [&]() {
+    r0 = r1; r1 = r2;
+    if (NP == 2) {
+      const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
+    } else {
+      rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
+    }
+    r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+    rk_ok = true;
+  };
+  // ---- hot step: 64 rows, each its own tie group of the streamed column, nothing open ---------------------------
+  auto hot_step = [&](const uint32_t (&rk)[NP]) {
+    if constexpr (half_mode) {
+      // lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One 8-byte gather per row;
+      // permlane32_swap turns the two 64-row registers (pair 0, pair 1) into the two sub-steps' operands
+      // [pair 0 rows 0..31 | pair 1 rows 0..31], [.. rows 32..63].
+      const auto sw = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false);
+      const bool hi = lane >= 32u;
+      unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
+      uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
+      const uint32_t l32 = lane & 31u;
+      constexpr int H = (HI > 0 ? HI : 1);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const uint32_t r = sub ? sw[1] : sw[0];
+        const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
+        // All LDS traffic of the sub-step is ISSUED first, in the order in which it must take effect -- the query's
+        // two reads, the rows' OR into seen, the reads of the prefix rebuild (one wave's DS operations execute in
+        // order, so the query sees the bitset before, the rebuild after the insertion) -- and the all-pairs count,
+        // which needs registers only, runs while they are in flight.
+        const uint32_t pre_lo = (uint32_t)spreH[loh >> 6];
+        const unsigned long long word_lo = seenH[loh >> 6];
+        wave_lds_fence();
+        seen_insert(seenH, qh);
+        wave_lds_fence();
+        unsigned long long wv[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
+        const uint32_t inpairs = half_count(qh, loh, lane);
+        // (the loaded words are consumed only behind the all-pairs block: an empty asm pins that order, or the
+        //  scheduler hoists the popcounts -- and the wait for the loads -- in front of it)
+        uint32_t pre_lo_k = pre_lo;
+        unsigned long long word_lo_k = word_lo;
+        asm volatile("" : "+v"(pre_lo_k), "+v"(word_lo_k));
+#pragma unroll
+        for (int i = 0; i < H; ++i) asm volatile("" : "+v"(wv[i]));
+        dis_half += pre_lo_k + (uint32_t)__popcll(word_lo_k & low_mask64(loh & 63u)) + inpairs;
+        // prefix of the half's bitset: lane l owns words [l*H, (l+1)*H)
+        uint32_t cw[H], run = 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          run = (uint32_t)__builtin_popcount((uint32_t)wv[i]) + run;
+          run = (uint32_t)__builtin_popcount((uint32_t)(wv[i] >> 32)) + run;
+          cw[i] = run;
+        }
+        const uint32_t excl = half_incl_scan(run) - run;
+        uint16_t* pre = spreH + l32 * (uint32_t)H;
+        pre[0] = (uint16_t)excl;
+#pragma unroll
+        for (int i = 1; i < H; ++i) pre[i] = (uint16_t)(excl + cw[i - 1]);
+        wave_lds_fence();
+      }
+    } else {
+      // one pair on the whole wave: gather, count, insert into `seen`, update its counts
+      const uint32_t q0 = rk[0] & 0xFFFFu, lo0 = rk[0] >> 16;
+      const TwoLevel T = tl_view(S[0].L.seen, S[0].L.spre);
+      S[0].dis += tl_query(T, lo0, IT, magic) + wave_allpairs(q0, lo0, lane);
+      wave_lds_fence();
+      seen_insert(S[0].L.seen, q0);
+      tl_update(T, true, q0, IT, magic, lane);
+      wave_lds_fence();
+    }
+  };
   while (pos < end_main) {
+    if (pos + 64 <= hot_until) {
+      // The singleton region (on continuous data: everything but the rows missing in the streamed column): a loop
+      // of its own, so that the tie steps' state does not live in (or get merged into) the hot loop's registers.
+      do {
+        uint32_t rk[NP];
+        if (rk_ok) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) rk[k] = rk_pre[k];
+        } else if (NP == 2) {
+          const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+        } else {
+          rk[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
+        }
+        pos += 64;
+        advance64();
+        hot_step(rk);
+      } while (pos + 64 <= hot_until);
+      hi_ok = false;
+      continue;
+    }
     const uint32_t row = r0;
     const uint32_t hi_now = hi_pre;
     const bool hi_now_ok = hi_ok;
@@ -1656,19 +1756,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
     pos = pos_next;
-    if (nact == 64) {  // the ring stays aligned: next step's rows are in r1 already -> gather its rec values now
-      // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at
-      //  the top of the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
-      r0 = r1; r1 = r2;
-      if (NP == 2) {
-        const uint2 rv = gload_rec2(rec_blk, r0);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
-      } else {
-        rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
-      }
-      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
-      rk_ok = true;
+    if (nact == 64) {  // the ring stays aligned
+      advance64();
     } else {
       // a shorter step: the next step's rows are in the ring already, nact lanes further on -> rotate the ring
       // (three cross-lane moves) instead of reloading it, and gather the rec values of the next step right away:
@@ -1702,40 +1791,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
     uint32_t q[NP], lo[NP];
 
-    if (half_mode && all_fast) {
-      // ---- half-wave hot step: lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One
-      //      8-byte gather per row; permlane32_swap turns the two 64-row registers (pair 0, pair 1) into
-      //      the two sub-steps' operands [pair 0 rows 0..31 | pair 1 rows 0..31], [.. rows 32..63]. ------
-      const auto sw = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false);
-      const bool hi = lane >= 32u;
-      unsigned long long* seenH = hi ? S[NP - 1].L.seen : S[0].L.seen;
-      uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
-      const uint32_t l32 = lane & 31u;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const uint32_t r = sub ? sw[1] : sw[0];
-        const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
-        const uint32_t cnt = (uint32_t)spreH[loh >> 6] + (uint32_t)__popcll(seenH[loh >> 6] & low_mask64(loh & 63u));
-        dis_half += cnt + half_count(qh, loh, lane);
-        wave_lds_fence();
-        seen_insert(seenH, qh);
-        wave_lds_fence();
-        rebuild_prefix_half<(HI > 0 ? HI : 1)>(seenH, spreH, l32);
-        wave_lds_fence();
-      }
-      continue;
-    }
-
-    if (!half_mode && all_fast) {
-      // ---- hot step, one pair on the whole wave: all 64 rows are valid, each row is its own tie group of
-      //      the streamed column, and no group stays open: gather, count, insert into `seen`. -----------
-      const uint32_t q0 = rk[0] & 0xFFFFu, lo0 = rk[0] >> 16;
-      const TwoLevel T = tl_view(S[0].L.seen, S[0].L.spre);
-      S[0].dis += tl_query(T, lo0, IT, magic) + wave_allpairs(q0, lo0, lane);
-      wave_lds_fence();
-      seen_insert(S[0].L.seen, q0);
-      tl_update(T, true, q0, IT, magic, lane);
-      wave_lds_fence();
+    if (all_fast) {
+      hot_step(rk);
       continue;
     }
 

@@ -44,7 +44,7 @@ EXPORTS = (
     "icikt_version", "icikt_device_count", "icikt_ctx_create", "icikt_ctx_destroy", "icikt_last_error",
     "icikt_ctx_set_stream", "icikt_ctx_use_own_stream", "icikt_sync", "icikt_prepare_dev", "icikt_prepare_cols_dev", "icikt_prepare_cols_f64", "icikt_prep_arrays", "icikt_expand_cols_dev", "icikt_set_pairs", "icikt_set_pairs_combn",
     "icikt_num_pairs", "icikt_run_dev", "icikt_kernel_ms", "icikt_reset_timers", "icikt_pairs_f64",
-    "icikt_pair_f64", "icikt_missingness_f64", "icikt_selftest", "icikt_debug_set_plan",
+    "icikt_pair_f64", "icikt_pairs_complete_f64", "icikt_missingness_f64", "icikt_selftest", "icikt_debug_set_plan",
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
 )
@@ -125,6 +125,8 @@ def lib():
     L.icikt_reset_timers.argtypes = [c_vp]
     L.icikt_pairs_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u32,
                                   c_vp, c_vp, c_vp]
+    L.icikt_pairs_complete_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_u32,
+                                           c_vp, c_vp, c_vp]
     L.icikt_pair_f64.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_u32, c_vp, c_vp, c_vp]
     L.icikt_missingness_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]
     L.icikt_selftest.argtypes = [c_vp]
@@ -285,6 +287,23 @@ class Context:
         self._chk(lib().icikt_pairs_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a), P,
                                         PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, _ptr(out),
                                         _ptr(cnt), _ptr(rsn)), "icikt_pairs_f64")
+        return out, cnt, rsn
+
+    def pairs_complete(self, X, pi, pj, alternative="two.sided", continuity=False, flags: int = 0,
+                       want_counts: bool = False):
+        """kt_fast(use = "pairwise.complete.obs"): per pair, rows with a missing value in either vector are dropped."""
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        n_feat, n_samp = Xf.shape
+        pi_a = np.ascontiguousarray(pi, dtype=np.int32)
+        pj_a = np.ascontiguousarray(pj, dtype=np.int32)
+        P = pi_a.shape[0]
+        out = np.empty((P, 4), dtype=np.float64)
+        cnt = np.zeros((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
+        rsn = np.zeros(P, dtype=np.int32)
+        alt = ALTERNATIVE.get(alternative, ALT_OTHER)
+        self._chk(lib().icikt_pairs_complete_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a),
+                                                 P, alt, int(bool(continuity)), flags, _ptr(out), _ptr(cnt), _ptr(rsn)),
+                  "icikt_pairs_complete_f64")
         return out, cnt, rsn
 
     def pair(self, x, y, perspective="local", alternative="two.sided", continuity=False, flags: int = 0):

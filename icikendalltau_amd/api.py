@@ -51,6 +51,11 @@ class HipEngine:
     def missingness(self, X, pi, pj):
         return self.ctx.missingness(X, pi, pj)
 
+    def pairs_complete(self, X, pi, pj):
+        """kt_fast(use = "pairwise.complete.obs") on the device: (out4, reasons)."""
+        out, _cnt, rsn = self.ctx.pairs_complete(X, pi, pj, "two.sided", False, self.flags)
+        return out, rsn
+
     def pairs_block_dev(self, X, pi, pj, begin, end, n_each, perspective, alternative, continuity, dist, device,
                         via_host):
         """This rank's block [begin, end) of a pair list under torch.distributed: column-sharded pre-pass
@@ -224,20 +229,30 @@ def _as_matrix(data_matrix, colnames, arg):
 
 
 def setup_missing_matrix(data_matrix: np.ndarray, global_na) -> np.ndarray:
-    """Logical exclude_loc (R/utils.R:1-23)."""
-    exclude = np.zeros(data_matrix.shape, dtype=bool)
+    """Logical exclude_loc (R/utils.R:1-23), in the memory order of the matrix (no transposing copies)."""
     vals = [] if global_na is None else list(np.atleast_1d(np.asarray(global_na, dtype=np.float64)))
-    if len(vals) > 0:
-        if any(math.isnan(v) for v in vals):
-            exclude |= np.isnan(data_matrix)
-            vals = [v for v in vals if not math.isnan(v)]
-        if any(math.isinf(v) for v in vals):
-            exclude |= np.isinf(data_matrix)
-            vals = [v for v in vals if not math.isinf(v)]
+    has_nan = any(math.isnan(v) for v in vals)
+    has_inf = any(math.isinf(v) for v in vals)
+    vals = [v for v in vals if not (math.isnan(v) or math.isinf(v))]
+    if has_nan and has_inf:
+        exclude = ~np.isfinite(data_matrix)  # one pass for NA and Inf
+    elif has_nan:
+        exclude = np.isnan(data_matrix)
+    elif has_inf:
+        exclude = np.isinf(data_matrix)
+    else:
+        exclude = np.zeros_like(data_matrix, dtype=bool)
     for v in vals:
         with np.errstate(invalid="ignore"):
             exclude |= (data_matrix == v)
     return exclude
+
+
+def _masked_fortran(data_matrix: np.ndarray, exclude_loc: np.ndarray) -> np.ndarray:
+    """exclude_data[exclude_loc] = NA (R/kendalltau.R:120-121) as a column-major float64 matrix."""
+    out = np.array(data_matrix, dtype=np.float64, order="F", copy=True)
+    out[exclude_loc] = np.nan
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -382,7 +397,7 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
     """
     data_matrix, names = _as_matrix(data_matrix, colnames, "data_matrix")
     exclude_loc = setup_missing_matrix(data_matrix, global_na)
-    exclude_data = np.asfortranarray(np.where(exclude_loc, np.nan, data_matrix))
+    exclude_data = _masked_fortran(data_matrix, exclude_loc)
     n_sample = exclude_data.shape[1]
 
     eng = engine or _default_engine()
@@ -415,7 +430,7 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
         _warn_reason(r)
 
     raw, pvalue, taumax, completeness = out[:, 0], out[:, 1], out[:, 2], out[:, 3]
-    n_good = (~exclude_loc).sum(axis=0).astype(np.float64)
+    n_good = (exclude_loc.shape[0] - exclude_loc.sum(axis=0)).astype(np.float64)
     frac_complete = n_good / exclude_loc.shape[0]
 
     # scale_and_reshape
@@ -503,7 +518,8 @@ def kt_fast(x, y=None, use="everything", alternative="two.sided", continuity=Fal
     any column are dropped first; "pairwise.complete.obs": per pair, rows with an NA in either vector are
     dropped.  The last one runs on the GPU as ici_kt(..., perspective = "local") of the two vectors with both
     entries of such rows set missing -- identical to dropping the rows, since "local" removes rows missing in
-    both (src/kendallc.cpp:180-185) and nothing missing remains.
+    both (src/kendallc.cpp:180-185) and nothing missing remains; the HIP engine masks, sorts and counts every
+    pair on the device (icikt_pairs_complete_f64), other engines get the masked vectors from the host.
     """
     na_method = _match_use(use)
     if na_method == "na.or.complete":
@@ -537,7 +553,13 @@ def kt_fast(x, y=None, use="everything", alternative="two.sided", continuity=Fal
             X = X[keep]
     if do_computation:
         t1 = time.perf_counter()
-        if na_method == "pairwise.complete.obs" and np.isnan(X).any():
+        if na_method == "pairwise.complete.obs" and np.isnan(X).any() and hasattr(eng, "pairs_complete"):
+            # masking, per-pair sorts and counting on the device (icikt_pairs_complete_f64)
+            out, rsn = eng.pairs_complete(np.asfortranarray(X), pi, pj)
+            for r in rsn[rsn > 1]:
+                _warn_reason(r)
+            tau, pvalue = out[:, 0].copy(), out[:, 1].copy()
+        elif na_method == "pairwise.complete.obs" and np.isnan(X).any():
             na = np.isnan(X)
             for b in range(0, P, max_pair_chunk):
                 sl = slice(b, min(P, b + max_pair_chunk))

@@ -285,7 +285,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
-  c->d_X.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
+  c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (auto& p : c->ev_pool[k]) {
       if (p.a) (void)hipEventDestroy(p.a);
@@ -801,6 +801,76 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
   const hipError_t es = hipStreamSynchronize(c->stream);
   if (rc) return rc;
   if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(es));
+  return ICIKT_SUCCESS;
+}
+
+// kt_fast(use = "pairwise.complete.obs"): every pair gets its own two columns with the rows that miss either value
+// masked in both (k_mask_pairs), sorted (K0) and counted (K1, one pair per wave) on the device; the perspective is
+// "local" by construction.  Pairs go through in chunks that keep the masked columns within ~1.5 GiB.
+int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                             const int32_t* pi, const int32_t* pj, int64_t n_pairs, int alternative, int continuity,
+                             uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = check_shape(c, "pairs_complete", n_feat, n_samp, ld);
+  if (rc) return rc;
+  if (n_feat > 0 && n_samp > 0 && !X) return fail(c, ICIKT_E_INVALID, "pairs_complete: null matrix");
+  rc = check_pair_list(c, "pairs_complete", pi, pj, n_pairs, n_samp);
+  if (rc) return rc;
+  if (n_pairs == 0) return ICIKT_SUCCESS;
+  if (!out4) return fail(c, ICIKT_E_INVALID, "pairs_complete: null output");
+  if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return fail(c, ICIKT_E_INVALID, "pairs_complete: bad alternative code");
+  rc = use_device(c);
+  if (rc) return rc;
+  // the matrix and the pair list, once
+  rc = icikt_set_pairs(c, pi, pj, n_pairs);
+  if (rc) return rc;
+  DevBuf<int32_t> all_pi, all_pj;  // the caller's list stays on the device while d_pi / d_pj hold a chunk's (2k, 2k+1)
+  HIPCHK(c, all_pi.reserve((size_t)n_pairs));
+  HIPCHK(c, all_pj.reserve((size_t)n_pairs));
+  auto body = [&]() -> int {
+    HIPCHK(c, hipMemcpyAsync(all_pi.p, c->d_pi.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(all_pj.p, c->d_pj.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    int r = ICIKT_SUCCESS;
+    if (n_feat > 0) {  // H2D of the matrix; none of its own columns is sorted, only the masked pair columns are
+      const size_t nel = (size_t)n_feat * (size_t)n_samp;
+      HIPCHK(c, c->d_X.reserve(nel));
+      HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
+                                 (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
+    }
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_pairs, ((int64_t)3 << 29) / std::max<int64_t>(16 * n_feat, 16)));
+    HIPCHK(c, c->d_Xp.reserve((size_t)std::max<int64_t>(2 * chunk * n_feat, 1)));
+    HIPCHK(c, c->d_out4.reserve((size_t)chunk * 4));
+    if (counts) HIPCHK(c, c->d_counts.reserve((size_t)chunk * ICIKT_CNT_FIELDS));
+    if (reasons) HIPCHK(c, c->d_reasons.reserve((size_t)chunk));
+    std::vector<int32_t> qi, qj;
+    for (int64_t first = 0; first < n_pairs; first += chunk) {
+      const int64_t m = std::min(chunk, n_pairs - first);
+      HIPCHK(c, icikt::launch_mask_pairs(c->d_X.p, n_feat, (int)n_feat, all_pi.p, all_pj.p, first, m, c->d_Xp.p, c->stream));
+      r = icikt_prepare_dev(c, c->d_Xp.p, n_feat, 2 * m, n_feat, flags);
+      if (r) return r;
+      if ((int64_t)qi.size() != m) {
+        qi.resize((size_t)m); qj.resize((size_t)m);
+        for (int64_t k = 0; k < m; ++k) { qi[(size_t)k] = (int32_t)(2 * k); qj[(size_t)k] = (int32_t)(2 * k + 1); }
+        r = icikt_set_pairs(c, qi.data(), qj.data(), m);
+        if (r) return r;
+      }
+      r = icikt_run_dev(c, ICIKT_PERSPECTIVE_LOCAL, alternative, continuity, flags, c->d_out4.p,
+                        counts ? c->d_counts.p : nullptr, reasons ? c->d_reasons.p : nullptr);
+      if (r) return r;
+      r = icikt::host::download(c, out4 + 4 * first, c->d_out4.p, (size_t)m * 4 * sizeof(double));
+      if (!r && counts) r = icikt::host::download(c, counts + ICIKT_CNT_FIELDS * first, c->d_counts.p, (size_t)m * ICIKT_CNT_FIELDS * sizeof(int64_t));
+      if (!r && reasons) r = icikt::host::download(c, reasons + first, c->d_reasons.p, (size_t)m * sizeof(int32_t));
+      if (r) return r;
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // the chunk's buffers are reused by the next one
+    }
+    return ICIKT_SUCCESS;
+  };
+  rc = body();
+  const hipError_t es = hipStreamSynchronize(c->stream);
+  all_pi.release();
+  all_pj.release();
+  if (rc) return rc;
+  if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs_complete: ") + hipGetErrorString(es));
   return ICIKT_SUCCESS;
 }
 

@@ -96,6 +96,8 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
                      double* out4, int64_t* counts, int32_t* reasons, hipStream_t s);
 hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
                               int64_t* missing, hipStream_t s);
+hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,
+                             int64_t npairs, double* dXp, hipStream_t s);
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t s);
 
 }  // namespace icikt

@@ -69,7 +69,7 @@ struct icikt_ctx {
   void* pinned = nullptr;   // pinned staging area (h2d mode "stage")
   size_t pinned_bytes = 0;
   int h2d_mode = -1;        // -1: library default; 0 plain (pageable source), 1 register the caller's buffer, 2 stage
-  DevBuf<double> d_X, d_out4;
+  DevBuf<double> d_X, d_out4, d_Xp;  // d_Xp: masked column pairs of icikt_pairs_complete_f64
   DevBuf<int64_t> d_counts;
   DevBuf<int32_t> d_reasons;
   DevBuf<uint32_t> d_self;

@@ -2159,6 +2159,24 @@ k_missingness(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// kt_fast(use = "pairwise.complete.obs") (R/kendalltau.R:310-354, 448-545): per pair, rows with a missing value in
+// EITHER vector are dropped.  Writes the pair's two columns with both entries of such rows missing; "local" then
+// removes exactly those rows (src/kendallc.cpp:180-185) and nothing missing remains.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mask_pairs(const double* __restrict__ X, int64_t ld, int n, const int32_t* __restrict__ pi,
+             const int32_t* __restrict__ pj, int64_t first, double* __restrict__ Xp) {
+  const int64_t p = blockIdx.y;   // pair of the chunk
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const double a = X[(int64_t)pi[first + p] * ld + i], b = X[(int64_t)pj[first + p] * ld + i];
+  const bool drop = (a != a) || (b != b);
+  const double na = __longlong_as_double(0x7FF8000000000000ll);
+  Xp[(2 * p) * (int64_t)n + i] = drop ? na : a;
+  Xp[(2 * p + 1) * (int64_t)n + i] = drop ? na : b;
+}
+
+// ------------------------------------------------------------------------------------------------
 // self-test of the DPP primitives
 // ------------------------------------------------------------------------------------------------
 __global__ void k_selftest(uint32_t* out) {
@@ -2268,6 +2286,14 @@ hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32
   const int threads = 256;
   const int64_t blocks = (n_pairs * 64 + threads - 1) / threads;
   hipLaunchKernelGGL(k_missingness, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, n_pairs, missing);
+  return hipGetLastError();
+}
+
+hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,
+                             int64_t npairs, double* dXp, hipStream_t s) {
+  if (npairs <= 0 || n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mask_pairs, dim3((unsigned)((n + 255) / 256), (unsigned)npairs), dim3(256), 0, s, dX, ld, n, pi,
+                     pj, first, dXp);
   return hipGetLastError();
 }
 

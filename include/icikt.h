@@ -217,6 +217,13 @@ int icikt_multi_phase_ms(const icikt_multi *m, double *ms);
 /* icikt_debug_set_plan() on every rank's context. */
 int icikt_multi_debug_set_plan(icikt_multi *m, const char *spec);
 
+/* kt_fast(use = "pairwise.complete.obs") (R/kendalltau.R:310-354, 448-545): for every pair the rows with a missing
+ * value in EITHER vector are dropped, then ici_kt(..., perspective = "local") of what remains.  The masking, the
+ * per-pair sorts and the counting all run on the device (pairs in chunks); same outputs as icikt_pairs_f64. */
+int icikt_pairs_complete_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                             const int32_t *pi, const int32_t *pj, int64_t n_pairs, int alternative,
+                             int continuity, uint32_t flags, double *out4, int64_t *counts, int32_t *reasons);
+
 /* pairwise_completeness() arithmetic (R/kendalltau.R:611-629): missingness[p] = #rows missing in
  * either column, from a host matrix whose missing cells are NaN.  Self pairs allowed. */
 int icikt_missingness_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,

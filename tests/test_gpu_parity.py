@@ -579,3 +579,34 @@ def test_host_upload_modes(plan_ctx, mode):
         plan_ctx.debug_set_plan("h2d=bogus")
     with pytest.raises(_lib.IciktError, match="unknown key"):
         plan_ctx.debug_set_plan("nope=1")
+
+
+def test_pairs_complete_on_device(hip_ctx):
+    """icikt_pairs_complete_f64 (kt_fast use = "pairwise.complete.obs"): masking + per-pair sort + counting on the
+    device, several chunks of pairs, self pairs included; against the oracle on host-masked vectors."""
+    O = _oracle()
+    rng = np.random.default_rng(73)
+    n, S = 20000, 120                                   # 7 260 pairs x 2 columns x 160 KB = 2.3 GB of masked columns
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random(X.shape) < 0.08] = np.nan
+    X[:, 7] = np.round(X[:, 7] * 3)
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=0))   # self pairs too, as kt_fast has them
+    out, cnt, rsn = hip_ctx.pairs_complete(X, pi, pj, want_counts=True)
+    assert out.shape == (len(pi), 4) and np.all(rsn == 0)
+    sel = rng.choice(len(pi), size=150, replace=False)
+    for p in sel:
+        either = np.isnan(X[:, pi[p]]) | np.isnan(X[:, pj[p]])
+        x = np.where(either, np.nan, X[:, pi[p]])
+        y = np.where(either, np.nan, X[:, pj[p]])
+        ref, rcnt, rr = O.ici_kt(x, y, "local")
+        assert rr == 0
+        assert [int(v) for v in cnt[p]] == [rcnt[k] for k in ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")]
+        assert float(np.max(np.abs(out[p] - ref))) <= ATOL
+    assert np.all(cnt[:, 1] == 0)                        # nothing missing remains after the drop
+    # the python front-end reaches it
+    from icikendalltau_amd import api
+    names = [f"c{i}" for i in range(6)]
+    g = api.kt_fast(X[:3000, :6], use="pairwise.complete.obs", colnames=names)
+    from tests.oracle_engine import OracleEngine
+    o = api.kt_fast(X[:3000, :6], use="pairwise.complete.obs", colnames=names, engine=OracleEngine())
+    assert np.nanmax(np.abs(g["tau"].to_numpy() - o["tau"].to_numpy())) <= ATOL

@@ -412,11 +412,15 @@ def extras(line, args, cfg, X, ctx, dev):
     if args.config != "c5":
         names = [f"s{i}" for i in range(S)]
         eng = api.HipEngine(device=dev.index)
-        t0 = time.perf_counter()
-        res = api.ici_kendalltau(X, global_na=(float("nan"), float("inf")), perspective="global", colnames=names, engine=eng)
-        t_e2e = time.perf_counter() - t0
-        line["e2e_ici_kendalltau_ms"] = t_e2e * 1e3
-        line["e2e_run_time_field_ms"] = res["run_time"] * 1e3
+        ts, rt = [], []
+        for _ in range(3):   # the first call also creates the engine's context and workspaces
+            t0 = time.perf_counter()
+            res = api.ici_kendalltau(X, perspective="global", colnames=names, engine=eng)
+            ts.append(time.perf_counter() - t0)
+            rt.append(res["run_time"])
+        line["e2e_ici_kendalltau_ms"] = min(ts) * 1e3          # masking, pair list, the engine call, five S x S matrices
+        line["e2e_first_call_ms"] = ts[0] * 1e3
+        line["e2e_run_time_field_ms"] = min(rt) * 1e3          # the reference's run_time: the split_fun call alone
     else:
         # (3) BASELINE config 5's subset legs: include_only = the first 64 names (pairs with s1 OR s2 among them) in
         #     both perspectives, and pairwise_completeness (self pairs included) on the same subset

@@ -109,6 +109,17 @@ def _default_engine():
     return HipEngine()
 
 
+_multi_engines: dict = {}
+
+
+def _multi_engine(n_gpu, devices):
+    """One MultiHipEngine per device list: RCCL communicators are expensive to create."""
+    devs = tuple(int(d) for d in devices) if devices is not None else tuple(range(int(n_gpu)))
+    if devs not in _multi_engines:
+        _multi_engines[devs] = MultiHipEngine(devices=list(devs))
+    return _multi_engines[devs]
+
+
 # --------------------------------------------------------------------------------------------------
 # ici_kt: one pair (R/RcppExports.R:62-64 -> src/kendallc.cpp:166)
 # --------------------------------------------------------------------------------------------------
@@ -386,8 +397,13 @@ def _named_matrix(values: np.ndarray, names):
 
 def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), perspective="global", scale_max=True,
                    diag_good=True, include_only=None, alternative="two.sided", continuity=False,
-                   check_timing=False, return_matrix=True, colnames=None, engine=None):
+                   check_timing=False, return_matrix=True, colnames=None, engine=None, n_gpu=1, devices=None):
     """All-pairs ICI-Kendall-tau between the COLUMNS (samples) of a features x samples matrix.
+
+    ``n_gpu`` > 1 (or ``devices``) uses several MI355X behind one library call (icikt_pairs_multi_f64: a host
+    thread per GPU, RCCL all-gather / gather over xGMI) -- the role furrr workers play in the reference
+    (R/kendalltau.R:127,158): the `core` column then numbers the GPUs' pair blocks.  Under an initialised
+    torch.distributed process group the ranks are the cores instead (one process per GPU).
 
     Mirrors R/kendalltau.R:96-179: same argument names and defaults; returns a dict with ``cor, raw,
     pvalue, taumax, completeness`` (samples x samples, un-computed cells 0), ``keep`` and ``run_time``,
@@ -400,9 +416,13 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
     exclude_data = _masked_fortran(data_matrix, exclude_loc)
     n_sample = exclude_data.shape[1]
 
-    eng = engine or _default_engine()
     _dist, _rank, world = _dist_info()
-    pi, pj, core = setup_comparisons(names, include_only, diag_good, ncore=world)
+    ncore = world
+    if engine is None and world == 1 and (n_gpu > 1 or devices is not None):
+        engine = _multi_engine(n_gpu, devices)
+        ncore = len(engine.ctx.devices)
+    eng = engine or _default_engine()
+    pi, pj, core = setup_comparisons(names, include_only, diag_good, ncore=ncore)
     n_todo = len(pi)
 
     if check_timing:  # R/kendalltau.R:141-148, 633-669
@@ -416,7 +436,7 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
         n_comp = len(pick)
         t_each = t_total / n_comp
         t_theoretical = t_each * n_todo
-        t_cores = t_theoretical / world
+        t_cores = t_theoretical / ncore
         which = ["n_tested", "n_todo", "time_tested", "time_single", "time_all", "time_across_cores",
                  "time_minutes", "time_hours", "time_days"]
         value = [n_comp, n_todo, t_total, t_each, t_theoretical, t_cores, t_cores / 60, t_cores / (60 * 60),

@@ -1230,9 +1230,15 @@ __device__ __forceinline__ uint32_t seg_query(unsigned long long* seen, uint16_t
 }
 
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st, const unsigned long long F, const int nact,
-                                                              const uint32_t rk, const int IT, const uint32_t magic,
+__device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st, const unsigned long long F_in, const int nact_in,
+                                                              const uint32_t rk, const int IT_in, const uint32_t magic_in,
                                                               const uint32_t lane) {
+  // arguments of an out-of-line function arrive in vector registers: the wave-uniform ones go back to scalar
+  // registers, or everything derived from them (the flag arithmetic, loop counters) runs on the vector unit
+  const unsigned long long F = uniform_u64(F_in);
+  const int nact = __builtin_amdgcn_readfirstlane(nact_in);
+  const int IT = __builtin_amdgcn_readfirstlane(IT_in);
+  const uint32_t magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)magic_in);
   unsigned long long* seen = (unsigned long long*)st.seen;
   uint16_t* spre = (uint16_t*)st.spre;
   const uint32_t sl = (SEG == 32) ? (lane & 31u) : lane;
@@ -1286,10 +1292,15 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
 // group list when the group closes (close_group_ties).  A single-step group of a row-mode pair needs no pend at
 // all: its rows are inserted into `seen` directly and "after - before" cancels the rows of earlier groups.
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) SegCounts seg_group_step(const SegState st, const int nact, const bool single,
-                                                              const bool closes, const bool rowmode, const uint32_t rk,
-                                                              const uint32_t hi_in, const uint32_t cfill, const int IT,
-                                                              const uint32_t magic, const uint32_t lane) {
+__device__ __attribute__((noinline)) SegCounts seg_group_step(const SegState st, const int nact_in, const bool single_in,
+                                                              const bool closes_in, const bool rowmode, const uint32_t rk,
+                                                              const uint32_t hi_in, const uint32_t cfill, const int IT_in,
+                                                              const uint32_t magic_in, const uint32_t lane) {
+  const int nact = __builtin_amdgcn_readfirstlane(nact_in);   // wave-uniform arguments back to scalar registers
+  const bool single = __builtin_amdgcn_readfirstlane((int)single_in) != 0;
+  const bool closes = __builtin_amdgcn_readfirstlane((int)closes_in) != 0;
+  const int IT = __builtin_amdgcn_readfirstlane(IT_in);
+  const uint32_t magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)magic_in);
   unsigned long long* seen = (unsigned long long*)st.seen;
   uint16_t* spre = (uint16_t*)st.spre;
   const uint32_t sl = (SEG == 32) ? (lane & 31u) : lane;
@@ -1349,7 +1360,8 @@ __device__ __attribute__((noinline)) SegCounts seg_group_step(const SegState st,
 
 // a group closes: its rows, collected in pend, become visible in seen
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int IT, const uint32_t lane) {
+__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int IT_in, const uint32_t lane) {
+  const int IT = __builtin_amdgcn_readfirstlane(IT_in);
   unsigned long long* seen = (unsigned long long*)st.seen;
   unsigned long long* pend = (unsigned long long*)st.pend;
   uint16_t* spre = (uint16_t*)st.spre;

@@ -118,3 +118,21 @@ def test_multi_error_contract():
         assert np.all(r == 0) and not np.isnan(o).any()
     finally:
         m.close()
+
+
+def test_api_n_gpu_argument(single):
+    """api.ici_kendalltau(n_gpu = / devices =): the Python mirror of the R wrapper's n_gpu -- `core` numbers the GPUs'
+    pair blocks (ceiling(P / n_gpu) consecutive pairs, R/kendalltau.R:250-255), results equal the one-GPU call."""
+    from icikendalltau_amd import api
+    X = _matrix(1500, 21, 9)
+    names = [f"s{i}" for i in range(21)]
+    one = api.ici_kendalltau(X, colnames=names, return_matrix=False)["cor"]
+    two = api.ici_kendalltau(X, colnames=names, return_matrix=False, devices=[0, 0, 0])["cor"]
+    for col in ("s1", "s2"):
+        assert list(one[col]) == list(two[col])
+    for col in ("raw", "pvalue", "taumax", "completeness", "cor"):
+        assert np.array_equal(one[col].to_numpy(), two[col].to_numpy(), equal_nan=True)
+    assert list(two["core"]) == [1] * 70 + [2] * 70 + [3] * 70 + [0] * 21     # 210 pairs over 3 GPUs
+    assert list(one["core"]) == [1] * 210 + [0] * 21
+    m = api.ici_kendalltau(X, colnames=names, n_gpu=1, perspective="local")
+    assert m["cor"].shape == (21, 21)

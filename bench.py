@@ -310,14 +310,17 @@ def main():
         value = P_total * args.steps / elapsed
         # roofline of the dominant kernel (K1): algorithmic bytes per launch = pairs in the launch x (16 n + 32)
         # (two float64 columns in, four float64 out per pair: SURVEY.md section 8(d)) / avg launch duration
+        # (the pair kernel runs as one launch per pre-pass group when it overlaps the pre-pass: the launches of a
+        #  step together process P_local pairs, so the step's K1 time is what the bytes are divided by)
         k1_ms, k1_n = k_ms["pairs"]
-        k1_avg_s = (k1_ms / max(k1_n, 1)) / 1e3
+        k1_avg_s = (k1_ms / args.steps) / 1e3
         alg_bytes = P_local * (16 * n + 32)
         achieved = alg_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         traffic, traffic_src = hbm_traffic(n, S, P_local)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k1_pairs",
                 "avg_launch_ms": k1_avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_launches_per_step": k1_n / args.steps,
                 "note": "frac prices the reference's data flow (two f64 columns per pair) against HBM; the columns are "
                         "sorted once and reused S-1 times, so the kernel's real limiter is VALU issue + LDS, not HBM"}
         if traffic:

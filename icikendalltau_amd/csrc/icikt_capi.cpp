@@ -135,7 +135,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2 + 2));  // seen, pend, spre, ppre
+  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2) + icikt::K1_HALF_PRE);  // seen, pend, ppre + prefix slots
   else  // one pair per wave: seen [, pend], the two-level counts [, ppre]
     pl.perpair_bytes = (int)((size_t)pl.stride * (pl.pend_global ? 8 : (8 + 8 + 2)) + icikt::K1_TL_BYTES);
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));

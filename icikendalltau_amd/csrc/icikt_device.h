@@ -71,6 +71,9 @@ struct PrepView {
 // one pair per wave: bytes of the two-level counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32)
 constexpr int K1_TL_BYTES = 2048 + 256 + 256;
 
+// half-wave kernels: bytes of a pair's prefix slots (32 lanes x 8 x u16, one aligned 16-byte slot per lane)
+constexpr int K1_HALF_PRE = 32 * 8 * 2;
+
 // half-wave K1 kernels exist for 1..ICIKT_HALF_ITEMS_MAX words per lane of a half's prefix rebuild (n <= 10 176)
 constexpr int ICIKT_HALF_ITEMS_MAX = 5;
 

@@ -974,9 +974,36 @@ __device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
   return v;
 }
 
-// prefix rebuild of one bitset per half: lane l (0..31) of a half owns words [l*HI, (l+1)*HI).  The arrays
-// of a half-wave kernel are padded to 32*HI words, so nothing is predicated; v_bcnt accumulates the running
-// count on its own.
+// Prefix of one bitset per half: lane l (0..31) of a half owns words [l*HI, (l+1)*HI) and keeps their exclusive
+// prefix counts in ONE aligned 16-byte slot of `pre` (8 x u16, HI <= 5 of them used): the K1 hot loop is bound by
+// LDS operations, not by VALU issue (removing the whole all-pairs block changes nothing, removing the prefix
+// stores 15 %: DESIGN.md section 7), and HI u16 values at a stride of 2*HI bytes made one misaligned 8-byte store
+// plus a 2-byte one.  Word w lives in slot w / HI, entry w % HI.
+constexpr int K1_HALF_SLOT = 8;                       // u16 entries per lane slot
+constexpr int K1_HALF_PRE_BYTES = 32 * K1_HALF_SLOT * 2;
+template <int HI>
+__device__ __forceinline__ uint32_t half_pre_index(uint32_t w) {
+  const uint32_t o = w / (uint32_t)HI;
+  return o * (uint32_t)K1_HALF_SLOT + (w - o * (uint32_t)HI);
+}
+template <int HI>
+__device__ __forceinline__ uint32_t prefix_query_half(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
+  const uint32_t w = pos >> 6;
+  return (uint32_t)pre[half_pre_index<HI>(w)] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
+}
+// counts of the HI words a lane holds in registers -> the lane's slot; cw[i] = bits in words 0 .. i of the lane
+template <int HI>
+__device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32_t excl, const uint32_t (&cw)[HI]) {
+  uint32_t v[4];
+  v[0] = excl; v[1] = 0; v[2] = 0; v[3] = 0;
+  if (HI > 1) v[0] |= (excl + cw[0]) << 16;
+  if (HI > 2) v[1] = excl + cw[1];
+  if (HI > 3) v[1] |= (excl + cw[2]) << 16;
+  if (HI > 4) v[2] = excl + cw[3];
+  uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)K1_HALF_SLOT);
+  if (HI > 4) *slot = make_uint4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<uint2*>(slot) = make_uint2(v[0], v[1]);
+}
 template <int HI>
 __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bits, uint16_t* pre, uint32_t l) {
   const uint32_t base = l * (uint32_t)HI;
@@ -989,9 +1016,7 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
     c[i] = run;
   }
   const uint32_t excl = half_incl_scan(run) - run;
-  pre[base] = (uint16_t)excl;
-#pragma unroll
-  for (int i = 1; i < HI; ++i) pre[base + i] = (uint16_t)(excl + c[i - 1]);
+  half_pre_store<HI>(pre, l, excl, c);
 }
 
 // ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages, no LDS)
@@ -1226,7 +1251,7 @@ struct SegCounts { uint32_t dis, neg, tie, tie2, cfill; };
 
 template <int SEG, int HI>
 __device__ __forceinline__ uint32_t seg_query(unsigned long long* seen, uint16_t* spre, uint32_t lo, int IT, uint32_t magic) {
-  return (SEG == 64) ? tl_query(tl_view(seen, spre), lo, IT, magic) : prefix_query(seen, spre, lo);
+  return (SEG == 64) ? tl_query(tl_view(seen, spre), lo, IT, magic) : prefix_query_half<(HI > 0 ? HI : 1)>(seen, spre, lo);
 }
 
 template <int SEG, int HI>
@@ -1507,13 +1532,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
       for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
     } else {
+      // half-wave kernels: seen | pend | prefix slots of seen (32 lanes x 16 B) | ppre
       Pg[k].bits = S[k].L.seen + Wp4;
       S[k].L.spre = reinterpret_cast<uint16_t*>(Pg[k].bits + Wp4);
-      Pg[k].pre16 = S[k].L.spre + Wp4;
+      Pg[k].pre16 = S[k].L.spre + K1_HALF_PRE_BYTES / 2;
       Pg[k].pre = nullptr;
-      for (int w = lane; w < Wp4; w += 64) {
-        S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; S[k].L.spre[w] = 0; Pg[k].pre16[w] = 0;
-      }
+      for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; Pg[k].pre16[w] = 0; }
+      for (int w = lane; w < K1_HALF_PRE_BYTES / 2; w += 64) S[k].L.spre[w] = 0;
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
@@ -1613,7 +1638,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // two reads, the rows' OR into seen, the reads of the prefix rebuild (one wave's DS operations execute in
         // order, so the query sees the bitset before, the rebuild after the insertion) -- and the all-pairs count,
         // which needs registers only, runs while they are in flight.
-        const uint32_t pre_lo = (uint32_t)spreH[loh >> 6];
+        const uint32_t pre_lo = (uint32_t)spreH[half_pre_index<H>(loh >> 6)];
         const unsigned long long word_lo = seenH[loh >> 6];
         wave_lds_fence();
         seen_insert(seenH, qh);
@@ -1630,7 +1655,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
         for (int i = 0; i < H; ++i) asm volatile("" : "+v"(wv[i]));
         dis_half += pre_lo_k + (uint32_t)__popcll(word_lo_k & low_mask64(loh & 63u)) + inpairs;
-        // prefix of the half's bitset: lane l owns words [l*H, (l+1)*H)
+        // prefix of the half's bitset: lane l owns words [l*H, (l+1)*H); one aligned 16-byte store per lane
         uint32_t cw[H], run = 0;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
@@ -1638,11 +1663,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           run = (uint32_t)__builtin_popcount((uint32_t)(wv[i] >> 32)) + run;
           cw[i] = run;
         }
-        const uint32_t excl = half_incl_scan(run) - run;
-        uint16_t* pre = spreH + l32 * (uint32_t)H;
-        pre[0] = (uint16_t)excl;
-#pragma unroll
-        for (int i = 1; i < H; ++i) pre[i] = (uint16_t)(excl + cw[i - 1]);
+        half_pre_store<H>(spreH, l32, half_incl_scan(run) - run, cw);
         wave_lds_fence();
       }
     } else {

@@ -969,9 +969,9 @@ int icikt_selftest(icikt_ctx* c) {
   if (!c) return ICIKT_E_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
-  HIPCHK(c, c->d_self.reserve(576));
+  HIPCHK(c, c->d_self.reserve(640));
   HIPCHK(c, icikt::launch_selftest(c->d_self.p, c->stream));
-  uint32_t h[576];
+  uint32_t h[640];
   HIPCHK(c, hipMemcpyAsync(h, c->d_self.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (uint32_t l = 0; l < 64; ++l) {
@@ -1004,6 +1004,22 @@ int icikt_selftest(icikt_ctx* c) {
     if (got != want) {
       if (c->plan_ov.verbose) fprintf(stderr, "[icikt] selftest half %u: got %u want %u\n", half, got, want);
       return fail(c, ICIKT_E_HIP, "selftest: half_allpairs mismatch");
+    }
+  }
+  // ... and the packed form: two sub-steps' rows at once, the counts of both summed
+  for (uint32_t half = 0; half < 2; ++half) {
+    uint32_t want = 0, got = 0;
+    for (uint32_t l = half * 32; l < half * 32 + 32; ++l) {
+      const uint32_t lo = ((l * 40503u + 977u) >> 3) & 0xFFFu, lo2 = ((l * 69069u + 12345u) >> 5) & 0x27BFu;
+      for (uint32_t j = half * 32; j < l; ++j) {
+        want += (((j * 2654435761u >> 20) & 0xFFFu) < lo) ? 1u : 0u;
+        want += (((j * 1103515245u >> 17) & 0x27BFu) < lo2) ? 1u : 0u;
+      }
+      got += h[576 + l];
+    }
+    if (got != want) {
+      if (c->plan_ov.verbose) fprintf(stderr, "[icikt] selftest half %u (packed): got %u want %u\n", half, got, want);
+      return fail(c, ICIKT_E_HIP, "selftest: half_step_count mismatch");
     }
   }
   return ICIKT_SUCCESS;

@@ -824,6 +824,47 @@ __device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t
   return half_allpairs(q, lo, xa, ~offer, lane);
 }
 
+// ---- both 32-row sub-steps of a half-wave step in one chain (hot steps) -----------------------------------------
+// The in-step pairs of a sub-step need registers only, so the two sub-steps of a 64-row step are counted TOGETHER,
+// one in each 16-bit half of the operands (positions of a half-wave kernel are < 16 384 = 14 bits):
+//     A = 0x3FFF - q   (what a row offers)        B = 0x4000 + lo   (what a row compares with)
+//     A_a + B_j = 0x7FFF + lo_j - q_a :  bit 15 set  <=>  q_a < lo_j,  and nothing carries into the upper half.
+// One DPP add per shift distance serves 2 x 64 compares, and its two flag bits (15, 31) are shifted into a bit
+// vector by two full-rate instructions (v_lshrrev, v_and_or) -- the carry forms of half_allpairs (v_sub_co_dpp +
+// v_addc) are both half-rate.  Every flag of a lane counts for the lane's pair, so the vectors are only
+// popcounted.  A lane without a source (row_shr past the row start, bound_ctrl:0) adds 0: B < 0x8000, no flag, no
+// correction.  Between the half's two rows the sum is symmetric: an upper lane adds the lower rows' A to its B, a
+// lower lane the upper rows' B to its A, so `offer` is both what a lane offers and what it adds (layout of the
+// partners as in half_count).  At most 16 flags per field and vector: one vector for the 15 in-row distances, one
+// for the 8 between rows.
+#define ICIKT_PSHR(b) "v_add_u32_dpp %1, %2, %3 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+                      "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
+#define ICIKT_PROR(b) "v_add_u32_dpp %1, %2, %3 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
+                      "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
+__device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane) {
+  const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
+  const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
+  const uint32_t A = 0x3FFF3FFFu - Q, B = 0x40004000u + LO;
+  const uint32_t offer = (lane & 16u) ? B : A;
+  const auto r = __builtin_amdgcn_permlane16_swap(offer, offer, false, false);
+  const uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[1], 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+  const uint32_t xa = (lane & 16u) ? r[0] : rot;
+  const uint32_t M = 0x80008000u;
+  uint32_t in_row = 0, cross, t;
+  asm volatile("s_nop 1\n\t"
+               ICIKT_PSHR(1) ICIKT_PSHR(2) ICIKT_PSHR(3) ICIKT_PSHR(4) ICIKT_PSHR(5) ICIKT_PSHR(6) ICIKT_PSHR(7)
+               ICIKT_PSHR(8) ICIKT_PSHR(9) ICIKT_PSHR(10) ICIKT_PSHR(11) ICIKT_PSHR(12) ICIKT_PSHR(13)
+               ICIKT_PSHR(14) ICIKT_PSHR(15)
+               : "+v"(in_row), "=&v"(t)
+               : "v"(A), "v"(B), "s"(M));
+  cross = (xa + offer) & M;
+  asm volatile("s_nop 1\n\t"
+               ICIKT_PROR(1) ICIKT_PROR(2) ICIKT_PROR(3) ICIKT_PROR(4) ICIKT_PROR(5) ICIKT_PROR(6) ICIKT_PROR(7)
+               : "+v"(cross), "=&v"(t)
+               : "v"(xa), "v"(offer), "s"(M));
+  return (uint32_t)__builtin_popcount(in_row) + (uint32_t)__builtin_popcount(cross);
+}
+
 // ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
 // Same construction as the half-wave step, for four DPP rows: 15 in-row compares (row_shr) and, for the six
 // row pairs, three rounds in which every row has one partner row (1: 0-1 2-3, 2: 0-2 1-3, 3: 0-3 1-2) and both
@@ -1630,6 +1671,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint16_t* spreH = hi ? S[NP - 1].L.spre : S[0].L.spre;
       const uint32_t l32 = lane & 31u;
       constexpr int H = (HI > 0 ? HI : 1);
+      // the in-step pairs of both sub-steps, while sub-step 0's LDS reads are in flight
+      uint32_t inpairs = 0;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const uint32_t r = sub ? sw[1] : sw[0];
@@ -1646,7 +1689,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         unsigned long long wv[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
-        const uint32_t inpairs = half_count(qh, loh, lane);
+        if (sub == 0) inpairs = half_step_count(sw[0], sw[1], lane);
         // (the loaded words are consumed only behind the all-pairs block: an empty asm pins that order, or the
         //  scheduler hoists the popcounts -- and the wait for the loads -- in front of it)
         uint32_t pre_lo_k = pre_lo;
@@ -1654,7 +1697,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         asm volatile("" : "+v"(pre_lo_k), "+v"(word_lo_k));
 #pragma unroll
         for (int i = 0; i < H; ++i) asm volatile("" : "+v"(wv[i]));
-        dis_half += pre_lo_k + (uint32_t)__popcll(word_lo_k & low_mask64(loh & 63u)) + inpairs;
+        dis_half += pre_lo_k + (uint32_t)__popcll(word_lo_k & low_mask64(loh & 63u)) + (sub == 0 ? inpairs : 0u);
         // prefix of the half's bitset: lane l owns words [l*H, (l+1)*H); one aligned 16-byte store per lane
         uint32_t cw[H], run = 0;
 #pragma unroll
@@ -2222,6 +2265,10 @@ __global__ void k_selftest(uint32_t* out) {
   // half-wave pieces: q, lo from a fixed pseudo-random table; the host recomputes the counts
   const uint32_t q = (lane * 2654435761u >> 20) & 0xFFFu, lo = ((lane * 40503u + 977u) >> 3) & 0xFFFu;
   out[192 + lane] = half_count(q, lo, lane);  // summed per half by the host
+  {  // the packed form of two sub-steps at once: rows (q, lo) and (q2, lo2) must give both counts together
+    const uint32_t q2 = (lane * 1103515245u >> 17) & 0x27BFu, lo2 = ((lane * 69069u + 12345u) >> 5) & 0x27BFu;
+    out[576 + lane] = half_step_count(q | (lo << 16), q2 | (lo2 << 16), lane);
+  }
   const auto sw = __builtin_amdgcn_permlane32_swap(lane, 100u + lane, false, false);
   out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)
   out[320 + lane] = sw[1];                                     // lanes < 32: 32 + lane, else 100 + lane

@@ -88,6 +88,15 @@ __device__ __forceinline__ void seen_insert(unsigned long long* bits, uint32_t p
   atomicOr(reinterpret_cast<uint32_t*>(bits) + (pos >> 5), 1u << (pos & 31u));
 }
 
+// popcount(x) + acc in the one instruction that does both (hipcc splits chains of these into popcounts and adds)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ uint32_t bcnt64_acc(unsigned long long x, uint32_t acc) {
+  return bcnt_acc((uint32_t)(x >> 32), bcnt_acc((uint32_t)x, acc));
+}
 __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/) {
   return (1ull << bits) - 1ull;
 }
@@ -837,10 +846,15 @@ __device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t
 // lower lane the upper rows' B to its A, so `offer` is both what a lane offers and what it adds (layout of the
 // partners as in half_count).  At most 16 flags per field and vector: one vector for the 15 in-row distances, one
 // for the 8 between rows.
-#define ICIKT_PSHR(b) "v_add_u32_dpp %1, %2, %3 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-                      "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
-#define ICIKT_PROR(b) "v_add_u32_dpp %1, %2, %3 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" \
-                      "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
+// (In a mixed instruction stream every VALU instruction of this kernel costs about one 4-cycle issue slot, whatever
+// its class -- tools/ubench/valu_rate.hip -- so what counts is the NUMBER of instructions.)  The flag bits of two
+// sums are gathered by one v_perm_b32 (bytes 1 and 3 of both: four flags at bit 7 of a byte) and shifted into the
+// vector together: 2.5 instructions per 256 compares.
+#define ICIKT_PACC  "v_perm_b32 %1, %1, %2, %6\n\tv_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %5, %0\n\t"
+#define ICIKT_PSHR2(a, b) "v_add_u32_dpp %1, %3, %4 row_shr:" #a " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+                          "v_add_u32_dpp %2, %3, %4 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" ICIKT_PACC
+#define ICIKT_PROR2(a, b) "v_add_u32_dpp %1, %3, %4 row_ror:" #a " row_mask:0xf bank_mask:0xf\n\t" \
+                          "v_add_u32_dpp %2, %3, %4 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" ICIKT_PACC
 __device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane) {
   const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
   const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
@@ -849,20 +863,30 @@ __device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, 
   const auto r = __builtin_amdgcn_permlane16_swap(offer, offer, false, false);
   const uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[1], 0x121 /*row_ror:1*/, 0xf, 0xf, false);
   const uint32_t xa = (lane & 16u) ? r[0] : rot;
-  const uint32_t M = 0x80008000u;
-  uint32_t in_row = 0, cross, t;
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
+  uint32_t v1, v2, t1, t2;
+  // vector 1: the 15 in-row distances and distance 0 between the rows (8 x 4 flags: bits 0..7 of every byte)
   asm volatile("s_nop 1\n\t"
-               ICIKT_PSHR(1) ICIKT_PSHR(2) ICIKT_PSHR(3) ICIKT_PSHR(4) ICIKT_PSHR(5) ICIKT_PSHR(6) ICIKT_PSHR(7)
-               ICIKT_PSHR(8) ICIKT_PSHR(9) ICIKT_PSHR(10) ICIKT_PSHR(11) ICIKT_PSHR(12) ICIKT_PSHR(13)
-               ICIKT_PSHR(14) ICIKT_PSHR(15)
-               : "+v"(in_row), "=&v"(t)
-               : "v"(A), "v"(B), "s"(M));
-  cross = (xa + offer) & M;
+               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PSHR2(3, 4) ICIKT_PSHR2(5, 6) ICIKT_PSHR2(7, 8) ICIKT_PSHR2(9, 10) ICIKT_PSHR2(11, 12)
+               ICIKT_PSHR2(13, 14)
+               "v_add_u32_dpp %1, %3, %4 row_shr:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_e32 %2, %7, %8\n\t" ICIKT_PACC
+               : "=&v"(v1), "=&v"(t1), "=&v"(t2)
+               : "v"(A), "v"(B), "s"(M8), "s"(SEL), "v"(xa), "v"(offer));
+  // vector 2: distances 1..7 between the rows (the last sum alone: its flags, bits 15 and 31, go in unpermuted)
   asm volatile("s_nop 1\n\t"
-               ICIKT_PROR(1) ICIKT_PROR(2) ICIKT_PROR(3) ICIKT_PROR(4) ICIKT_PROR(5) ICIKT_PROR(6) ICIKT_PROR(7)
-               : "+v"(cross), "=&v"(t)
-               : "v"(xa), "v"(offer), "s"(M));
-  return (uint32_t)__builtin_popcount(in_row) + (uint32_t)__builtin_popcount(cross);
+               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PROR2(3, 4) ICIKT_PROR2(5, 6)
+               "v_add_u32_dpp %1, %3, %4 row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+               "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %7, %0\n\t"
+               : "=&v"(v2), "=&v"(t1), "=&v"(t2)
+               : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
+  return bcnt_acc(v2, bcnt_acc(v1, 0u));
 }
 
 // ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
@@ -1015,11 +1039,11 @@ __device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
   return v;
 }
 
-// Prefix of one bitset per half: lane l (0..31) of a half owns words [l*HI, (l+1)*HI) and keeps their exclusive
-// prefix counts in ONE aligned 16-byte slot of `pre` (8 x u16, HI <= 5 of them used): the K1 hot loop is bound by
-// LDS operations, not by VALU issue (removing the whole all-pairs block changes nothing, removing the prefix
-// stores 15 %: DESIGN.md section 7), and HI u16 values at a stride of 2*HI bytes made one misaligned 8-byte store
-// plus a 2-byte one.  Word w lives in slot w / HI, entry w % HI.
+// Prefix of one bitset per half: lane l (0..31) of a half owns words [l*HI, (l+1)*HI) and keeps their INCLUSIVE
+// prefix counts (bits in words 0 .. w) in ONE aligned 16-byte slot of `pre` (8 x u16, HI <= 5 of them used): HI u16
+// values at a stride of 2*HI bytes made one misaligned 8-byte store plus a 2-byte one, and that store alone kept
+// the LDS unit busy.  Word w lives in slot w / HI, entry w % HI.  A query is
+// `entry - popcount(word >> bit)`: the shift takes its count from the low six bits of the position, no mask is built.
 constexpr int K1_HALF_SLOT = 8;                       // u16 entries per lane slot
 constexpr int K1_HALF_PRE_BYTES = 32 * K1_HALF_SLOT * 2;
 template <int HI>
@@ -1030,17 +1054,20 @@ __device__ __forceinline__ uint32_t half_pre_index(uint32_t w) {
 template <int HI>
 __device__ __forceinline__ uint32_t prefix_query_half(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
   const uint32_t w = pos >> 6;
-  return (uint32_t)pre[half_pre_index<HI>(w)] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
+  return (uint32_t)pre[half_pre_index<HI>(w)] - (uint32_t)__popcll(bits[w] >> (pos & 63u));
 }
-// counts of the HI words a lane holds in registers -> the lane's slot; cw[i] = bits in words 0 .. i of the lane
+// counts of the HI words a lane holds in registers -> the lane's slot; cw[i] = bits in words 0 .. i of the lane,
+// incl = the half's inclusive scan of cw[HI - 1]
 template <int HI>
-__device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32_t excl, const uint32_t (&cw)[HI]) {
-  uint32_t v[4];
-  v[0] = excl; v[1] = 0; v[2] = 0; v[3] = 0;
-  if (HI > 1) v[0] |= (excl + cw[0]) << 16;
-  if (HI > 2) v[1] = excl + cw[1];
-  if (HI > 3) v[1] |= (excl + cw[2]) << 16;
-  if (HI > 4) v[2] = excl + cw[3];
+__device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32_t incl, const uint32_t (&cw)[HI]) {
+  const uint32_t excl = incl - cw[HI - 1];
+  const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: counts < 2^14)
+  uint32_t v[4] = {0u, 0u, 0u, 0u};
+  if (HI == 1) v[0] = incl;
+  if (HI >= 2) v[0] = (cw[0] | (cw[1] << 16)) + both;
+  if (HI == 3) v[1] = incl;
+  if (HI >= 4) v[1] = (cw[2] | (cw[3] << 16)) + both;
+  if (HI == 5) v[2] = incl;
   uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)K1_HALF_SLOT);
   if (HI > 4) *slot = make_uint4(v[0], v[1], v[2], v[3]);
   else *reinterpret_cast<uint2*>(slot) = make_uint2(v[0], v[1]);
@@ -1051,16 +1078,12 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
   uint32_t c[HI], run = 0;
 #pragma unroll
   for (int i = 0; i < HI; ++i) {
-    const unsigned long long v = bits[base + i];
-    run = (uint32_t)__builtin_popcount((uint32_t)v) + run;
-    run = (uint32_t)__builtin_popcount((uint32_t)(v >> 32)) + run;
+    run = bcnt64_acc(bits[base + i], run);
     c[i] = run;
   }
-  const uint32_t excl = half_incl_scan(run) - run;
-  half_pre_store<HI>(pre, l, excl, c);
+  half_pre_store<HI>(pre, l, half_incl_scan(run), c);
 }
 
-// ascending bitonic sort of one 32-bit value per lane across the wave (21 compare-exchange stages, no LDS)
 template <int K, int J>
 __device__ __forceinline__ uint32_t wave_sort_stage(uint32_t v, uint32_t lane) {
   const uint32_t other = lane_xor<J>(v, lane);
@@ -1637,7 +1660,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // groups (then nothing of it stays open: no pend, no merge), or a piece of ONE group that is longer than a
   // step (the open-group path of pair_step_rest).  pos = first position of the step, nact = its rows, F =
   // group-start flags of its rows, Fn = "the row after the step starts a group".
-  uint32_t dis_half = 0;  // half-wave steps: lane (h, l) counts for pair h
+  uint32_t dis_half = 0, dis_half_neg = 0;  // half-wave steps: lane (h, l) counts dis_half - dis_half_neg for pair h
   // fast tie steps: per lane, for the lane's pair (half-wave kernels: lanes >= 32 belong to the second pair)
   uint32_t seg_dis = 0, seg_neg = 0, seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
   bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
@@ -1697,16 +1720,17 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         asm volatile("" : "+v"(pre_lo_k), "+v"(word_lo_k));
 #pragma unroll
         for (int i = 0; i < H; ++i) asm volatile("" : "+v"(wv[i]));
-        dis_half += pre_lo_k + (uint32_t)__popcll(word_lo_k & low_mask64(loh & 63u)) + (sub == 0 ? inpairs : 0u);
+        // (the prefix entries are inclusive: what is subtracted is the part of the word at and above the position)
+        dis_half += pre_lo_k + (sub == 0 ? inpairs : 0u);
+        dis_half_neg = bcnt64_acc(word_lo_k >> (loh & 63u), dis_half_neg);
         // prefix of the half's bitset: lane l owns words [l*H, (l+1)*H); one aligned 16-byte store per lane
         uint32_t cw[H], run = 0;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-          run = (uint32_t)__builtin_popcount((uint32_t)wv[i]) + run;
-          run = (uint32_t)__builtin_popcount((uint32_t)(wv[i] >> 32)) + run;
+          run = bcnt64_acc(wv[i], run);
           cw[i] = run;
         }
-        half_pre_store<H>(spreH, l32, half_incl_scan(run) - run, cw);
+        half_pre_store<H>(spreH, l32, half_incl_scan(run), cw);
         wave_lds_fence();
       }
     } else {
@@ -1994,7 +2018,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   for (int k = 0; k < NP; ++k) {
     const bool mine = (NP == 1) || ((lane >= 32u) == (k == NP - 1));   // per-lane accumulators of this pair
     const unsigned long long dis = wave_sum_u64(S[k].dis) + wave_sum_u64(mine ? dis_half : 0u) +
-                                   wave_sum_u64(mine ? seg_dis : 0u) - wave_sum_u64(mine ? seg_neg : 0u) - corr[k];
+                                   wave_sum_u64(mine ? seg_dis : 0u) - wave_sum_u64(mine ? seg_neg + dis_half_neg : 0u) - corr[k];
     const unsigned long long ntie = wave_sum_u64(S[k].tie) + wave_sum_u64(mine ? seg_tie : 0u) +
                                     ((wave_sum_u64(S[k].tie2) + wave_sum_u64(mine ? seg_tie2 : 0u)) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);

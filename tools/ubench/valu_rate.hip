@@ -36,17 +36,62 @@
 #define G_MIXB "v_sub_u32_dpp %1, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\tv_sub_u32_dpp %1, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\t"
 #define G_MIXC "v_sub_u32_dpp %1, %4, %5" DPPR "v_sub_u32_dpp %2, %4, %5" DPPR "v_alignbit_b32 %0, %0, %1, 31\n\tv_alignbit_b32 %3, %3, %2, 31\n\t"
 
+#define G_ANDOR "v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_and_or_b32 %3, %3, %4, %5\n\t"
+#define G_LSHR "v_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+#define G_ADD3 "v_add3_u32 %0, %0, %4, %5\n\tv_add3_u32 %1, %1, %4, %5\n\tv_add3_u32 %2, %2, %4, %5\n\tv_add3_u32 %3, %3, %4, %5\n\t"
+#define G_PERM "v_perm_b32 %0, %0, %4, %5\n\tv_perm_b32 %1, %1, %4, %5\n\tv_perm_b32 %2, %2, %4, %5\n\tv_perm_b32 %3, %3, %4, %5\n\t"
+#define G_BFI "v_bfi_b32 %0, %0, %4, %5\n\tv_bfi_b32 %1, %1, %4, %5\n\tv_bfi_b32 %2, %2, %4, %5\n\tv_bfi_b32 %3, %3, %4, %5\n\t"
+#define G_LSHLADD "v_lshl_add_u32 %0, %0, 3, %4\n\tv_lshl_add_u32 %1, %1, 3, %4\n\tv_lshl_add_u32 %2, %2, 3, %4\n\tv_lshl_add_u32 %3, %3, 3, %4\n\t"
+#define G_CNDS "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %4, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %4, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %4, s[20:21]\n\t"
+#define G_LSHL64 "v_lshlrev_b64 v[20:21], %4, v[20:21]\n\tv_lshlrev_b64 v[22:23], %4, v[22:23]\n\t"
+#define G_MUL24 "v_mul_u32_u24 %0, %0, %4\n\tv_mul_u32_u24 %1, %1, %4\n\tv_mul_u32_u24 %2, %2, %4\n\tv_mul_u32_u24 %3, %3, %4\n\t"
+#define G_MULLO16 "v_mul_lo_u16 %0, %0, %4\n\tv_mul_lo_u16 %1, %1, %4\n\tv_mul_lo_u16 %2, %2, %4\n\tv_mul_lo_u16 %3, %3, %4\n\t"
+#define G_PL16 "v_permlane16_swap_b32 %0, %5\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %5\n\tv_permlane16_swap_b32 %3, %5\n\t"
+#define G_PL32 "v_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %5\n\tv_permlane32_swap_b32 %3, %5\n\t"
+#define G_ADDDPP "v_add_u32_dpp %0, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %1, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %2, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %3, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define G_DOT4 "v_dot4_u32_u8 %0, %4, %5, %0\n\tv_dot4_u32_u8 %1, %4, %5, %1\n\tv_dot4_u32_u8 %2, %4, %5, %2\n\tv_dot4_u32_u8 %3, %4, %5, %3\n\t"
+#define G_SAD "v_sad_u32 %0, %4, %5, %0\n\tv_sad_u32 %1, %4, %5, %1\n\tv_sad_u32 %2, %4, %5, %2\n\tv_sad_u32 %3, %4, %5, %3\n\t"
+#define G_MAD24 "v_mad_u32_u24 %0, %4, %5, %0\n\tv_mad_u32_u24 %1, %4, %5, %1\n\tv_mad_u32_u24 %2, %4, %5, %2\n\tv_mad_u32_u24 %3, %4, %5, %3\n\t"
+#define G_XOR "v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\tv_xor_b32 %2, %2, %4\n\tv_xor_b32 %3, %3, %4\n\t"
+#define G_MIXP "v_add_u32_dpp %1, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\tv_add_u32_dpp %3, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %2, 1, %2\n\tv_and_or_b32 %2, %3, %4, %2\n\t"
+#define G_MIXQ "v_add_u32_dpp %1, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %3, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_perm_b32 %1, %1, %3, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
+#define G_SBCNT "v_cmp_lt_u32_e32 vcc, %0, %4\n\ts_bcnt1_i32_b64 s20, vcc\n\ts_add_u32 s21, s21, s20\n\tv_cmp_lt_u32_e32 vcc, %1, %4\n\ts_bcnt1_i32_b64 s20, vcc\n\ts_add_u32 s21, s21, s20\n\t"
+#define G_SALU "s_add_u32 s20, s20, s21\n\ts_add_u32 s22, s22, s21\n\ts_add_u32 s23, s23, s21\n\ts_add_u32 s24, s24, s21\n\t"
+#define G_VS "v_add_u32 %0, %0, %4\n\ts_add_u32 s20, s20, s21\n\tv_add_u32 %1, %1, %4\n\ts_add_u32 s22, s22, s21\n\tv_add_u32 %2, %2, %4\n\ts_add_u32 s23, s23, s21\n\tv_add_u32 %3, %3, %4\n\ts_add_u32 s24, s24, s21\n\t"
+
 template <int V>
 __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
   uint32_t a = threadIdx.x, b = threadIdx.x * 3, c = threadIdx.x * 5, d = threadIdx.x * 7, e = 0x00010001u, f = 3;
   for (int it = 0; it < iters; ++it) {
-#define RUN(G) asm volatile(REP64(G) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc")
+#define RUN(G) asm volatile(REP64(G) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc", "s20", "s21", "s22", "s23", "s24", "v20", "v21", "v22", "v23")
     if (V == 0) RUN(G_FMA); else if (V == 1) RUN(G_ADD); else if (V == 2) RUN(G_DPP); else if (V == 3) RUN(G_DPPR);
     else if (V == 4) RUN(G_MOV); else if (V == 5) RUN(G_CMP); else if (V == 6) RUN(G_ADDC); else if (V == 7) RUN(G_PKSUB);
     else if (V == 8) RUN(G_PKADD); else if (V == 9) RUN(G_CNDM); else if (V == 10) RUN(G_BCNT); else if (V == 11) RUN(G_SUBF);
     else if (V == 12) RUN(G_ADDF); else if (V == 13) RUN(G_ADDFDPP); else if (V == 14) RUN(G_MIX1); else if (V == 15) RUN(G_MIXF);
     else if (V == 16) RUN(G_ALIGN); else if (V == 17) RUN(G_SUBDPP); else if (V == 18) RUN(G_SUBCODPP);
     else if (V == 19) RUN(G_MIXA); else if (V == 20) RUN(G_MIXB); else if (V == 21) RUN(G_MIXC);
+    else if (V == 22) RUN(G_ANDOR);
+    else if (V == 23) RUN(G_LSHR);
+    else if (V == 24) RUN(G_ADD3);
+    else if (V == 25) RUN(G_PERM);
+    else if (V == 26) RUN(G_BFI);
+    else if (V == 27) RUN(G_LSHLADD);
+    else if (V == 28) RUN(G_CNDS);
+    else if (V == 29) RUN(G_LSHL64);
+    else if (V == 30) RUN(G_MUL24);
+    else if (V == 31) RUN(G_MULLO16);
+    else if (V == 32) RUN(G_PL16);
+    else if (V == 33) RUN(G_PL32);
+    else if (V == 34) RUN(G_ADDDPP);
+    else if (V == 35) RUN(G_DOT4);
+    else if (V == 36) RUN(G_SAD);
+    else if (V == 37) RUN(G_MAD24);
+    else if (V == 38) RUN(G_XOR);
+    else if (V == 39) RUN(G_MIXP);
+    else if (V == 40) RUN(G_MIXQ);
+    else if (V == 41) RUN(G_SBCNT);
+    else if (V == 42) RUN(G_SALU);
+    else if (V == 43) RUN(G_VS);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
 }
@@ -69,6 +114,7 @@ int run(const char* name, uint32_t* d) {
 }
 
 int main() {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   uint32_t* d;
   CHK(hipMalloc(&d, 256 * 8 * 256 * 4));
   if (run<0>("v_fma_f32", d)) return 1;
@@ -93,6 +139,28 @@ int main() {
   if (run<19>("mix sub_co_dpp/addc", d)) return 1;
   if (run<20>("mix sub_dpp/alignbit", d)) return 1;
   if (run<21>("mix 2sub_dpp/2alignbit", d)) return 1;
+  if (run<22>("andor", d)) return 1;
+  if (run<23>("lshr", d)) return 1;
+  if (run<24>("add3", d)) return 1;
+  if (run<25>("perm", d)) return 1;
+  if (run<26>("bfi", d)) return 1;
+  if (run<27>("lshladd", d)) return 1;
+  if (run<28>("cnds", d)) return 1;
+  if (run<29>("lshl64", d)) return 1;
+  if (run<30>("mul24", d)) return 1;
+  if (run<31>("mullo16", d)) return 1;
+  if (run<32>("pl16", d)) return 1;
+  if (run<33>("pl32", d)) return 1;
+  if (run<34>("adddpp", d)) return 1;
+  if (run<35>("dot4", d)) return 1;
+  if (run<36>("sad", d)) return 1;
+  if (run<37>("mad24", d)) return 1;
+  if (run<38>("xor", d)) return 1;
+  if (run<39>("mixp", d)) return 1;
+  if (run<40>("mixq", d)) return 1;
+  if (run<41>("sbcnt", d)) return 1;
+  if (run<42>("salu", d)) return 1;
+  if (run<43>("vs", d)) return 1;
   if (run<0>("v_fma_f32 (again)", d)) return 1;
   return 0;
 }

@@ -94,6 +94,12 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
   asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
   return r;
 }
+// (hi << 16) | lo in one instruction (hipcc emits a shift and an OR when it can prove the operands disjoint)
+__device__ __forceinline__ uint32_t pack16(uint32_t hi, uint32_t lo) {
+  uint32_t r;
+  asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(hi), "v"(lo));
+  return r;
+}
 __device__ __forceinline__ uint32_t bcnt64_acc(unsigned long long x, uint32_t acc) {
   return bcnt_acc((uint32_t)(x >> 32), bcnt_acc((uint32_t)x, acc));
 }
@@ -855,14 +861,20 @@ __device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t
                           "v_add_u32_dpp %2, %3, %4 row_shr:" #b " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" ICIKT_PACC
 #define ICIKT_PROR2(a, b) "v_add_u32_dpp %1, %3, %4 row_ror:" #a " row_mask:0xf bank_mask:0xf\n\t" \
                           "v_add_u32_dpp %2, %3, %4 row_ror:" #b " row_mask:0xf bank_mask:0xf\n\t" ICIKT_PACC
-__device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane) {
+// byte address, for ds_bpermute, of the lane whose offer a lane reads at distance 0 between the rows: an upper
+// lane the lower row's lane at its own position, a lower lane the upper row's lane one position to the left
+__device__ __forceinline__ uint32_t half_partner_addr(uint32_t lane) {
+  const uint32_t p = lane & 15u, h = lane & 32u;
+  return ((lane & 16u) ? (h + p) : (h + 16u + ((p + 15u) & 15u))) * 4u;
+}
+__device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane, uint32_t partner_addr) {
   const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
   const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
   const uint32_t A = 0x3FFF3FFFu - Q, B = 0x40004000u + LO;
   const uint32_t offer = (lane & 16u) ? B : A;
-  const auto r = __builtin_amdgcn_permlane16_swap(offer, offer, false, false);
-  const uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[1], 0x121 /*row_ror:1*/, 0xf, 0xf, false);
-  const uint32_t xa = (lane & 16u) ? r[0] : rot;
+  // the partners' offers come through the LDS crossbar (no memory is touched): the LDS unit has slack, the vector
+  // unit has none (permlane16_swap + rotate + select were 7 issue slots)
+  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)offer);
   const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
   uint32_t v1, v2, t1, t2;
   // vector 1: the 15 in-row distances and distance 0 between the rows (8 x 4 flags: bits 0..7 of every byte)
@@ -1064,9 +1076,9 @@ __device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32
   const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: counts < 2^14)
   uint32_t v[4] = {0u, 0u, 0u, 0u};
   if (HI == 1) v[0] = incl;
-  if (HI >= 2) v[0] = (cw[0] | (cw[1] << 16)) + both;
+  if (HI >= 2) v[0] = pack16(cw[1], cw[0]) + both;
   if (HI == 3) v[1] = incl;
-  if (HI >= 4) v[1] = (cw[2] | (cw[3] << 16)) + both;
+  if (HI >= 4) v[1] = pack16(cw[3], cw[2]) + both;
   if (HI == 5) v[2] = incl;
   uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)K1_HALF_SLOT);
   if (HI > 4) *slot = make_uint4(v[0], v[1], v[2], v[3]);
@@ -1660,6 +1672,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // groups (then nothing of it stays open: no pend, no merge), or a piece of ONE group that is longer than a
   // step (the open-group path of pair_step_rest).  pos = first position of the step, nact = its rows, F =
   // group-start flags of its rows, Fn = "the row after the step starts a group".
+  const uint32_t partner_addr = half_partner_addr(lane);
   uint32_t dis_half = 0, dis_half_neg = 0;  // half-wave steps: lane (h, l) counts dis_half - dis_half_neg for pair h
   // fast tie steps: per lane, for the lane's pair (half-wave kernels: lanes >= 32 belong to the second pair)
   uint32_t seg_dis = 0, seg_neg = 0, seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
@@ -1712,7 +1725,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         unsigned long long wv[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
-        if (sub == 0) inpairs = half_step_count(sw[0], sw[1], lane);
+        if (sub == 0) inpairs = half_step_count(sw[0], sw[1], lane, partner_addr);
         // (the loaded words are consumed only behind the all-pairs block: an empty asm pins that order, or the
         //  scheduler hoists the popcounts -- and the wait for the loads -- in front of it)
         uint32_t pre_lo_k = pre_lo;
@@ -2291,7 +2304,7 @@ __global__ void k_selftest(uint32_t* out) {
   out[192 + lane] = half_count(q, lo, lane);  // summed per half by the host
   {  // the packed form of two sub-steps at once: rows (q, lo) and (q2, lo2) must give both counts together
     const uint32_t q2 = (lane * 1103515245u >> 17) & 0x27BFu, lo2 = ((lane * 69069u + 12345u) >> 5) & 0x27BFu;
-    out[576 + lane] = half_step_count(q | (lo << 16), q2 | (lo2 << 16), lane);
+    out[576 + lane] = half_step_count(q | (lo << 16), q2 | (lo2 << 16), lane, half_partner_addr(lane));
   }
   const auto sw = __builtin_amdgcn_permlane32_swap(lane, 100u + lane, false, false);
   out[256 + lane] = sw[0];                                     // lanes < 32: lane, else 100 + (lane - 32)

@@ -55,9 +55,26 @@
 #define G_XOR "v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\tv_xor_b32 %2, %2, %4\n\tv_xor_b32 %3, %3, %4\n\t"
 #define G_MIXP "v_add_u32_dpp %1, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\tv_add_u32_dpp %3, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %2, 1, %2\n\tv_and_or_b32 %2, %3, %4, %2\n\t"
 #define G_MIXQ "v_add_u32_dpp %1, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %3, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_perm_b32 %1, %1, %3, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %4, %0\n\t"
-#define G_SBCNT "v_cmp_lt_u32_e32 vcc, %0, %4\n\ts_bcnt1_i32_b64 s20, vcc\n\ts_add_u32 s21, s21, s20\n\tv_cmp_lt_u32_e32 vcc, %1, %4\n\ts_bcnt1_i32_b64 s20, vcc\n\ts_add_u32 s21, s21, s20\n\t"
-#define G_SALU "s_add_u32 s20, s20, s21\n\ts_add_u32 s22, s22, s21\n\ts_add_u32 s23, s23, s21\n\ts_add_u32 s24, s24, s21\n\t"
-#define G_VS "v_add_u32 %0, %0, %4\n\ts_add_u32 s20, s20, s21\n\tv_add_u32 %1, %1, %4\n\ts_add_u32 s22, s22, s21\n\tv_add_u32 %2, %2, %4\n\ts_add_u32 s23, s23, s21\n\tv_add_u32 %3, %3, %4\n\ts_add_u32 s24, s24, s21\n\t"
+#define G_HFHF "v_and_or_b32 %0, %0, %4, %5\n\tv_lshrrev_b32 %1, 1, %1\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+#define G_HHFF "v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+#define G_FFDEP "v_add_u32 %0, %0, %4\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %1, %1, %4\n\t"
+#define G_HFFdep "v_and_or_b32 %0, %0, %4, %5\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %1, %1, %4\n\tv_and_or_b32 %2, %2, %4, %5\n\t"
+#define G_DFF "v_add_u32_dpp %0, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_add_u32_dpp %3, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define G_BFF "v_bcnt_u32_b32 %0, %0, %4\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_bcnt_u32_b32 %3, %3, %4\n\t"
+#define G_FFFH "v_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_and_or_b32 %3, %3, %4, %5\n\t"
+#define G_H1F7 "v_and_or_b32 %0, %0, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_H1F15 "v_and_or_b32 %0, %0, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_H2F14 "v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\t"
+#define G_H4F12 "v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_and_or_b32 %3, %3, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+#define G_H8F8 "v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_and_or_b32 %3, %3, %4, %5\n\tv_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_and_or_b32 %3, %3, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+#define G_A1F7 "v_add_u32 %0, %0, %4\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_D1F15 "v_add_u32_dpp %0, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_B1F15 "v_bcnt_u32_b32 %0, %0, %4\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_C1F15 "v_cmp_lt_u32_e32 vcc, %0, %4\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_P1F15 "v_perm_b32 %0, %0, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_X1F15 "v_add3_u32 %0, %0, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_FMA1F15 "v_fma_f32 %0, %0, %4, %5\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
+#define G_L1F15 "v_lshl_add_u32 %0, %0, 3, %4\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\tv_lshrrev_b32 %3, 1, %3\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %1, 1, %1\n\tv_lshrrev_b32 %2, 1, %2\n\t"
 
 template <int V>
 __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
@@ -70,6 +87,26 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
     else if (V == 12) RUN(G_ADDF); else if (V == 13) RUN(G_ADDFDPP); else if (V == 14) RUN(G_MIX1); else if (V == 15) RUN(G_MIXF);
     else if (V == 16) RUN(G_ALIGN); else if (V == 17) RUN(G_SUBDPP); else if (V == 18) RUN(G_SUBCODPP);
     else if (V == 19) RUN(G_MIXA); else if (V == 20) RUN(G_MIXB); else if (V == 21) RUN(G_MIXC);
+    else if (V == 100) RUN(G_D1F15);
+    else if (V == 101) RUN(G_B1F15);
+    else if (V == 102) RUN(G_C1F15);
+    else if (V == 103) RUN(G_P1F15);
+    else if (V == 104) RUN(G_X1F15);
+    else if (V == 105) RUN(G_FMA1F15);
+    else if (V == 106) RUN(G_L1F15);
+    else if (V == 80) RUN(G_H1F7);
+    else if (V == 81) RUN(G_H1F15);
+    else if (V == 82) RUN(G_H2F14);
+    else if (V == 83) RUN(G_H4F12);
+    else if (V == 84) RUN(G_H8F8);
+    else if (V == 85) RUN(G_A1F7);
+    else if (V == 60) RUN(G_HFHF);
+    else if (V == 61) RUN(G_HHFF);
+    else if (V == 62) RUN(G_FFDEP);
+    else if (V == 63) RUN(G_HFFdep);
+    else if (V == 64) RUN(G_DFF);
+    else if (V == 65) RUN(G_BFF);
+    else if (V == 66) RUN(G_FFFH);
     else if (V == 22) RUN(G_ANDOR);
     else if (V == 23) RUN(G_LSHR);
     else if (V == 24) RUN(G_ADD3);
@@ -89,9 +126,6 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
     else if (V == 38) RUN(G_XOR);
     else if (V == 39) RUN(G_MIXP);
     else if (V == 40) RUN(G_MIXQ);
-    else if (V == 41) RUN(G_SBCNT);
-    else if (V == 42) RUN(G_SALU);
-    else if (V == 43) RUN(G_VS);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
 }
@@ -118,6 +152,21 @@ int main() {
   uint32_t* d;
   CHK(hipMalloc(&d, 256 * 8 * 256 * 4));
   if (run<0>("v_fma_f32", d)) return 1;
+  if (run<100>("D1F15 (per 4 of 16)", d)) return 1;
+  if (run<101>("B1F15 (per 4 of 16)", d)) return 1;
+  if (run<102>("C1F15 (per 4 of 16)", d)) return 1;
+  if (run<103>("P1F15 (per 4 of 16)", d)) return 1;
+  if (run<104>("X1F15 (per 4 of 16)", d)) return 1;
+  if (run<105>("FMA1F15 (per 4 of 16)", d)) return 1;
+  if (run<106>("L1F15 (per 4 of 16)", d)) return 1;
+
+  if (run<80>("H1F7 (per 4)", d)) return 1;
+  if (run<81>("H1F15 (per 4)", d)) return 1;
+  if (run<82>("H2F14 (per 4)", d)) return 1;
+  if (run<83>("H4F12 (per 4)", d)) return 1;
+  if (run<84>("H8F8 (per 4)", d)) return 1;
+  if (run<85>("A1F7 (per 4)", d)) return 1;
+
   if (run<1>("v_add_u32", d)) return 1;
   if (run<2>("v_mov_dpp wave_shr", d)) return 1;
   if (run<3>("v_mov_dpp row_shr", d)) return 1;
@@ -158,9 +207,13 @@ int main() {
   if (run<38>("xor", d)) return 1;
   if (run<39>("mixp", d)) return 1;
   if (run<40>("mixq", d)) return 1;
-  if (run<41>("sbcnt", d)) return 1;
-  if (run<42>("salu", d)) return 1;
-  if (run<43>("vs", d)) return 1;
+  if (run<60>("HFHF", d)) return 1;
+  if (run<61>("HHFF", d)) return 1;
+  if (run<62>("FFDEP", d)) return 1;
+  if (run<63>("HFFdep", d)) return 1;
+  if (run<64>("DFF", d)) return 1;
+  if (run<65>("BFF", d)) return 1;
+  if (run<66>("FFFH", d)) return 1;
   if (run<0>("v_fma_f32 (again)", d)) return 1;
   return 0;
 }

@@ -1317,7 +1317,7 @@ typedef __attribute__((address_space(3))) unsigned long long* lds_u64p;
 typedef __attribute__((address_space(3))) uint16_t* lds_u16p;
 // MIXED steps take groups of up to this many rows (the correction loop costs ~10 instructions per row of the
 // step's largest group); longer groups get GROUP steps of their own.  A whole wave amortises a longer loop.
-__host__ __device__ constexpr int k1_ks(bool half) { return half ? 12 : 20; }
+__host__ __device__ constexpr int k1_ks(bool half) { return half ? 16 : 20; }
 
 struct SegState {   // per-lane LDS views of the lane's pair
   lds_u64p seen, pend;
@@ -1384,6 +1384,92 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
     rebuild_prefix_half<(HI > 0 ? HI : 1)>(seen, spre, sl);
   }
   wave_lds_fence();
+  return c;
+}
+
+// MIXED step of a half-wave kernel: up to 64 rows of COMPLETE groups of at most k1_ks(true) rows, BOTH pairs.
+// Splitting "rows before my group" into "rows before me" minus "rows of my group before me" separates the work:
+//  (1) rows before me with q < lo_me: what the hot step counts -- prefix query + the packed in-step chain on two
+//      32-row sub-steps per pair -- and it does not look at the groups at all (the sub-steps need not end where
+//      groups end).  Lanes past the step's rows carry q = 0x3FFF, lo = 0: they never count, are never counted,
+//      their query is 0, and only their insertion is masked.
+//  (2) pairs inside a group, in the row layout (lane = row of the streamed column, both pairs' values in the lane):
+//      d = 1 .. largest group - 1 whole-wave shifts of X = (0x3FFF - q) | (0x4000 + lo) << 16 added to the lane's
+//      own X with its halves swapped give, in bits 15 and 31, [q_prev < lo_me] and [q_me < lo_prev]; one bit vector
+//      per pair collects them (one bit per distance).  A lane's group reaches idx rows back, so the vector masked
+//      to distances <= idx holds the lane's spurious counts (first flag) and, where neither flag is set, its joint
+//      ties: lo_prev == lo_me, because tie groups of the gathered column are disjoint ranges.
+// Per 64 rows and two pairs: the hot step + ~35 + 8 per distance instructions (round 2 before: one 32-row segment
+// per call, an unpacked all-pairs chain, ~10 instructions per distance and pair).
+template <int HI>
+__device__ __attribute__((noinline)) SegCounts half_mixed64_step(const SegState st, const unsigned long long F_in,
+                                                                 const int nact_in, const uint32_t rk0, const uint32_t rk1,
+                                                                 const uint32_t lane, const uint32_t partner_addr) {
+  constexpr int H = (HI > 0 ? HI : 1);
+  const unsigned long long F = uniform_u64(F_in);
+  const int nact = __builtin_amdgcn_readfirstlane(nact_in);
+  unsigned long long* seen = (unsigned long long*)st.seen;
+  uint16_t* spre = (uint16_t*)st.spre;
+  const uint32_t l32 = lane & 31u;
+  const bool valid = (int)lane < nact;
+  const uint32_t none = 0x00003FFFu;   // q = 0x3FFF, lo = 0
+  const uint32_t v0 = valid ? rk0 : none, v1 = valid ? rk1 : none;
+  SegCounts c;
+  c.tie2 = 0; c.cfill = 0;
+  // ---- (1) the hot step on masked rows ------------------------------------------------------------------------
+  const auto sw = __builtin_amdgcn_permlane32_swap(v0, v1, false, false);
+  uint32_t pos_cnt = half_step_count(sw[0], sw[1], lane, partner_addr), neg_cnt = 0;
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    if (sub == 1 && nact <= 32) break;   // wave-uniform
+    const uint32_t r = sub ? sw[1] : sw[0];
+    const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
+    const bool vs = (int)(l32 + 32u * (uint32_t)sub) < nact;
+    const uint32_t w = loh >> 6;
+    pos_cnt += (uint32_t)spre[half_pre_index<H>(w)];
+    neg_cnt = bcnt64_acc(seen[w] >> (loh & 63u), neg_cnt);
+    wave_lds_fence();
+    if (vs) seen_insert(seen, qh);
+    wave_lds_fence();
+    rebuild_prefix_half<H>(seen, spre, l32);
+    wave_lds_fence();
+  }
+  // ---- (2) pairs inside a group ---------------------------------------------------------------------------------
+  int dmax = 0;   // longest run of rows that continue a group = largest group - 1 (wave-uniform, from the flags)
+  {
+    unsigned long long z = ~F & ((nact >= 64) ? ~0ull : ((1ull << nact) - 1ull));
+    while (z != 0ull) { z &= z >> 1; ++dmax; }
+  }
+  uint32_t spur_tie = 0;   // row layout: pair 0's counts in bits 0..15, pair 1's in bits 16..31 (spur | tie << 8)
+  if (dmax > 0) {
+    const uint32_t X0 = 0x40003FFFu + (v0 & 0xFFFF0000u) - (v0 & 0xFFFFu);
+    const uint32_t X1 = 0x40003FFFu + (v1 & 0xFFFF0000u) - (v1 & 0xFFFFu);
+    const uint32_t Y0 = __builtin_amdgcn_alignbit(X0, X0, 16), Y1 = __builtin_amdgcn_alignbit(X1, X1, 16);
+    const uint32_t M16 = 0x80008000u;
+    uint32_t s0 = X0, s1 = X1, V0 = 0, V1 = 0;
+    for (int d = 0; d < dmax; ++d) {
+      s0 = dpp_wave_shr1(0u, s0);     // lane l now holds row l - (d + 1); no source: 0, no flag
+      s1 = dpp_wave_shr1(0u, s1);
+      V0 = (V0 >> 1) | ((s0 + Y0) & M16);
+      V1 = (V1 >> 1) | ((s1 + Y1) & M16);
+    }
+    // rows of my group before me: distance to the last group start at or before me
+    const unsigned long long upto = F & ((2ull << lane) - 1ull);
+    const uint32_t idx = valid ? (lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull))) : 0u;
+    // distance d sits at bit 15 - (dmax - d): distances 1 .. idx are bits 16 - dmax .. 15 - dmax + idx
+    const uint32_t m = ((1u << idx) - 1u) << (16 - dmax);
+    const uint32_t sp0 = (uint32_t)__builtin_popcount(V0 & m), sp1 = (uint32_t)__builtin_popcount(V1 & m);
+    const uint32_t t0 = (uint32_t)__builtin_popcount(~(V0 | (V0 >> 16)) & m);
+    const uint32_t t1 = (uint32_t)__builtin_popcount(~(V1 | (V1 >> 16)) & m);
+    spur_tie = sp0 | (t0 << 8) | (sp1 << 16) | (t1 << 24);
+  }
+  // row layout -> the lane's pair: lanes < 32 take pair 0's counts of rows l and l + 32, lanes >= 32 pair 1's
+  const auto st2 = __builtin_amdgcn_permlane32_swap(spur_tie, spur_tie, false, false);
+  const uint32_t a = (lane < 32u) ? (st2[0] & 0xFFFFu) : (st2[0] >> 16);
+  const uint32_t b = (lane < 32u) ? (st2[1] & 0xFFFFu) : (st2[1] >> 16);
+  c.dis = pos_cnt;
+  c.neg = neg_cnt + (a & 0xFFu) + (b & 0xFFu);
+  c.tie = (a >> 8) + (b >> 8);
   return c;
 }
 
@@ -1840,8 +1926,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             for (int i = 1; i < KS; ++i) r &= z >> i;            // bit i: rows i .. i + KS - 1 continue a group: > KS rows
             int s0 = 64;                                         // start of the first group the step must not take
             if (r != 0ull) s0 = 63 - (int)__builtin_clzll(Fz & ((1ull << __builtin_ctzll(r)) - 1ull));
-            if (!half_mode && avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));  // cut by the window
-            const int upper = min(lim, s0);
+            if (avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));  // cut by the window
+            const int upper = min(min(remaining, 64), s0);      // (a MIXED step of a half-wave kernel takes 64 rows too)
             nact = (upper >= 64) ? 64 : (63 - (int)__builtin_clzll(Fz & ((2ull << upper) - 1ull) & ~1ull));
             if (nact < 64) F &= (1ull << nact) - 1ull;
           }
@@ -1916,8 +2002,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       SegState st;
       const uint16_t* hbase = hiG[0];
       if (half_mode) {
-        rkS = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[0];  // [pair 0 | pair 1] of rows 0..31
-        rowS = __builtin_amdgcn_permlane32_swap(row, row, false, false)[0];           // rows 0..31 in both halves
+        if (kind != 1) {
+          rkS = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[0];  // [pair 0 | pair 1] of rows 0..31
+          rowS = __builtin_amdgcn_permlane32_swap(row, row, false, false)[0];           // rows 0..31 in both halves
+        }
         const bool hi = lane >= 32u;
         st.seen = (lds_u64p)(hi ? S[NP - 1].L.seen : S[0].L.seen);
         st.spre = (lds_u16p)(hi ? S[NP - 1].L.spre : S[0].L.spre);
@@ -1930,7 +2018,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       }
       SegCounts c;
       if (kind == 1) {
-        c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
+        if constexpr (half_mode) c = half_mixed64_step<HI>(st, F, nact, rk[0], rk[NP - 1], lane, partner_addr);
+        else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {
         // last position of the row's tie group in the gathered column
         const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hbase, rowS);

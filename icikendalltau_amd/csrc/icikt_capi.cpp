@@ -98,12 +98,12 @@ struct K1Plan {
 K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
-  // n <= 10 176 (a half wave rebuilds a prefix with <= 5 words per lane): two pairs per wave, one per half,
+  // n <= 14 272 (a half wave rebuilds a prefix with <= 7 words per lane): two pairs per wave, one per half,
   // pend in LDS.  Longer columns: one pair per wave on all 64 lanes (measured crossover between n = 10 000 and
   // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 20 waves per CU (n <~ 25 000), beyond
   // that the LDS state is what limits occupancy and pend moves to a per-wave slot in global memory (slower
   // steps when the streamed column has tie groups).
-  const bool half_ok = ((pv.Wp + 31) >> 5) <= icikt::ICIKT_HALF_ITEMS_MAX;
+  const bool half_ok = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
   int np = half_ok ? 2 : 1;
   // few pairs: when one pair per wave still fits the chip in one round (24 waves per CU), twice the waves hide
   // the latency of a step better than two pairs per wave share their loads (yeast, 4 560 pairs: 0.69 -> 0.48 ms)
@@ -127,7 +127,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
   // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
   // LDS arrays of such a kernel are padded to 32 * half_items words
-  pl.half_items = (pv.Wp + 31) >> 5;
+  pl.half_items = icikt::k1_half_items(pv.Wp);
   if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) {
     pl.opts &= ~1;
     pl.half_items = 0;

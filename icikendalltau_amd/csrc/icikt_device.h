@@ -74,8 +74,11 @@ constexpr int K1_TL_BYTES = 2048 + 256 + 256;
 // half-wave kernels: bytes of a pair's prefix slots (32 lanes x 8 x u16, one aligned 16-byte slot per lane)
 constexpr int K1_HALF_PRE = 32 * 8 * 2;
 
-// half-wave K1 kernels exist for 1..ICIKT_HALF_ITEMS_MAX words per lane of a half's prefix rebuild (n <= 10 176)
-constexpr int ICIKT_HALF_ITEMS_MAX = 5;
+// half-wave K1 kernels exist for 1..7 words per lane of a half's prefix rebuild: n <= 14 272 (the packed in-step
+// compares of those kernels need positions below 2^14; 8 words per lane put the lanes' words at a 64-byte stride,
+// an 8-way LDS bank conflict per read: measured at half the speed of one pair per wave)
+constexpr int ICIKT_HALF_ITEMS_MAX = 7;
+__host__ __device__ inline int k1_half_items(int Wp) { return (Wp + 31) >> 5; }
 
 // Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan.  The
 // arrays are padded so that the hot steps' prefix rebuilds run without predicates:

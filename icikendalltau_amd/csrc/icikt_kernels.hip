@@ -1075,11 +1075,11 @@ __device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32
   const uint32_t excl = incl - cw[HI - 1];
   const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: counts < 2^14)
   uint32_t v[4] = {0u, 0u, 0u, 0u};
-  if (HI == 1) v[0] = incl;
-  if (HI >= 2) v[0] = pack16(cw[1], cw[0]) + both;
-  if (HI == 3) v[1] = incl;
-  if (HI >= 4) v[1] = pack16(cw[3], cw[2]) + both;
-  if (HI == 5) v[2] = incl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (HI == 2 * i + 1) v[i] = incl;                                     // the lane's last word, alone in its dword
+    if (HI >= 2 * i + 2) v[i] = pack16(cw[(2 * i + 1) % HI], cw[(2 * i) % HI]) + both;
+  }
   uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)K1_HALF_SLOT);
   if (HI > 4) *slot = make_uint4(v[0], v[1], v[2], v[3]);
   else *reinterpret_cast<uint2*>(slot) = make_uint2(v[0], v[1]);
@@ -1577,7 +1577,7 @@ __device__ __attribute__((noinline)) void seg_group_close(const SegState st, con
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, bool PG, int HI>
-__global__ void __launch_bounds__(512, 6)  // 6 waves per SIMD (<= 80 VGPRs)
+__global__ void __launch_bounds__(512, (HI > 5 ? 4 : 6))  // 6 waves per SIMD (<= 80 VGPRs); HI > 5: the LDS state allows 4
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
          int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
@@ -2431,6 +2431,8 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       case 3: return &k1_pairs<2, false, 3>;
       case 4: return &k1_pairs<2, false, 4>;
       case 5: return &k1_pairs<2, false, 5>;
+      case 6: return &k1_pairs<2, false, 6>;
+      case 7: return &k1_pairs<2, false, 7>;
       default: break;
     }
   }

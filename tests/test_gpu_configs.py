@@ -142,6 +142,32 @@ def test_half_wave_five_words_per_lane(plan_ctx, n, na_frac):
             assert float(np.nanmax(np.abs(out - ref))) <= ATOL
 
 
+@pytest.mark.parametrize("n", [10177, 12224, 12225, 14000, 14272, 14273])
+def test_half_wave_six_and_seven_words_per_lane(plan_ctx, n):
+    """k1_pairs<2, false, 6> (10 177 .. 12 224 rows) and <2, false, 7> (12 225 .. 14 272 rows), and the first length
+    past them (one pair per wave): every window edge, missing values, tie groups inside and longer than a step; two pairs per wave forced, then the
+    library's own plan."""
+    rng = np.random.default_rng(n)
+    S = 8
+    X = rng.standard_normal((n, S))
+    X[:, 2] = np.round(X[:, 2] * 400)
+    X[:, 5] = np.round(X[:, 5] * 3)
+    k = n // 12
+    idx = np.argpartition(X, k, axis=0)[:k]
+    np.put_along_axis(X, idx, np.nan, axis=0)
+    X[rng.random(n) < 0.3, 7] = np.nan
+    O = _oracle()
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    for plan in ({"np": 2}, None):
+        plan_ctx.debug_set_plan(plan)
+        for perspective in ("global", "local"):
+            out, cnt, rsn = plan_ctx.pairs(X, perspective=perspective)
+            ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, perspective)
+            assert np.array_equal(rsn, rrsn)
+            assert np.array_equal(cnt, rcnt[:, :cnt.shape[1]])
+            assert float(np.nanmax(np.abs(out - ref))) <= ATOL
+
+
 def test_half_wave_five_words_natural_plan(hip_ctx):
     """10 000 x 128 = 8 128 pairs: enough pairs for the plan to choose two pairs per wave by itself."""
     from bench import make_matrix

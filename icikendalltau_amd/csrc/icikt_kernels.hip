@@ -41,14 +41,38 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
+// Whole-wave reductions as a butterfly over ds_swizzle (lane ^ 1 .. 16: the pattern is an immediate) and
+// v_permlane32_swap (lane ^ 32).  (__shfl_xor goes through ds_bpermute with one address register per distance;
+// hipcc keeps those five registers alive from the first reduction of a task to the last -- across the hot loop --
+// and spills them.  DPP scans need no addresses either, but cost three times the vector instructions.)
+template <int X>
+__device__ __forceinline__ uint32_t swz_xor(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (X << 10) | 0x1F);
+}
+__device__ __forceinline__ uint32_t xor32(uint32_t v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // [0]: lanes 0..31 twice, [1]: lanes 32..63 twice
+  return r[0] ^ r[1] ^ v;                                                // the other half's value
+}
+template <int X>
+__device__ __forceinline__ unsigned long long swz_xor64(unsigned long long v) {
+  return (unsigned long long)swz_xor<X>((uint32_t)v) | ((unsigned long long)swz_xor<X>((uint32_t)(v >> 32)) << 32);
+}
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += swz_xor64<1>(v);
+  v += swz_xor64<2>(v);
+  v += swz_xor64<4>(v);
+  v += swz_xor64<8>(v);
+  v += swz_xor64<16>(v);
+  v += (unsigned long long)xor32((uint32_t)v) | ((unsigned long long)xor32((uint32_t)(v >> 32)) << 32);
   return v;
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  v = max(v, (int)swz_xor<1>((uint32_t)v));
+  v = max(v, (int)swz_xor<2>((uint32_t)v));
+  v = max(v, (int)swz_xor<4>((uint32_t)v));
+  v = max(v, (int)swz_xor<8>((uint32_t)v));
+  v = max(v, (int)swz_xor<16>((uint32_t)v));
+  v = max(v, (int)xor32((uint32_t)v));
   return v;
 }
 
@@ -1598,7 +1622,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const int nwaves = (int)gridDim.x * wpb;
 
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
-  const uint32_t lane = lane_id();
+  // (from the exec-mask count, not from threadIdx.x: the thread id would stay live -- and spill -- to the task's end)
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
   const int items = (Wp + 63) >> 6;
   const int IT = tl_items(Wp);                              // one pair per wave: words of seen owned by a lane
@@ -1761,7 +1786,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t partner_addr = half_partner_addr(lane);
   uint32_t dis_half = 0, dis_half_neg = 0;  // half-wave steps: lane (h, l) counts dis_half - dis_half_neg for pair h
   // fast tie steps: per lane, for the lane's pair (half-wave kernels: lanes >= 32 belong to the second pair)
-  uint32_t seg_dis = 0, seg_neg = 0, seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
+  // (their counts and subtrahends go into dis_half / dis_half_neg: the same per-lane convention, two registers fewer)
+  uint32_t seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
   bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
   int pos = 0;
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
@@ -1916,8 +1942,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           constexpr int KS = k1_ks(half_mode);
           if ((F & 1ull) == 0ull || next > KS) {
             kind = 2;
-            nact = min(next, lim);
-            closes = next <= lim;
+            // (a half-wave kernel takes up to 64 rows of the group too: two 32-row pieces in one step of the ring)
+            const int glim = half_mode ? min(remaining, 64) : lim;
+            nact = min(next, glim);
+            closes = next <= glim;
           } else {
             kind = 1;
             const unsigned long long z = ~Fz;                    // rows that continue a group
@@ -1983,8 +2011,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // the gathered column -> gathered now, beside the rec values (half-wave kernels: rows 0..31 for both halves)
       hi_ok = kind != 0;
       if (hi_ok) {
+        // (lane_t: the per-lane choices of a tie step are made HERE, from a copy of the lane number the optimiser
+        //  cannot see through -- hoisted out of the loop they occupy registers across the hot loop and spill)
+        uint32_t lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
         const uint32_t rowN = half_mode ? (uint32_t)__builtin_amdgcn_permlane32_swap(r0, r0, false, false)[0] : r0;
-        const uint16_t* hb = (half_mode && lane >= 32u) ? hiG[NP - 1] : hiG[0];
+        const uint16_t* hb = (half_mode && lane_t >= 32u) ? hiG[NP - 1] : hiG[0];
         hi_pre = gload_u16(hb, rowN);
       }
     }
@@ -2001,12 +2033,14 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint32_t rkS = rk[0], rowS = row;
       SegState st;
       const uint16_t* hbase = hiG[0];
+      uint32_t lane_t = lane;
+      asm volatile("" : "+v"(lane_t));   // see above: keeps the per-lane choices below inside the tie step
       if (half_mode) {
         if (kind != 1) {
           rkS = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[0];  // [pair 0 | pair 1] of rows 0..31
           rowS = __builtin_amdgcn_permlane32_swap(row, row, false, false)[0];           // rows 0..31 in both halves
         }
-        const bool hi = lane >= 32u;
+        const bool hi = lane_t >= 32u;
         st.seen = (lds_u64p)(hi ? S[NP - 1].L.seen : S[0].L.seen);
         st.spre = (lds_u16p)(hi ? S[NP - 1].L.spre : S[0].L.spre);
         st.pend = (lds_u64p)(hi ? Pg[NP - 1].bits : Pg[0].bits);
@@ -2018,14 +2052,30 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       }
       SegCounts c;
       if (kind == 1) {
-        if constexpr (half_mode) c = half_mixed64_step<HI>(st, F, nact, rk[0], rk[NP - 1], lane, partner_addr);
+        if constexpr (half_mode) c = half_mixed64_step<HI>(st, F, nact, rk[0], rk[NP - 1], lane_t, partner_addr);
         else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {
         // last position of the row's tie group in the gathered column
         const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hbase, rowS);
-        const bool rowmode = ((half_mode && lane >= 32u) ? ntgB[NP - 1] : ntgB[0]) < 0;
-        const bool single = closes && !seg_open;        // the group starts and ends in this step
-        c = seg_group_step<SW, HI>(st, nact, single, closes, rowmode, rkS, hiA, seg_cfill, IT, magic, lane);
+        const bool rowmode = ((half_mode && lane_t >= 32u) ? ntgB[NP - 1] : ntgB[0]) < 0;
+        // a half-wave kernel takes up to 64 rows of the group: two 32-row pieces through ONE call site
+        const int npieces = (half_mode && nact > 32) ? 2 : 1;
+        const bool single = closes && !seg_open && npieces == 1;   // the group starts and ends in this step
+        uint32_t rk2 = 0, hi2 = 0;
+        if (npieces == 2) {   // rows 32 .. nact - 1: their values and tie-group ends
+          rk2 = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[1];
+          hi2 = gload_u16(hbase, __builtin_amdgcn_permlane32_swap(row, row, false, false)[1]);
+        }
+        for (int pc = 0; pc < npieces; ++pc) {
+          const bool lastp = pc == npieces - 1;
+          const int np_rows = (npieces == 2) ? (pc ? nact - 32 : 32) : nact;
+          c = seg_group_step<SW, HI>(st, np_rows, single, closes && lastp, rowmode, pc ? rk2 : rkS, pc ? hi2 : hiA,
+                                     seg_cfill, IT, magic, lane);
+          if (!lastp) {
+            dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
+            seg_cfill = c.cfill;
+          }
+        }
         seg_cfill = c.cfill;
         seg_open = !closes;
         if (closes) {
@@ -2040,7 +2090,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           if (!single || any_list) seg_group_close<SW, HI>(st, IT, lane);
         }
       }
-      seg_dis += c.dis; seg_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
+      dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
     } else {
     // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
     {
@@ -2120,7 +2170,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   for (int k = 0; k < NP; ++k) {
     const bool mine = (NP == 1) || ((lane >= 32u) == (k == NP - 1));   // per-lane accumulators of this pair
     const unsigned long long dis = wave_sum_u64(S[k].dis) + wave_sum_u64(mine ? dis_half : 0u) +
-                                   wave_sum_u64(mine ? seg_dis : 0u) - wave_sum_u64(mine ? seg_neg + dis_half_neg : 0u) - corr[k];
+                                   0ull - wave_sum_u64(mine ? dis_half_neg : 0u) - corr[k];
     const unsigned long long ntie = wave_sum_u64(S[k].tie) + wave_sum_u64(mine ? seg_tie : 0u) +
                                     ((wave_sum_u64(S[k].tie2) + wave_sum_u64(mine ? seg_tie2 : 0u)) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);

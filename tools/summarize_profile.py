@@ -60,6 +60,9 @@ if k1 and "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
           "hbm_bytes_per_launch_uncorrected": (k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024,
           "source": f"profiles/{a.tag}_pmc.md (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes)",
           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request); separate --pmc passes"}
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE"):
+        if c in k1:
+            js[c] = k1[c]
     json.dump(js, open(os.path.join(out, "k1_hbm_traffic.json"), "w"), indent=1)
     print(js)
 print("wrote", sorted(os.listdir(out)))

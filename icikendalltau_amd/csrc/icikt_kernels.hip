@@ -1341,7 +1341,7 @@ typedef __attribute__((address_space(3))) unsigned long long* lds_u64p;
 typedef __attribute__((address_space(3))) uint16_t* lds_u16p;
 // MIXED steps take groups of up to this many rows (the correction loop costs ~10 instructions per row of the
 // step's largest group); longer groups get GROUP steps of their own.  A whole wave amortises a longer loop.
-__host__ __device__ constexpr int k1_ks(bool half) { return half ? 16 : 20; }
+__host__ __device__ constexpr int k1_ks(bool half) { return half ? 32 : 20; }
 
 struct SegState {   // per-lane LDS views of the lane's pair
   lds_u64p seen, pend;
@@ -1470,21 +1470,37 @@ __device__ __attribute__((noinline)) SegCounts half_mixed64_step(const SegState 
     const uint32_t X1 = 0x40003FFFu + (v1 & 0xFFFF0000u) - (v1 & 0xFFFFu);
     const uint32_t Y0 = __builtin_amdgcn_alignbit(X0, X0, 16), Y1 = __builtin_amdgcn_alignbit(X1, X1, 16);
     const uint32_t M16 = 0x80008000u;
-    uint32_t s0 = X0, s1 = X1, V0 = 0, V1 = 0;
-    for (int d = 0; d < dmax; ++d) {
+    // one vector holds 16 distances (a 17th shift would move the upper flags into the lower half): distances
+    // 1 .. 16 in V0 / V1, 17 .. 31 in W0 / W1
+    uint32_t s0 = X0, s1 = X1, V0 = 0, V1 = 0, W0 = 0, W1 = 0;
+    const int n1 = min(dmax, 16), n2 = dmax - n1;
+    for (int d = 0; d < n1; ++d) {
       s0 = dpp_wave_shr1(0u, s0);     // lane l now holds row l - (d + 1); no source: 0, no flag
       s1 = dpp_wave_shr1(0u, s1);
       V0 = (V0 >> 1) | ((s0 + Y0) & M16);
       V1 = (V1 >> 1) | ((s1 + Y1) & M16);
     }
+    for (int d = 0; d < n2; ++d) {
+      s0 = dpp_wave_shr1(0u, s0);
+      s1 = dpp_wave_shr1(0u, s1);
+      W0 = (W0 >> 1) | ((s0 + Y0) & M16);
+      W1 = (W1 >> 1) | ((s1 + Y1) & M16);
+    }
     // rows of my group before me: distance to the last group start at or before me
     const unsigned long long upto = F & ((2ull << lane) - 1ull);
     const uint32_t idx = valid ? (lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull))) : 0u;
-    // distance d sits at bit 15 - (dmax - d): distances 1 .. idx are bits 16 - dmax .. 15 - dmax + idx
-    const uint32_t m = ((1u << idx) - 1u) << (16 - dmax);
-    const uint32_t sp0 = (uint32_t)__builtin_popcount(V0 & m), sp1 = (uint32_t)__builtin_popcount(V1 & m);
-    const uint32_t t0 = (uint32_t)__builtin_popcount(~(V0 | (V0 >> 16)) & m);
-    const uint32_t t1 = (uint32_t)__builtin_popcount(~(V1 | (V1 >> 16)) & m);
+    // in a vector of k distances, its i-th distance (1-based) sits at bit 15 - (k - i)
+    const uint32_t i1 = min(idx, 16u), i2 = idx - i1;
+    const uint32_t m = ((1u << i1) - 1u) << (16 - n1);
+    uint32_t sp0 = (uint32_t)__builtin_popcount(V0 & m), sp1 = (uint32_t)__builtin_popcount(V1 & m);
+    uint32_t t0 = (uint32_t)__builtin_popcount(~(V0 | (V0 >> 16)) & m);
+    uint32_t t1 = (uint32_t)__builtin_popcount(~(V1 | (V1 >> 16)) & m);
+    if (n2 > 0) {
+      const uint32_t m2 = ((1u << i2) - 1u) << (16 - n2);
+      sp0 += (uint32_t)__builtin_popcount(W0 & m2); sp1 += (uint32_t)__builtin_popcount(W1 & m2);
+      t0 += (uint32_t)__builtin_popcount(~(W0 | (W0 >> 16)) & m2);
+      t1 += (uint32_t)__builtin_popcount(~(W1 | (W1 >> 16)) & m2);
+    }
     spur_tie = sp0 | (t0 << 8) | (sp1 << 16) | (t1 << 24);
   }
   // row layout -> the lane's pair: lanes < 32 take pair 0's counts of rows l and l + 32, lanes >= 32 pair 1's
@@ -1950,8 +1966,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             kind = 1;
             const unsigned long long z = ~Fz;                    // rows that continue a group
             unsigned long long r = z;
+            // bit i: rows i .. i + KS - 1 continue a group: > KS rows
+            if constexpr (KS == 32) {
+              r &= r >> 1; r &= r >> 2; r &= r >> 4; r &= r >> 8; r &= r >> 16;
+            } else {
 #pragma unroll
-            for (int i = 1; i < KS; ++i) r &= z >> i;            // bit i: rows i .. i + KS - 1 continue a group: > KS rows
+              for (int i = 1; i < KS; ++i) r &= z >> i;
+            }
             int s0 = 64;                                         // start of the first group the step must not take
             if (r != 0ull) s0 = 63 - (int)__builtin_clzll(Fz & ((1ull << __builtin_ctzll(r)) - 1ull));
             if (avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));  // cut by the window
@@ -2007,9 +2028,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       rk_ok = true;
     }
     if (fast_ties) {
-      // a tie region: the next step may be a GROUP step, which needs the last position of every row's tie group in
-      // the gathered column -> gathered now, beside the rec values (half-wave kernels: rows 0..31 for both halves)
-      hi_ok = kind != 0;
+      // a GROUP step needs the last position of every row's tie group in the gathered column -> gathered one step
+      // ahead, beside the rec values (half-wave kernels: rows 0..31 for both halves)
+      hi_ok = kind == 2;   // after a GROUP step the next one is most likely a GROUP step too (MIXED steps need no ends)
       if (hi_ok) {
         // (lane_t: the per-lane choices of a tie step are made HERE, from a copy of the lane number the optimiser
         //  cannot see through -- hoisted out of the loop they occupy registers across the hot loop and spill)

@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 ATOL = 1e-10
 
 CONFIGS = {
-    "c3": dict(n_feat=10000, n_samp=256, n_na=500, seed=3, steps=20, warmup=3, cpu_sample=6000),
-    "c4": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, steps=20, warmup=3, cpu_sample=12000),
+    "c3": dict(n_feat=10000, n_samp=256, n_na=500, seed=3, steps=20, warmup=5, cpu_sample=6000),
+    "c4": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, steps=20, warmup=5, cpu_sample=12000),
     "c5": dict(n_feat=50000, n_samp=2048, n_na=1000, seed=5, steps=3, warmup=1, cpu_sample=1200),
 }
 

@@ -68,8 +68,8 @@ struct PrepView {
   uint32_t* sort_idx;             // [chunk][npow2]
 };
 
-// one pair per wave: bytes of the two-level counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32)
-constexpr int K1_TL_BYTES = 2048 + 256 + 256;
+// one pair per wave: bytes of the counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32, locg 64 x 4 x u16)
+constexpr int K1_TL_BYTES = 2048 + 256 + 256 + 512;
 
 // half-wave kernels: bytes of a pair's prefix slots (32 lanes x 8 x u16, one aligned 16-byte slot per lane)
 constexpr int K1_HALF_PRE = 32 * 8 * 2;

@@ -981,9 +981,10 @@ __device__ __forceinline__ uint32_t wave_allpairs(uint32_t q, uint32_t lo, uint3
 // of the streamed column closes) everything is recomputed once from the words (tl_rebuild).
 struct TwoLevel {
   unsigned long long* seen;
-  uint16_t* loc;    // [64][16]
+  uint16_t* loc;    // [64][4][4]: per owner and group of four words, bits in the group's words below word jj
   uint32_t* lb;     // [64]
   uint32_t* hist;   // [64], all zero between steps
+  uint16_t* locg;   // [64][4]: per owner, bits in its groups below group g
 };
 __device__ __forceinline__ TwoLevel tl_view(unsigned long long* seen, uint16_t* spre) {
   TwoLevel t;
@@ -991,9 +992,10 @@ __device__ __forceinline__ TwoLevel tl_view(unsigned long long* seen, uint16_t* 
   t.loc = spre;
   t.lb = reinterpret_cast<uint32_t*>(spre + 1024);
   t.hist = t.lb + 64;
+  t.locg = reinterpret_cast<uint16_t*>(t.hist + 64);
   return t;
 }
-constexpr int TL_BYTES = K1_TL_BYTES;  // loc + lb + hist
+constexpr int TL_BYTES = K1_TL_BYTES;  // loc + lb + hist + locg
 // words per owner: the W = Wp - 1 words that can hold bits (the guard word never does) over 64 lanes, rounded up
 // to even (two words are read at a time); <= 16 for every n <= 65 535
 __device__ __forceinline__ int tl_items(int Wp) { return ((((Wp - 1) + 63) >> 6) + 1) & ~1; }
@@ -1005,16 +1007,23 @@ __device__ __forceinline__ uint32_t tl_magic(int IT) {  // 65536 / IT + 1 for th
 }
 
 // word -> (owner, index inside the owner); magic = 65536 / IT + 1 is exact for every w < 1100, IT <= 16
+// (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
 __device__ __forceinline__ void tl_split(uint32_t w, int IT, uint32_t magic, uint32_t& o, uint32_t& j) {
-  o = (w * magic) >> 16;
-  j = w - o * (uint32_t)IT;
+  o = __umul24(w, magic) >> 16;
+  j = w - __umul24(o, (uint32_t)IT);
 }
 
+// The counters inside an owner are kept on two levels (round 2b): its <= 16 words are four groups of four, locg[o]
+// = four u16 "bits in the groups below g", loc[o][g] = four u16 "bits in the group's words below jj".  A row then
+// costs exactly two 64-bit atomic adds whatever IT is -- "+1 in all fields above f" is the constant
+// 0x0001000100010000 << 16 f (what leaves the top is the fields that do not exist) -- where one level of sixteen
+// counters cost up to four adds in a predicated loop.  A query reads one u16 more.
 __device__ __forceinline__ uint32_t tl_query(const TwoLevel& T, uint32_t pos, int IT, uint32_t magic) {
   const uint32_t w = pos >> 6;
   uint32_t o, j;
   tl_split(w, IT, magic, o, j);
-  return T.lb[o] + (uint32_t)T.loc[o * 16u + j] + (uint32_t)__popcll(T.seen[w] & low_mask64(pos & 63u));
+  const uint32_t below_group = (IT > 4) ? (uint32_t)T.locg[o * 4u + (j >> 2)] : 0u;   // one group: nothing below it
+  return T.lb[o] + below_group + (uint32_t)T.loc[o * 16u + j] + (uint32_t)__popcll(T.seen[w] & low_mask64(pos & 63u));
 }
 
 // Rows with ins == true have just been OR-ed into seen at position q (by these lanes): bring lb and loc up to date.
@@ -1022,16 +1031,11 @@ __device__ __forceinline__ uint32_t tl_query(const TwoLevel& T, uint32_t pos, in
 __device__ __forceinline__ void tl_update(const TwoLevel& T, bool ins, uint32_t q, int IT, uint32_t magic, uint32_t lane) {
   uint32_t o, j;
   tl_split((q & 0xFFFFu) >> 6, IT, magic, o, j);
-  if (ins) atomicAdd(&T.hist[o], 1u);
-  // loc: +1 in the fields above j of the owner's 16 counters
-  const uint32_t g0 = j >> 2, f = j & 3u;
-  const unsigned long long FULL = 0x0001000100010001ull;
-  const unsigned long long part = (f == 3u) ? 0ull : (FULL << (16u * (f + 1u)));
-  const int ng = (IT + 3) >> 2;
-  unsigned long long* loc64 = reinterpret_cast<unsigned long long*>(T.loc) + o * 4u;
-  for (int g = 0; g < ng; ++g) {
-    const unsigned long long v = ((uint32_t)g < g0) ? 0ull : (((uint32_t)g == g0) ? part : FULL);
-    if (ins && v != 0ull) atomicAdd(&loc64[g], v);
+  if (ins) {
+    atomicAdd(&T.hist[o], 1u);
+    const unsigned long long ABOVE = 0x0001000100010000ull;
+    atomicAdd(reinterpret_cast<unsigned long long*>(T.loc) + o * 4u + (j >> 2), ABOVE << (16u * (j & 3u)));
+    if (IT > 4) atomicAdd(reinterpret_cast<unsigned long long*>(T.locg) + o, ABOVE << (16u * (j >> 2)));
   }
   wave_lds_fence();
   const uint32_t h = atomicExch(&T.hist[lane], 0u);
@@ -1039,13 +1043,14 @@ __device__ __forceinline__ void tl_update(const TwoLevel& T, bool ins, uint32_t 
   if (below != 0u) atomicAdd(&T.lb[lane], below);
 }
 
-// Recompute loc and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
+// Recompute loc, locg and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
 template <bool PG>
 __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge_from, int IT, uint32_t lane) {
   const uint32_t base = lane * (uint32_t)IT;
   ulonglong2* b2 = reinterpret_cast<ulonglong2*>(T.seen + base);
   uint32_t* l32 = reinterpret_cast<uint32_t*>(T.loc + lane * 16u);
-  uint32_t run = 0;
+  uint32_t run = 0, grun = 0;          // bits in the owner's words so far; of them, in the groups before this one
+  unsigned long long gpack = 0ull;     // locg[lane]: four u16
   for (int i = 0; i < (IT >> 1); ++i) {
     ulonglong2 v = b2[i];
     if (merge_from) {
@@ -1056,12 +1061,19 @@ __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge
       p_st<PG>(*merge_from, w, 0ull);
       p_st<PG>(*merge_from, w + 1, 0ull);
     }
-    const uint32_t c0 = run;
+    if ((i & 1) == 0) {  // words 2i, 2i+1 open group i / 2
+      grun = run;
+      gpack |= (unsigned long long)grun << (16 * (i >> 1));
+    }
+    const uint32_t c0 = run - grun;
     run += (uint32_t)__popcll(v.x);
-    const uint32_t c1 = run;
+    const uint32_t c1 = run - grun;
     run += (uint32_t)__popcll(v.y);
     l32[i] = c0 | (c1 << 16);
   }
+  for (int i = (IT >> 1); i < 8; ++i)   // groups past the owner's words: everything is below them
+    if ((i & 1) == 0) gpack |= (unsigned long long)run << (16 * (i >> 1));
+  reinterpret_cast<unsigned long long*>(T.locg)[lane] = gpack;
   T.lb[lane] = wave_incl_scan(run) - run;
 }
 

@@ -105,9 +105,11 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // steps when the streamed column has tie groups).
   const bool half_ok = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
   int np = half_ok ? 2 : 1;
-  // few pairs: when one pair per wave still fits the chip in one round (24 waves per CU), twice the waves hide
-  // the latency of a step better than two pairs per wave share their loads (yeast, 4 560 pairs: 0.69 -> 0.48 ms)
-  if (n_pairs <= (int64_t)24 * n_cu) np = 1;
+  // few pairs: twice the waves hide the latency of a step better than two pairs per wave share their loads while
+  // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
+  // 2 016 pairs, 0.255 vs 0.267 ms, two pairs per wave from 3 160 pairs on, 0.299 vs 0.350 ms; all 4 560 pairs:
+  // 0.352 vs 0.419 ms)
+  if (n_pairs <= (int64_t)10 * n_cu) np = 1;
   {
     const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2) + icikt::K1_TL_BYTES;  // seen, pend, ppre + counts
     pl.pend_global = !half_ok && full * 20 > lds_cap;

@@ -7,10 +7,14 @@ from icikendalltau_amd import _lib
 z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "yeast_missing.npz"))
 X = np.asfortranarray(z[z.files[0]].astype(np.float64))
 X[X == 0] = np.nan
+if len(sys.argv) > 2:
+    X = np.asfortranarray(X[:, :int(sys.argv[2])])   # fewer columns: fewer pairs
 n, S = X.shape
 nd = [len(np.unique(X[~np.isnan(X[:, c]), c])) for c in range(S)]
 print(f"yeast {n} x {S}: missing per column {np.isnan(X).sum(0).min()}..{np.isnan(X).sum(0).max()}, distinct values per column {min(nd)}..{max(nd)}")
 ctx = _lib.Context(0)
+if len(sys.argv) > 1:
+    ctx.debug_set_plan(sys.argv[1])   # e.g. "np=2"
 dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
 P = S * (S - 1) // 2
 ctx.set_pairs_combn(S, 0, P)

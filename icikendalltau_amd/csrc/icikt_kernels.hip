@@ -400,101 +400,77 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   }
 
   // ---- phase 3: tie groups in ascending order -----------------------------------------------------
-  // Group starts as a bitset in LDS, computed once with coalesced loads: bit k = "position k starts a tie group".
-  // The per-thread loops below walk short runs of CONSECUTIVE positions, i.e. the lanes of a wave read the sorted
-  // keys at a stride of 8 CH bytes, and they did so three times per position and pass (keys[k - 1], keys[k],
-  // keys[k + 1]): K0 without its sort was 0.44 of 1.03 ms on c4.  Bit n is set (the position after the last one
-  // starts a group), so "position k ends a group" is bit k + 1.
+  // Group starts as a bitset in LDS, computed once with coalesced loads: bit k = "position k starts a tie group";
+  // bit n is set (the position after the last one starts a group), so "position k ends a group" is bit k + 1.
+  // Every position then finds its group by two bit scans of that set -- first position `lo` = the last start at or
+  // before it, last position `hi` = the next start - 1 -- and thread t takes positions t, t + 1024, ...: every
+  // global access of the phase is coalesced except the writes by ROW (rec through the LDS tile, hirow).  Round 2a
+  // gave each thread a run of consecutive positions: the lanes of a wave then read keys and row indices at a
+  // stride of 8 n / 1024 bytes, three key loads per position and pass, and carried the open group from thread to
+  // thread with two 1 024-wide LDS scans (K0 without its sort: 0.44 of 1.03 ms on c4).
   for (int base = 0; base <= ((n >> 6) << 6); base += K0_THREADS) {
     const int k = base + tid;
     const bool st = (k <= n) && (k == 0 || k == n || keys[k - 1] != keys[k]);
     const unsigned long long b = __ballot(st);
     if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
   }
-  __syncthreads();
-  auto is_start = [&](int k) -> bool { return (sh_st[k >> 6] >> (k & 63)) & 1ull; };   // 0 <= k <= n
-  // thread t owns positions [k0, k1)
-  const int CH = (n + K0_THREADS - 1) / K0_THREADS;
-  const int k0 = min(n, tid * CH);
-  const int k1 = min(n, k0 + CH);
-  // last group start at or before the end of my chunk / first group end at or after its start
-  int last_start = -1;
-  int first_end = 0x7FFFFFFF;
-  for (int k = k0; k < k1; ++k) {
-    const bool st = is_start(k);
-    const bool en = is_start(k + 1);
-    if (st) last_start = k;
-    if (en && first_end == 0x7FFFFFFF) first_end = k;
-  }
-  // exclusive max-scan of last_start over threads (Hillis-Steele in LDS)
-  sh_i[tid] = last_start;
-  __syncthreads();
-  for (int s = 1; s < K0_THREADS; s <<= 1) {
-    int v = sh_i[tid];
-    int o = (tid >= s) ? sh_i[tid - s] : -1;
-    __syncthreads();
-    sh_i[tid] = max(v, o);
-    __syncthreads();
-  }
-  int run_lo = (tid > 0) ? sh_i[tid - 1] : -1;
-  __syncthreads();
-  // exclusive reverse min-scan of first_end
-  sh_i[tid] = first_end;
-  __syncthreads();
-  for (int s = 1; s < K0_THREADS; s <<= 1) {
-    int v = sh_i[tid];
-    int o = (tid + s < K0_THREADS) ? sh_i[tid + s] : 0x7FFFFFFF;
-    __syncthreads();
-    sh_i[tid] = min(v, o);
-    __syncthreads();
-  }
-  const int next_end = (tid + 1 < K0_THREADS) ? sh_i[tid + 1] : 0x7FFFFFFF;
-  __syncthreads();
-
-  for (int w = tid; w < 1024; w += K0_THREADS) sh_bits[w] = 0ull;
+  unsigned long long* sh_big = reinterpret_cast<unsigned long long*>(sh_ll);  // bit k: a group of >= 2 rows starts at k
+  for (int w = tid; w < 1024; w += K0_THREADS) { sh_bits[w] = 0ull; sh_big[w] = 0ull; }
   for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) order[k] = 0;  // zero padding: K1 prefetches one step ahead
   __syncthreads();
+  auto is_start = [&](int k) -> bool { return (sh_st[k >> 6] >> (k & 63)) & 1ull; };   // 0 <= k <= n
+  auto prev_start = [&](int k) -> int {   // last start at or before k (bit 0 is set)
+    int w = k >> 6;
+    unsigned long long m = sh_st[w] & (~0ull >> (63 - (k & 63)));
+    while (m == 0ull) m = sh_st[--w];
+    return (w << 6) + 63 - (int)__builtin_clzll(m);
+  };
+  auto next_start = [&](int k) -> int {   // first start after k (bit n is set)
+    const int q = k + 1;
+    int w = q >> 6;
+    unsigned long long m = sh_st[w] & (~0ull << (q & 63));
+    while (m == 0ull) m = sh_st[++w];
+    return (w << 6) + (int)__builtin_ctzll(m);
+  };
 
-  // per-thread tie statistics over the groups that START in my chunk
+  // per-thread tie statistics over the groups that START at my positions
   int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
   long long e0 = 0, e1 = 0, e2 = 0;     // exact
-  {  // backward sweep: last position of each row's tie group
-    int cur_hi = next_end;
-    for (int k = k1 - 1; k >= k0; --k) {
-      if (is_start(k + 1)) cur_hi = k;
-      hirow[idx[k]] = (uint16_t)cur_hi;
-    }
-  }
-  for (int k = k0; k < k1; ++k) {
-    const bool st = is_start(k);
-    if (st) run_lo = k;
-    const int lo = run_lo;
-    const uint32_t row = idx[k];
-    const int hi = (int)hirow[row];  // written by this thread above
-    // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
-    if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
-    else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
-    order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
-    if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
-    if (st) {
-      const int t = hi - lo + 1;
-      ++ngroups;
-      if (t >= 2) ++ntg_local;
-      maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
-      if (lo == 0) tfill = t;
-      if (t >= 2) {
-        const uint32_t ut = (uint32_t)t;
-        const uint32_t tt1 = ut * (ut - 1u);
-        s0 += tt1;
-        s1 += tt1 * (ut - 2u);
-        s2 += tt1 * (2u * ut + 5u);
-        const long long lt = t;
-        e0 += lt * (lt - 1);
-        e1 += lt * (lt - 1) * (lt - 2);
-        e2 += lt * (lt - 1) * (2 * lt + 5);
+  for (int base = 0; base < n; base += K0_THREADS) {
+    const int k = base + tid;
+    bool big = false;
+    if (k < n) {
+      const int lo = prev_start(k), hi = next_start(k) - 1;
+      const uint32_t row = idx[k];
+      hirow[row] = (uint16_t)hi;
+      // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
+      if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
+      else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
+      order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
+      if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
+      if (lo == k) {
+        const int t = hi - lo + 1;
+        ++ngroups;
+        big = t >= 2;
+        maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
+        if (lo == 0) tfill = t;
+        if (t >= 2) {
+          ++ntg_local;
+          const uint32_t ut = (uint32_t)t;
+          const uint32_t tt1 = ut * (ut - 1u);
+          s0 += tt1;
+          s1 += tt1 * (ut - 2u);
+          s2 += tt1 * (2u * ut + 5u);
+          const long long lt = t;
+          e0 += lt * (lt - 1);
+          e1 += lt * (lt - 1) * (lt - 2);
+          e2 += lt * (lt - 1) * (2 * lt + 5);
+        }
       }
     }
+    const unsigned long long bb = __ballot(big);
+    if (lane == 0 && (k >> 6) < 1024) sh_big[k >> 6] = bb;
   }
   __syncthreads();
   if (stage_rec) {
@@ -516,9 +492,12 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
 
   // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
-  // tie group of the OTHER column that spans several steps once, when that group closes
+  // tie group of the OTHER column that spans several steps once, when that group closes.  A group's place in the
+  // list = the groups of >= 2 rows that start before it: a prefix over the words of sh_big.
   {
-    sh_i[tid] = ntg_local;
+    const int nw = (n + 63) >> 6;                  // <= 1024 words, one per thread
+    const int cnt = (tid < nw) ? (int)__popcll(sh_big[tid]) : 0;
+    sh_i[tid] = cnt;
     __syncthreads();
     for (int sft = 1; sft < K0_THREADS; sft <<= 1) {
       const int v = sh_i[tid];
@@ -527,14 +506,16 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
       sh_i[tid] = v + o;
       __syncthreads();
     }
-    int off = sh_i[tid] - ntg_local;
-    __syncthreads();
-    for (int k = k0; k < k1; ++k) {
-      if (is_start(k)) {
-        const int hi = (int)hirow[idx[k]];
-        if (hi > k) tgl[off++] = (uint32_t)k | ((uint32_t)hi << 16);
+    if (tid < nw) {
+      int off = sh_i[tid] - cnt;
+      unsigned long long m = sh_big[tid];
+      while (m != 0ull) {
+        const int k = (tid << 6) + (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        tgl[off++] = (uint32_t)k | ((uint32_t)(next_start(k) - 1) << 16);
       }
     }
+    __syncthreads();
   }
   const int ntg = block_reduce<int>(ntg_local, sh_i, [](int a, int b) { return a + b; });
   ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });

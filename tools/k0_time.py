@@ -1,0 +1,15 @@
+"""K0 (the per-column pre-pass) alone on the c4 and c3 matrices: device-resident timing (development aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from icikendalltau_amd import _lib
+from bench import make_matrix
+for (n, S, na, seed) in ((10000, 1024, 1000, 4), (10000, 256, 500, 3), (50000, 512, 1000, 5)):
+    X = make_matrix(n, S, na, seed)
+    ctx = _lib.Context(0)
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    ts = []
+    for _ in range(6):
+        ctx.reset_timers(); ctx.prepare_dev(dX.data_ptr(), n, S, n, _lib.FLAG_TIMING); ctx.sync()
+        ts.append(ctx.kernel_ms(_lib.K_PREPARE)[0])
+    print(n, S, "K0 ms", " ".join("%.3f" % t for t in ts), flush=True)

@@ -62,6 +62,7 @@ struct icikt_ctx {
   DevBuf<uint32_t> d_pend_pre;
   DevBuf<int> d_task_ctr;  // persistent pair kernel: one task counter per XCD group, zeroed before every launch
   std::vector<int32_t> h_pi, h_pj, h_units;
+  bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
   hipStream_t copy_stream = nullptr;
@@ -114,8 +115,10 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
 int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end);
 // Host matrix -> device (columns [col_begin, col_end) only) overlapped with K0 by column chunks; the device copy
 // keeps the full n_feat x n_samp layout (leading dimension n_feat) in c->d_X.  prepare_alloc() must have run.
+// deferred_unregister (optional): when the source was page-locked for the call, do not wait for the copies; the
+// caller synchronises c->copy_stream and calls hipHostUnregister(*deferred_unregister) itself.
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags);
+                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr);
 // D2H of a result array into a pageable host buffer on c->stream (not synchronised)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 

@@ -741,6 +741,17 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
   return timer_end(c, ICIKT_K_PREPARE, flags);
 }
 
+// The pair kernel's task list for the prepared shape and the current pair list, built on the host now (while
+// copies and the pre-pass run) instead of inside icikt_run_dev, which then only uploads it.
+void prebuild_units(icikt_ctx* c) {
+  if (c->n_pairs <= 0) return;
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  if (c->wpb != pl.np) {
+    build_units(c, pl.np);
+    c->units_dirty = true;
+  }
+}
+
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -808,13 +819,7 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
     if (e0 != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(e0));
     return ICIKT_SUCCESS;
   }
-  {
-    const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
-    if (c->wpb != pl.np) {   // host work under the copies; icikt_run_dev uploads the list
-      build_units(c, pl.np);
-      c->units_dirty = true;
-    }
-  }
+  icikt::host::prebuild_units(c);   // host work under the copies; icikt_run_dev uploads the list
   auto body = [&]() -> int {
     HIPCHK(c, c->d_out4.reserve((size_t)P * 4));
     if (counts) HIPCHK(c, c->d_counts.reserve((size_t)P * ICIKT_CNT_FIELDS));

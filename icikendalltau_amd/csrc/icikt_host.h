@@ -119,6 +119,8 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
 // caller synchronises c->copy_stream and calls hipHostUnregister(*deferred_unregister) itself.
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
                        int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr);
+// Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).
+void prebuild_units(icikt_ctx* c);
 // D2H of a result array into a pageable host buffer on c->stream (not synchronised)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 

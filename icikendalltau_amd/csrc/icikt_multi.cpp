@@ -194,6 +194,7 @@ void rank_main(Call& a, int r) {
     else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
     RANKCHK(icikt::host::prepare_alloc(c, a.n_feat, S, a.alloc_cols, std::max<int64_t>(c1 - c0, 1)));
     RANKCHK(icikt::host::upload_and_prepare(c, a.X, a.n_feat, S, a.ld, c0, c1, a.flags & ~ICIKT_FLAG_TIMING));
+    icikt::host::prebuild_units(c);   // the task list of this rank's pair block, while its columns are copied
     RANKCHK_HIP(c->d_out4.reserve((size_t)std::max<int64_t>(a.n_each, 1) * 4));
     if (a.counts) RANKCHK_HIP(c->d_counts.reserve((size_t)std::max<int64_t>(a.n_each, 1) * ICIKT_CNT_FIELDS));
     if (a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));

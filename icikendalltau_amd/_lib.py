@@ -29,7 +29,8 @@ FLAG_TIMING = 2
 FLAG_REUSE_COUNTS = 4
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
-MAX_FEATURES = 65535
+MAX_FEATURES = 65535          # the tuned kernels
+MAX_FEATURES_WIDE = 262144    # the plain 32-bit path (exact integer arithmetic)
 PREP_ARRAYS = 5  # order, rec, hirow, meta (bitsets + stats per column), tgroups
 PREP_EXCHANGE = (0, 3)  # order and meta: the rest is rebuilt by expand_cols_dev()
 

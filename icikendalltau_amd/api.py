@@ -157,7 +157,9 @@ def ici_kt(x, y, perspective="local", alternative="two.sided", continuity=False,
     Same defaults as the reference (src/kendallc.cpp:166).  Any ``output`` other than "simple" prints the
     reference's report (src/kendallc.cpp:342-363: same labels, ``std::to_string`` formatting) from the counts
     record of the pair; ``ici_kt_counts`` returns those integers instead of printing them.
-    Vectors longer than 65 535 (``_lib.MAX_FEATURES``) are refused with an error that names the limit.
+    Vectors of up to 65 535 rows (``_lib.MAX_FEATURES``) run the tuned kernels; up to 262 144
+    (``_lib.MAX_FEATURES_WIDE``) a plain 32-bit path in exact integer arithmetic; longer ones are refused with an
+    error that names the limit.
     """
     x = np.asarray(x, dtype=np.float64).ravel()
     y = np.asarray(y, dtype=np.float64).ravel()

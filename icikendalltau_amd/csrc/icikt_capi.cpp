@@ -284,7 +284,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
-  c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release();
+  c->tgroups.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -334,16 +334,22 @@ int icikt_sync(icikt_ctx* c) {
 // Shared body of icikt_prepare_dev / icikt_prepare_cols_dev: allocate the prepared state for alloc_cols
 // columns and run the pre-pass over columns [col_begin, col_end).
 static const char* const kTooLong =
-    "n_feat exceeds ICIKT_MAX_FEATURES (65535 rows per column: positions are 16-bit; the reference's own "
-    "`int dis`, src/kendallc.cpp:78, is only safe to about that length)";
+    "n_feat exceeds ICIKT_MAX_FEATURES_WIDE (262144 rows per column; the tuned kernels take up to 65535, the plain "
+    "32-bit path up to 262144 -- its bitsets must fit the LDS of a CU)";
+static const char* const kNoWide =
+    "n_feat exceeds ICIKT_MAX_FEATURES (65535 rows per column): this entry has no path for wide columns";
 
-static int check_shape(icikt_ctx* c, const char* who, int64_t n_feat, int64_t n_samp, int64_t ld) {
+static int check_shape(icikt_ctx* c, const char* who, int64_t n_feat, int64_t n_samp, int64_t ld, bool wide_ok = true) {
   if (n_feat < 0 || n_samp < 0 || ld < n_feat) return fail(c, ICIKT_E_INVALID, std::string(who) + ": bad matrix shape");
-  if (n_feat > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, std::string(who) + ": " + kTooLong);
+  if (n_feat > ICIKT_MAX_FEATURES_WIDE) return fail(c, ICIKT_E_TOO_LONG, std::string(who) + ": " + kTooLong);
+  if (n_feat > ICIKT_MAX_FEATURES && !wide_ok) return fail(c, ICIKT_E_TOO_LONG, std::string(who) + ": " + kNoWide);
   return ICIKT_SUCCESS;
 }
 
-static int check_col_range(icikt_ctx* c, int64_t n_samp, int64_t col_begin, int64_t col_end, int64_t alloc_cols) {
+static int check_col_range(icikt_ctx* c, int64_t n_samp, int64_t col_begin, int64_t col_end, int64_t alloc_cols,
+                           int64_t n_feat = 0) {
+  if (n_feat > ICIKT_MAX_FEATURES && (col_begin != 0 || col_end != n_samp))   // the sharded pre-pass exchanges 16-bit arrays
+    return fail(c, ICIKT_E_TOO_LONG, std::string("prepare (column range): ") + kNoWide);
   if (col_begin < 0 || col_end < col_begin || col_end > n_samp || alloc_cols < n_samp)
     return fail(c, ICIKT_E_INVALID, "prepare: bad column range");
   // rec is interleaved in blocks of two columns: a column range is contiguous memory only on even boundaries
@@ -372,15 +378,26 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   const size_t S = (size_t)std::max<int64_t>(alloc_cols, 1);
   const size_t ncols = (size_t)std::max<int64_t>(sort_cols, 1);
 
-  HIPCHK(c, c->order.reserve(S * pv.n_ord));
-  HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
-  HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
+  pv.wide = n_feat > ICIKT_MAX_FEATURES ? 1 : 0;
   pv.mstride = 3 * pv.Wp + (int)(sizeof(ColStats) / 8);
   HIPCHK(c, c->meta.reserve(S * (size_t)pv.mstride));
   pv.tg_stride = pv.n_pad / 2 + 1;
-  HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
   // sort scratch: bounded to ~1 GiB
   size_t chunk = std::min<size_t>(ncols, std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)np2 * 12)));
+  if (pv.wide) {
+    // 32-bit positions in four separate arrays; the 16-bit arrays of the tuned kernels are not needed
+    HIPCHK(c, c->wide32.reserve(4 * S * (size_t)pv.n_pad));
+    HIPCHK(c, c->k0_bits.reserve(chunk * 2 * (size_t)(pv.Wp + 1)));
+    HIPCHK(c, c->order.reserve(1));
+    HIPCHK(c, c->hirow.reserve(1));
+    HIPCHK(c, c->rec.reserve(2));
+    HIPCHK(c, c->tgroups.reserve(1));
+  } else {
+    HIPCHK(c, c->order.reserve(S * pv.n_ord));
+    HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
+    HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
+    HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
+  }
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
   c->sort_chunk = (int)chunk;
@@ -389,6 +406,13 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   pv.meta = c->meta.p;
   pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;
+  if (pv.wide) {
+    pv.order32 = c->wide32.p;
+    pv.q32 = pv.order32 + S * (size_t)pv.n_pad;
+    pv.lo32 = pv.q32 + S * (size_t)pv.n_pad;
+    pv.hi32 = pv.lo32 + S * (size_t)pv.n_pad;
+    pv.k0_bits = c->k0_bits.p;
+  }
   c->pv = pv;
   c->alloc_cols = (int64_t)S;
   return ICIKT_SUCCESS;
@@ -422,7 +446,7 @@ static int prepare_impl(icikt_ctx* c, const double* dX, int64_t n_feat, int64_t 
   int rc = check_shape(c, "prepare", n_feat, n_samp, ld);
   if (rc) return rc;
   if (n_samp > 0 && n_feat > 0 && !dX) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
-  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols);
+  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols, n_feat);
   if (rc) return rc;
   rc = use_device(c);
   if (rc) return rc;
@@ -455,7 +479,7 @@ int icikt_prepare_cols_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_
   int rc = check_shape(c, "prepare", n_feat, n_samp, ld);
   if (rc) return rc;
   if (n_samp > 0 && n_feat > 0 && !X) return fail(c, ICIKT_E_INVALID, "prepare: null matrix");
-  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols);
+  rc = check_col_range(c, n_samp, col_begin, col_end, alloc_cols, n_feat);
   if (rc) return rc;
   rc = use_device(c);
   if (rc) return rc;
@@ -472,6 +496,7 @@ int icikt_expand_cols_dev(icikt_ctx* c, int64_t col_begin, int64_t col_end, uint
   if (!c->prepared) return fail(c, ICIKT_E_STATE, "expand_cols: nothing prepared");
   if (col_begin < 0 || col_end < col_begin || col_end > c->pv.n_samp)
     return fail(c, ICIKT_E_INVALID, "expand_cols: bad column range");
+  if (c->pv.wide) return fail(c, ICIKT_E_TOO_LONG, std::string("expand_cols: ") + kNoWide);
   int rc = use_device(c);
   if (rc) return rc;
   c->raw_valid = false;
@@ -484,6 +509,7 @@ int icikt_expand_cols_dev(icikt_ctx* c, int64_t col_begin, int64_t col_end, uint
 int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
   if (!c || !ptrs || !bytes_per_col) return ICIKT_E_INVALID;
   if (!c->prepared) return fail(c, ICIKT_E_STATE, "prep_arrays: nothing prepared");
+  if (c->pv.wide) return fail(c, ICIKT_E_TOO_LONG, std::string("prep_arrays: ") + kNoWide);
   const PrepView& pv = c->pv;
   ptrs[0] = pv.order;    bytes_per_col[0] = (int64_t)pv.n_ord * 2;
   ptrs[1] = pv.rec;      bytes_per_col[1] = (int64_t)pv.n_pad * 4;
@@ -569,6 +595,35 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   if (rc) return rc;
   if (c->n_pairs == 0) return ICIKT_SUCCESS;
 
+  if (c->pv.wide) {
+    // wide columns: the plain 32-bit pair kernel (one wave per pair, persistent single-wave workgroups that fetch
+    // pairs from a counter), exact integer arithmetic in the epilogue
+    const bool reuse_w = (flags & ICIKT_FLAG_REUSE_COUNTS) && c->raw_valid;
+    if (c->pv.n > 0 && !reuse_w) {
+      rc = timer_begin(c, ICIKT_K_PAIRS, flags);
+      if (rc) return rc;
+      const size_t lds = icikt::k1_wide_lds_bytes(c->pv.Wp);
+      int per_cu = 0;
+      HIPCHK(c, icikt::k1_wide_blocks_per_cu(lds, &per_cu));
+      if (per_cu < 1) return fail(c, ICIKT_E_HIP, "run: the wide pair kernel does not fit a CU");
+      const int blocks = (int)std::min<int64_t>(c->n_pairs, (int64_t)per_cu * c->prop.multiProcessorCount);
+      HIPCHK(c, c->d_task_ctr.reserve(8));
+      HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
+      if (c->plan_ov.verbose)
+        fprintf(stderr, "[icikt] K1 wide: lds=%zu B/wave, %d waves/CU, grid=%d, pairs=%lld\n", lds, per_cu, blocks,
+                (long long)c->n_pairs);
+      HIPCHK(c, icikt::launch_k1_wide(c->pv, c->d_pi.p, c->d_pj.p, c->d_raw.p, c->n_pairs, blocks, lds, c->d_task_ctr.p,
+                                      c->stream));
+      rc = timer_end(c, ICIKT_K_PAIRS, flags);
+      if (rc) return rc;
+      c->raw_valid = true;
+    }
+    rc = timer_begin(c, ICIKT_K_EPILOGUE, flags);
+    if (rc) return rc;
+    HIPCHK(c, icikt::launch_k2(c->pv, c->d_pi.p, c->d_pj.p, c->d_raw.p, c->n_pairs, perspective, alternative,
+                               continuity ? 1 : 0, /*exact64=*/1, d_out4, d_counts, d_reasons, c->stream));
+    return timer_end(c, ICIKT_K_EPILOGUE, flags);
+  }
   const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
   if (c->wpb != pl.np) {
     build_units(c, pl.np);
@@ -744,7 +799,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
 // The pair kernel's task list for the prepared shape and the current pair list, built on the host now (while
 // copies and the pre-pass run) instead of inside icikt_run_dev, which then only uploads it.
 void prebuild_units(icikt_ctx* c) {
-  if (c->n_pairs <= 0) return;
+  if (c->n_pairs <= 0 || c->pv.wide) return;
   const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
   if (c->wpb != pl.np) {
     build_units(c, pl.np);
@@ -848,7 +903,7 @@ int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int6
                              const int32_t* pi, const int32_t* pj, int64_t n_pairs, int alternative, int continuity,
                              uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
   if (!c) return ICIKT_E_INVALID;
-  int rc = check_shape(c, "pairs_complete", n_feat, n_samp, ld);
+  int rc = check_shape(c, "pairs_complete", n_feat, n_samp, ld, /*wide_ok=*/false);
   if (rc) return rc;
   if (n_feat > 0 && n_samp > 0 && !X) return fail(c, ICIKT_E_INVALID, "pairs_complete: null matrix");
   rc = check_pair_list(c, "pairs_complete", pi, pj, n_pairs, n_samp);
@@ -915,7 +970,7 @@ int icikt_pair_f64(icikt_ctx* c, const double* x, const double* y, int64_t n, in
                    int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reason) {
   if (!c) return ICIKT_E_INVALID;
   if (n < 0 || (n > 0 && (!x || !y))) return fail(c, ICIKT_E_INVALID, "pair: bad vectors");
-  if (n > ICIKT_MAX_FEATURES) return fail(c, ICIKT_E_TOO_LONG, std::string("pair: ") + kTooLong);
+  if (n > ICIKT_MAX_FEATURES_WIDE) return fail(c, ICIKT_E_TOO_LONG, std::string("pair: ") + kTooLong);
   std::vector<double> xy;
   try {
     xy.resize((size_t)std::max<int64_t>(2 * n, 1));

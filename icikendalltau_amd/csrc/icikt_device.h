@@ -66,6 +66,14 @@ struct PrepView {
   // sort scratch (per column of the current chunk)
   unsigned long long* sort_keys;  // [chunk][npow2]
   uint32_t* sort_idx;             // [chunk][npow2]
+  // ---- wide columns (65 535 < n <= ICIKT_MAX_FEATURES_WIDE): 32-bit positions, separate arrays, a plain pair
+  // kernel (k1_wide).  order / rec / hirow / tgroups are not allocated then.
+  int wide;
+  uint32_t* order32;              // [S][n_pad]  row at processing position k (descending value)
+  uint32_t* q32;                  // [S][n_pad]  per row: ascending stable position
+  uint32_t* lo32;                 // [S][n_pad]  per row: first position of its tie group
+  uint32_t* hi32;                 // [S][n_pad]  per row: last position of its tie group
+  unsigned long long* k0_bits;    // [chunk][2][Wp + 1]  K0's group-start and fill bitsets (LDS holds them up to 65 535 rows)
 };
 
 // one pair per wave: bytes of the counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32, locg 64 x 4 x u16)
@@ -91,6 +99,11 @@ __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
 }
 
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
+// wide columns: one wave per pair, grid of `blocks` single-wave workgroups that fetch pairs from *task_ctr
+hipError_t launch_k1_wide(const PrepView& pv, const int32_t* pi, const int32_t* pj, PairRaw* raw, int64_t n_pairs,
+                          int blocks, size_t lds_bytes, int* task_ctr, hipStream_t s);
+hipError_t k1_wide_blocks_per_cu(size_t lds_bytes, int* out);
+inline size_t k1_wide_lds_bytes(int Wp) { return (size_t)(Wp + 1) * (8 + 8 + 4 + 4); }
 hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s);
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,

@@ -224,17 +224,22 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
 #undef ICIKT_CE
 }
 
+// WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
+// memory (they outgrow the static LDS), no tie-group list and no rec staging.
+template <bool WIDE>
 __global__ void __launch_bounds__(K0_THREADS)
 k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin) {
   __shared__ long long sh_ll[K0_THREADS];
   __shared__ int sh_i[K0_THREADS];
-  __shared__ unsigned long long sh_bits[1024];  // fill-group bitset, W <= 1024 words
-  __shared__ unsigned long long sh_st[1028];    // phase 1: the min reduction; phase 3: group starts, n + 1 <= 65 536 bits
+  __shared__ unsigned long long sh_bits_lds[1024];  // fill-group bitset, W <= 1024 words
+  __shared__ unsigned long long sh_st_lds[1028];    // phase 1: the min reduction; phase 3: group starts, n + 1 <= 65 536 bits
+  unsigned long long* const sh_bits = WIDE ? pv.k0_bits + (size_t)blockIdx.x * 2 * (size_t)(pv.Wp + 1) : sh_bits_lds;
+  unsigned long long* const sh_st = WIDE ? sh_bits + (pv.Wp + 1) : sh_st_lds;
   __shared__ unsigned long long sh_sort[K0_TILE + K0_TILE / 2];  // 48 KB: the sort tile, later the rec staging area
   unsigned long long* sh_tk = sh_sort;                                      // sort tile: keys
   uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + K0_TILE);         // sort tile: row indices
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(sh_sort);                   // after the sort: rec by row
-  const bool stage_rec = pv.n_pad <= 3 * K0_TILE;                           // 12 288 rows x 4 B fit
+  const bool stage_rec = !WIDE && pv.n_pad <= 3 * K0_TILE;                  // 12 288 rows x 4 B fit
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -248,10 +253,14 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   unsigned long long* mask = pv.col_mask(c);
   unsigned long long* fmask = pv.col_fillmask(c);
   unsigned long long* gflag = pv.col_gflag(c);
-  uint16_t* order = pv.order + (int64_t)c * pv.n_ord;
-  uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
-  uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
-  uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
+  uint16_t* order = WIDE ? nullptr : pv.order + (int64_t)c * pv.n_ord;
+  uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
+  uint16_t* hirow = WIDE ? nullptr : pv.hirow + (int64_t)c * pv.n_pad;
+  uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
+  uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
+  uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
+  uint32_t* lo32 = WIDE ? pv.lo32 + (int64_t)c * pv.n_pad : nullptr;
+  uint32_t* hi32 = WIDE ? pv.hi32 + (int64_t)c * pv.n_pad : nullptr;
 
   // ---- phase 1: NA bitset, NA count, min of the non-missing values (kendallc.cpp:187-218) --------
   double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
@@ -268,7 +277,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   if (tid == 0) { mask[W] = 0ull; }
   // plain double min (no NaN among candidates)
   {
-    double* sh_d = reinterpret_cast<double*>(sh_st);   // (the start-flag bitset of phase 3 lives here later)
+    double* sh_d = reinterpret_cast<double*>(sh_st_lds);   // (the start-flag bitset of phase 3 lives here later)
     sh_d[tid] = tmin;
     __syncthreads();
     for (int s = K0_THREADS / 2; s > 0; s >>= 1) {
@@ -415,8 +424,15 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
   }
   unsigned long long* sh_big = reinterpret_cast<unsigned long long*>(sh_ll);  // bit k: a group of >= 2 rows starts at k
-  for (int w = tid; w < 1024; w += K0_THREADS) { sh_bits[w] = 0ull; sh_big[w] = 0ull; }
-  for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) order[k] = 0;  // zero padding: K1 prefetches one step ahead
+  for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += K0_THREADS) {
+    sh_bits[w] = 0ull;
+    if (!WIDE) sh_big[w] = 0ull;
+  }
+  if (WIDE) {
+    for (int k = n + tid; k < pv.n_pad; k += K0_THREADS) order32[k] = 0u;
+  } else {
+    for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) order[k] = 0;  // zero padding: K1 prefetches one step ahead
+  }
   __syncthreads();
   auto is_start = [&](int k) -> bool { return (sh_st[k >> 6] >> (k & 63)) & 1ull; };   // 0 <= k <= n
   auto prev_start = [&](int k) -> int {   // last start at or before k (bit 0 is set)
@@ -443,17 +459,22 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     if (k < n) {
       const int lo = prev_start(k), hi = next_start(k) - 1;
       const uint32_t row = idx[k];
+      if (WIDE) {
+        hi32[row] = (uint32_t)hi; q32[row] = (uint32_t)k; lo32[row] = (uint32_t)lo;
+        order32[n - 1 - k] = row;
+      } else {
       hirow[row] = (uint16_t)hi;
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
       order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
+      }
       if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
       if (lo == k) {
         const int t = hi - lo + 1;
         ++ngroups;
         big = t >= 2;
-        maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
+        if (!WIDE) maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
         if (lo == 0) tfill = t;
         if (t >= 2) {
           ++ntg_local;
@@ -470,7 +491,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
       }
     }
     const unsigned long long bb = __ballot(big);
-    if (lane == 0 && (k >> 6) < 1024) sh_big[k >> 6] = bb;
+    if (!WIDE && lane == 0 && (k >> 6) < 1024) sh_big[k >> 6] = bb;
   }
   __syncthreads();
   if (stage_rec) {
@@ -494,7 +515,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
   // tie group of the OTHER column that spans several steps once, when that group closes.  A group's place in the
   // list = the groups of >= 2 rows that start before it: a prefix over the words of sh_big.
-  {
+  if (!WIDE) {
     const int nw = (n + 63) >> 6;                  // <= 1024 words, one per thread
     const int cnt = (tid < nw) ? (int)__popcll(sh_big[tid]) : 0;
     sh_i[tid] = cnt;
@@ -2454,6 +2475,168 @@ k_mask_pairs(const double* __restrict__ X, int64_t ld, int n, const int32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1w: the pair kernel for wide columns (65 535 < n <= ICIKT_MAX_FEATURES_WIDE)
+// ------------------------------------------------------------------------------------------------
+// Same counting as k1_pairs -- walk the streamed column B in descending order, keep a bitset `seen` over the
+// gathered column's positions of all rows whose B-group is strictly above, count "bits below lo" with a prefix over
+// the words -- but with 32-bit positions from separate arrays and none of the fast paths: one pair per wave, one
+// wave per workgroup, the flat prefix rebuilt after every batch (O(n / 64) per batch, as in round 1), in-batch pairs
+// by whole-wave shifts.  A batch is either up to 64 rows of COMPLETE tie groups of B, or one group longer than 64
+// rows, which is handled in two passes over its rows: (1) query `seen`, collect the rows in `pend`; (2) with a
+// prefix over `pend`, every row counts the group's rows in its tie group [lo, hi] of A (k - 1 per row: every joint
+// pair twice); then pend is merged into seen.  Throughput is not the point of this kernel (n = 100 000: ~10^5 pairs/s
+// per GPU); it exists so that columns of any practical length are accepted, like the reference accepts them.
+__device__ __forceinline__ void wide_rebuild(const unsigned long long* bits, uint32_t* pre, int Wp, uint32_t lane) {
+  const int per = (Wp + 63) >> 6;                 // words per lane, contiguous
+  const int w0 = (int)lane * per, w1 = min(Wp, w0 + per);
+  uint32_t run = 0;
+  for (int w = w0; w < w1; ++w) run += (uint32_t)__popcll(bits[w]);
+  uint32_t below = wave_incl_scan(run) - run;
+  for (int w = w0; w < w1; ++w) {
+    pre[w] = below;
+    below += (uint32_t)__popcll(bits[w]);
+  }
+  if (lane == 63u) pre[Wp] = below;               // total (the guard entry: a query at position 64 Wp)
+}
+__device__ __forceinline__ uint32_t wide_query(const unsigned long long* bits, const uint32_t* pre, uint32_t pos) {
+  const uint32_t w = pos >> 6;
+  return pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
+}
+
+__global__ void __launch_bounds__(64)
+k1_wide(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
+        long long n_pairs, int* __restrict__ task_ctr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const int n = pv.n, W = pv.W, Wp = pv.Wp;
+  unsigned long long* seen = reinterpret_cast<unsigned long long*>(wsm);          // Wp + 1 words each
+  unsigned long long* pend = seen + (Wp + 1);
+  uint32_t* pre = reinterpret_cast<uint32_t*>(pend + (Wp + 1));                   // Wp + 1 entries each
+  uint32_t* ppre = pre + (Wp + 1);
+  for (;;) {
+    long long p = 0;
+    if (lane == 0u) p = (long long)atomicAdd(task_ctr, 1);
+    p = ((long long)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+    if (p >= n_pairs) return;
+    const int ca = __builtin_amdgcn_readfirstlane(pi[p]), cb_ = __builtin_amdgcn_readfirstlane(pj[p]);
+    const uint32_t* ordB = pv.order32 + (int64_t)cb_ * pv.n_pad;
+    const unsigned long long* gf = pv.col_gflag(cb_);
+    const uint32_t* qA = pv.q32 + (int64_t)ca * pv.n_pad;
+    const uint32_t* loA = pv.lo32 + (int64_t)ca * pv.n_pad;
+    const uint32_t* hiA = pv.hi32 + (int64_t)ca * pv.n_pad;
+    for (int w = (int)lane; w <= Wp; w += 64) { seen[w] = 0ull; pend[w] = 0ull; pre[w] = 0u; ppre[w] = 0u; }
+    wave_lds_fence();
+    unsigned long long dis = 0, tie = 0, tie2 = 0;   // per lane
+    int pos = 0;
+    while (pos < n) {
+      // flags of positions pos .. pos + 63 and of position pos + 64 (gf[W] is a zero guard word)
+      const int wc = pos >> 6, fb = pos & 63;
+      const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
+      unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+      const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;
+      const int remaining = n - pos;
+      const int avail = min(remaining, 64);
+      if (avail < 64) F &= (1ull << avail) - 1ull;
+      // group starts after position pos inside the window; the position after the data counts as a start
+      unsigned long long starts = F & ~1ull;
+      if (avail < 64) starts |= 1ull << avail;
+      const bool end_at_64 = (avail == 64) && (fnbit || remaining == 64);
+      if (starts == 0ull && !end_at_64) {
+        // ---- one group longer than the window: find its end, then two passes over its rows ------------------
+        int gend = pos + 64;
+        for (;;) {   // first start at or after gend (wave-uniform scalar scan of the flag words)
+          if (gend >= n) { gend = n; break; }
+          const int gw = gend >> 6, gb = gend & 63;
+          const unsigned long long m = gf[gw] >> gb;
+          if (m != 0ull) { gend = min(n, gend + (int)__builtin_ctzll(m)); break; }
+          gend = (gw + 1) << 6;
+        }
+        for (int b = pos; b < gend; b += 64) {
+          const int k = b + (int)lane;
+          if (k < gend) {
+            const uint32_t row = ordB[k];
+            const uint32_t q = qA[row], lo = loA[row];
+            dis += wide_query(seen, pre, lo);
+            seen_insert(pend, q);
+          }
+        }
+        wave_lds_fence();
+        wide_rebuild(pend, ppre, Wp, lane);
+        wave_lds_fence();
+        for (int b = pos; b < gend; b += 64) {
+          const int k = b + (int)lane;
+          if (k < gend) {
+            const uint32_t row = ordB[k];
+            const uint32_t lo = loA[row], hi = hiA[row];
+            const uint32_t cell = wide_query(pend, ppre, hi + 1u) - wide_query(pend, ppre, lo);
+            tie2 += cell - 1u;     // the row itself is in its cell
+          }
+        }
+        wave_lds_fence();
+        for (int w = (int)lane; w < Wp; w += 64) { seen[w] |= pend[w]; pend[w] = 0ull; }
+        wave_lds_fence();
+        wide_rebuild(seen, pre, Wp, lane);
+        wave_lds_fence();
+        pos = gend;
+        continue;
+      }
+      // ---- a batch of complete groups: rows pos .. pos + nact - 1 ------------------------------------------------
+      int nact;
+      if (end_at_64) nact = 64;
+      else nact = 63 - (int)__builtin_clzll(starts);      // the last start inside the window ends the batch
+      const bool valid = (int)lane < nact;
+      uint32_t q = 0xFFFFFFFFu, lo = 0u;
+      if (valid) {
+        const uint32_t row = ordB[pos + (int)lane];
+        q = qA[row];
+        lo = loA[row];
+      }
+      const uint32_t gid = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));   // number of the lane's group in the batch
+      if (valid) dis += wide_query(seen, pre, lo);
+      uint32_t sq = q, sg = gid, slo = lo;
+      for (int d = 1; d < nact; ++d) {
+        sq = dpp_wave_shr1(0xFFFFFFFFu, sq);     // lane l now holds lane l - d
+        sg = dpp_wave_shr1(0xFFFFFFFFu, sg);
+        slo = dpp_wave_shr1(0xFFFFFFFFu, slo);
+        if (valid && (int)lane >= d) {
+          if (sg != gid) dis += (sq < lo) ? 1u : 0u;       // an earlier group of the batch: is its row below mine in A?
+          else tie += (slo == lo) ? 1u : 0u;               // my own group: a joint tie?
+        }
+      }
+      wave_lds_fence();
+      if (valid) seen_insert(seen, q);
+      wave_lds_fence();
+      wide_rebuild(seen, pre, Wp, lane);
+      wave_lds_fence();
+      pos += nact;
+    }
+    // rows missing in both columns / in both fill groups
+    const unsigned long long* ma = pv.col_mask(ca);
+    const unsigned long long* mb = pv.col_mask(cb_);
+    const unsigned long long* fa = pv.col_fillmask(ca);
+    const unsigned long long* fbm = pv.col_fillmask(cb_);
+    unsigned long long cboth = 0, gboth = 0;
+    for (int w = (int)lane; w < W; w += 64) {
+      cboth += (unsigned long long)__popcll(ma[w] & mb[w]);
+      gboth += (unsigned long long)__popcll(fa[w] & fbm[w]);
+    }
+    const unsigned long long dis_t = wave_sum_u64(dis);
+    const unsigned long long tie_t = wave_sum_u64(tie) + (wave_sum_u64(tie2) >> 1);
+    const unsigned long long cb_t = wave_sum_u64(cboth), gg_t = wave_sum_u64(gboth);
+    if (lane == 0u) {
+      PairRaw o;
+      o.dis = dis_t;
+      o.ntie = tie_t;
+      o.c_both = (uint32_t)cb_t;
+      o.g = (uint32_t)gg_t;
+      raw[p] = o;
+    }
+    wave_lds_fence();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // self-test of the DPP primitives
 // ------------------------------------------------------------------------------------------------
 __global__ void k_selftest(uint32_t* out) {
@@ -2489,8 +2672,25 @@ __global__ void k_selftest(uint32_t* out) {
 // launchers (called from icikt_capi.cpp; keeps <<<>>> syntax inside the .hip translation unit)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s) {
-  hipLaunchKernelGGL(k0_prepare, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
+  if (pv.wide) hipLaunchKernelGGL(k0_prepare<true>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
+  else hipLaunchKernelGGL(k0_prepare<false>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
   return hipGetLastError();
+}
+
+hipError_t launch_k1_wide(const PrepView& pv, const int32_t* pi, const int32_t* pj, PairRaw* raw, int64_t n_pairs,
+                          int blocks, size_t lds_bytes, int* task_ctr, hipStream_t s) {
+  if (n_pairs <= 0 || blocks <= 0) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k1_wide, dim3(blocks), dim3(64), lds_bytes, s, pv, pi, pj, raw, (long long)n_pairs, task_ctr);
+  return hipGetLastError();
+}
+hipError_t k1_wide_blocks_per_cu(size_t lds_bytes, int* out) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, reinterpret_cast<const void*>(k1_wide), 64, lds_bytes);
 }
 
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,

@@ -397,7 +397,9 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
   // Too little work to split (fewer than two columns per rank, or a handful of pairs): rank 0's single-device
   // path, which also owns every argument check.  (One device with enough work runs the full flow below: the
   // collectives of a one-rank communicator are copies.)
-  if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0) {
+  // Wide columns (n_feat > ICIKT_MAX_FEATURES) run on rank 0 alone as well: the ranks exchange the 16-bit prepared
+  // state of the tuned kernels, which wide columns do not have.
+  if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0 || n_feat > ICIKT_MAX_FEATURES) {
     icikt_ctx* c = m->ctx[0];
     const int saved = c->h2d_mode;
     c->h2d_mode = -1;
@@ -408,8 +410,6 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
     return ICIKT_SUCCESS;
   }
   // argument checks (the ranks run unchecked): same texts as the single-device path
-  if (n_feat > ICIKT_MAX_FEATURES)
-    return mfail(m, ICIKT_E_TOO_LONG, "pairs_multi: n_feat exceeds ICIKT_MAX_FEATURES (65535 rows per column)");
   if (!X) return mfail(m, ICIKT_E_INVALID, "pairs_multi: null matrix");
   if (n_pairs < 0 || (pi && !pj)) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad pair list");
   if (pi)

@@ -19,9 +19,11 @@
  *     Degenerate pairs get R's NA_real_ bit pattern (0x7FF00000000007A2) in all four and a reason.
  *   - All functions return ICIKT_SUCCESS (0) or a negative ICIKT_E_* code; the message is kept in
  *     the context (icikt_last_error).  Nothing throws across the boundary.
- *   - n_feat <= ICIKT_MAX_FEATURES (65 535) rows per column: positions are 16-bit.  Longer columns are refused
- *     with ICIKT_E_TOO_LONG and a message that names the limit (the reference accepts any length, but its own
- *     `int dis`, src/kendallc.cpp:78, overflows from about that length on).
+ *   - n_feat <= ICIKT_MAX_FEATURES (65 535) rows per column run the tuned kernels (16-bit positions).  Longer
+ *     columns, up to ICIKT_MAX_FEATURES_WIDE (262 144) rows, are accepted by every single-device entry and run a
+ *     plain 32-bit path (about two orders of magnitude slower per pair) in EXACT integer arithmetic: the reference's
+ *     int32 wrap-around (its `int dis`, src/kendallc.cpp:78, and the Rcpp-sugar tie sums) is not reproduced there,
+ *     i.e. ICIKT_FLAG_EXACT_INT64 is implied.  Beyond that: ICIKT_E_TOO_LONG with a message that names the limit.
  *   - A context owns one HIP device, one stream and its workspaces.  Calls on one context must come
  *     from one thread at a time.  Must not be used in a fork()ed child of a process that has
  *     already created a context (R/utils.R:68-80 furrr multicore workers).
@@ -43,13 +45,14 @@ extern "C" {
 #define ICIKT_E_INVALID (-1)    /* bad argument (message says which) */
 #define ICIKT_E_HIP (-2)        /* HIP runtime error */
 #define ICIKT_E_NOMEM (-3)      /* host allocation failure */
-#define ICIKT_E_TOO_LONG (-4)   /* n_feat > ICIKT_MAX_FEATURES */
+#define ICIKT_E_TOO_LONG (-4)   /* n_feat > ICIKT_MAX_FEATURES_WIDE (or > ICIKT_MAX_FEATURES where wide columns are not supported) */
 #define ICIKT_E_STATE (-5)      /* call order: prepare / set_pairs before run */
 #define ICIKT_E_NO_DEVICE (-6)  /* no usable HIP device: the product path never falls back to CPU */
 
 /* n_feat limit of the uint16 rank path.  The reference's `int dis` (src/kendallc.cpp:78) and
  * int32 tie sums are themselves only safe to n ~ 65 535. */
 #define ICIKT_MAX_FEATURES 65535
+#define ICIKT_MAX_FEATURES_WIDE 262144
 
 /* perspective (src/kendallc.cpp:180) */
 #define ICIKT_PERSPECTIVE_LOCAL 0

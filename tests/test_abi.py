@@ -38,6 +38,7 @@ def test_constants_match_header():
     assert int(defs["ICIKT_ALT_LESS"]) == _lib.ALTERNATIVE["less"]
     assert int(defs["ICIKT_ALT_GREATER"]) == _lib.ALTERNATIVE["greater"]
     assert int(defs["ICIKT_MAX_FEATURES"]) == _lib.MAX_FEATURES
+    assert int(defs["ICIKT_MAX_FEATURES_WIDE"]) == _lib.MAX_FEATURES_WIDE
     assert int(defs["ICIKT_E_NO_DEVICE"]) == _lib.E_NO_DEVICE
     for i, f in enumerate(_lib.CNT_FIELDS):
         assert int(defs["ICIKT_CNT_" + f.upper()]) == i

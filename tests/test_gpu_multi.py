@@ -111,8 +111,16 @@ def test_multi_error_contract():
         X = _matrix(500, 20, 5)
         with pytest.raises(_lib.IciktError, match="column index out of range"):
             m.pairs(X, np.array([0] * 200, np.int32), np.array([20] * 200, np.int32))
-        with pytest.raises(_lib.IciktError, match="65535"):
-            m.pairs(np.zeros((70000, 20)))
+        with pytest.raises(_lib.IciktError, match="262144"):
+            m.pairs(np.zeros((262145, 4)))
+        # wide columns (65 535 < n <= 262 144) run on the first device alone, through the same entry
+        Xw = _matrix(66000, 4, 6)
+        from icikendalltau_amd import _lib as L2
+        c1 = L2.Context(0)
+        try:
+            _same(m.pairs(Xw, perspective="global"), c1.pairs(Xw, perspective="global"))
+        finally:
+            c1.close()
         # and still usable afterwards
         o, _c, r = m.pairs(X, perspective="global")
         assert np.all(r == 0) and not np.isnan(o).any()

@@ -346,8 +346,72 @@ def test_max_length_65535(hip_ctx):
         assert all(cnt[k] == rcnt[k] for k in cnt)
         assert np.max(np.abs(out - ref)) <= ATOL
     from icikendalltau_amd._lib import IciktError
-    with pytest.raises(IciktError, match="65535"):
-        hip_ctx.pair(np.zeros(65536), np.zeros(65536))
+    with pytest.raises(IciktError, match="262144"):
+        hip_ctx.pair(np.zeros(262145), np.zeros(262145))
+
+
+def test_wide_columns_longest(hip_ctx):
+    """n = ICIKT_MAX_FEATURES_WIDE = 262 144 rows: one wave per CU (98 KB of LDS state), three columns."""
+    n = 262144
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal(n)
+    X = base[:, None] + 0.04 * rng.standard_normal((n, 3))   # tau ~ 0.97: `dis` must fit the reference's int
+    X[:, 1] = np.round(X[:, 1] * 300)
+    X[np.argsort(X[:, 2])[:5000], 2] = np.nan
+    X = np.asfortranarray(X)
+    O = _oracle()
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(3, k=1))
+    out, cnt, rsn = hip_ctx.pairs(X, perspective="global")
+    ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, "global", int32_compat=False)
+    assert int(rcnt[:, 2].max()) < 2**30               # far from where the oracle's int dis saturates
+    assert np.array_equal(rsn, rrsn) and np.array_equal(cnt, rcnt[:, :cnt.shape[1]])
+    assert float(np.nanmax(np.abs(out - ref))) <= ATOL
+
+
+@pytest.mark.parametrize("n", [65536, 70001, 140000])
+def test_wide_columns(hip_ctx, n):
+    """65 535 < n <= 262 144 rows: the plain 32-bit path (k0_prepare<true>, k1_wide), exact integer arithmetic --
+    compared with the oracle in its exact mode (int32_compat = False; the reference's int32 sums wrap at these
+    lengths).  Continuous columns, small tie groups (batches of complete groups), a few huge groups (the two-pass
+    long-group path), left-censored and scattered missing values, both perspectives; then the host entry for a
+    matrix, its explicit-list form, REUSE_COUNTS and missingness on the same shape."""
+    rng = np.random.default_rng(n)
+    S = 5
+    # (the columns are positively correlated: the reference keeps `dis` in an int, src/kendallc.cpp:78, and so does
+    #  the oracle -- with independent columns of 140 000 rows the count itself, ~n^2 / 4, no longer fits)
+    base = rng.standard_normal(n)
+    X = base[:, None] + (0.35 if n < 100000 else 0.1) * rng.standard_normal((n, S))
+    X[:, 1] = np.round(X[:, 1] * 2000)            # groups of a few rows up to ~50
+    X[:, 2] = np.round(X[:, 2] * 1.5)             # ~10 groups of thousands of rows
+    k = n // 20
+    idx = np.argpartition(X[:, [0, 3]], k, axis=0)[:k]
+    for c, col in enumerate((0, 3)):
+        X[idx[:, c], col] = np.nan                # left-censored: the missing rows are the last (long) tie group
+    X[rng.random(n) < 0.02, 4] = np.nan
+    X = np.asfortranarray(X)
+    O = _oracle()
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    for perspective in ("global", "local"):
+        out, cnt, rsn = hip_ctx.pairs(X, perspective=perspective)
+        ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, perspective, int32_compat=False)
+        assert np.array_equal(rsn, rrsn)
+        assert int(rcnt[:, 2].max()) < 2**30              # dis far from where the reference's int saturates
+        assert np.array_equal(cnt, rcnt[:, :cnt.shape[1]])
+        assert float(np.nanmax(np.abs(out - ref))) <= ATOL
+    # explicit list in another order, pairs in both orientations; a single pair through the vector entry
+    sel = np.array([9, 0, 4, 4, 7], dtype=np.int64)
+    qi = np.where(np.arange(len(sel)) % 2 == 0, pi[sel], pj[sel]).astype(np.int32)
+    qj = np.where(np.arange(len(sel)) % 2 == 0, pj[sel], pi[sel]).astype(np.int32)
+    out_l, cnt_l, rsn_l = hip_ctx.pairs(X, qi, qj, "global")
+    ref_l, rcnt_l, rrsn_l = O.ici_pairs(X, qi, qj, "global", int32_compat=False)
+    assert np.array_equal(rsn_l, rrsn_l) and np.array_equal(cnt_l, rcnt_l[:, :cnt_l.shape[1]])
+    assert float(np.nanmax(np.abs(out_l - ref_l))) <= ATOL
+    o1, c1, r1 = hip_ctx.pair(X[:, 1], X[:, 2], "local")
+    ro, rc_, rr = O.ici_kt(X[:, 1], X[:, 2], "local", int32_compat=False)
+    assert r1 == rr and all(c1[f] == rc_[f] for f in c1) and np.max(np.abs(o1 - ro)) <= ATOL
+    miss = hip_ctx.missingness(X, pi, pj)
+    M = np.isnan(X)
+    assert np.array_equal(miss, np.array([(M[:, a] | M[:, b]).sum() for a, b in zip(pi, pj)]))
 
 
 def test_int32_wrap_of_a_large_joint_cell(hip_ctx):

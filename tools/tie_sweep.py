@@ -9,6 +9,8 @@ n, S = 10000, 256
 rng = np.random.default_rng(3)
 base = rng.standard_normal((n, S))
 ctx = _lib.Context(0)
+if len(sys.argv) > 1:
+    ctx.debug_set_plan(sys.argv[1])   # e.g. tgmax=1000
 P = S * (S - 1) // 2
 ctx.set_pairs_combn(S, 0, P)
 out = torch.empty((P, 4), dtype=torch.float64, device="cuda")

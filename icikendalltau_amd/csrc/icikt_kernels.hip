@@ -2595,6 +2595,11 @@ k1_wide(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restrict__
       const uint32_t gid = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));   // number of the lane's group in the batch
       if (valid) dis += wide_query(seen, pre, lo);
       uint32_t sq = q, sg = gid, slo = lo;
+      if (nact == 64 && F == ~0ull) {
+        // 64 rows, each its own group (continuous data): the 39-compare all-pairs count of the one-pair kernels
+        // (32-bit compares: positions of any width) instead of 63 shifts
+        dis += wave_allpairs(q, lo, lane);
+      } else
       for (int d = 1; d < nact; ++d) {
         sq = dpp_wave_shr1(0xFFFFFFFFu, sq);     // lane l now holds lane l - d
         sg = dpp_wave_shr1(0xFFFFFFFFu, sg);

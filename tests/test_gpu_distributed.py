@@ -41,6 +41,25 @@ def test_bench_sequence_two_ranks_gloo(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_bench_sequence_one_rank_rccl(tmp_path):
+    """The same sequence over the real nccl (= RCCL) backend with a process group of ONE rank: zero-copy torch views of
+    the library's device arrays go through all_gather_into_tensor and gather on the GPU (the two-rank rehearsal
+    above moves them through host memory)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICIKT_BENCH_FORCE_DIST="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1", "--config", "c3", "--steps", "2",
+           "--warmup", "1"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["pre_pass"] == "sharded+allgather"
+    assert line["check"]["ok"] and line["check"]["assembled_pairs"] == 32640 and line["check"]["nan_rows"] == 0
+    assert line["check"]["max_abs_diff"] <= 1e-10
+
+
+@pytest.mark.timeout(900)
 def test_api_run_sharded_two_ranks_gloo(tmp_path):
     res = _torchrun(["tests/dist_worker.py", str(tmp_path)], {}, 840)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]

@@ -1870,10 +1870,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // two reads, the rows' OR into seen, the reads of the prefix rebuild (one wave's DS operations execute in
         // order, so the query sees the bitset before, the rebuild after the insertion) -- and the all-pairs count,
         // which needs registers only, runs while they are in flight.
-        const uint32_t pre_lo = (uint32_t)spreH[half_pre_index<H>(loh >> 6)];
-        const unsigned long long word_lo = seenH[loh >> 6];
+        // (addresses in bytes: slot w / H at 16 bytes, entry w % H at 2 -> 2 w + (16 - 2 H) (w / H); the word index of q
+        //  is a bit field of the gathered value)
+        const uint32_t wlo = r >> 22;
+        const uint32_t dlo = (wlo * (65536u / (uint32_t)H + 1u)) >> 16;     // w / H for w < 256, H <= 7
+        const uint32_t pre_lo = (uint32_t)*reinterpret_cast<const uint16_t*>(
+            reinterpret_cast<const unsigned char*>(spreH) + 2u * wlo + (16u - 2u * (uint32_t)H) * dlo);
+        const unsigned long long word_lo = seenH[wlo];
         wave_lds_fence();
-        seen_insert(seenH, qh);
+        atomicOr(reinterpret_cast<uint32_t*>(seenH) + __builtin_amdgcn_ubfe(r, 5, 9), 1u << (qh & 31u));
         wave_lds_fence();
         unsigned long long wv[H];
 #pragma unroll

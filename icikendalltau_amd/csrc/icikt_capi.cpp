@@ -220,20 +220,16 @@ int upload_pairs(icikt_ctx* c) {
   HIPCHK(c, c->d_pj.reserve((size_t)std::max<int64_t>(P, 1)));
   HIPCHK(c, c->d_raw.reserve((size_t)std::max<int64_t>(P, 1)));
   if (P > 0) {
-    HIPCHK(c, hipMemcpyAsync(c->d_pi.p, c->h_pi.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pj.p, c->h_pj.data(), P * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    int rc = icikt::host::upload_sync(c, c->d_pi.p, c->h_pi.data(), (size_t)P * sizeof(int32_t));
+    if (!rc) rc = icikt::host::upload_sync(c, c->d_pj.p, c->h_pj.data(), (size_t)P * sizeof(int32_t));
+    if (rc) return rc;
   }
-  // the host vectors must outlive the async copies
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   return ICIKT_SUCCESS;
 }
 
 int upload_units(icikt_ctx* c) {
   HIPCHK(c, c->d_unit_start.reserve(c->h_units.size()));
-  HIPCHK(c, hipMemcpyAsync(c->d_unit_start.p, c->h_units.data(), c->h_units.size() * sizeof(int32_t),
-                           hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return ICIKT_SUCCESS;
+  return icikt::host::upload_sync(c, c->d_unit_start.p, c->h_units.data(), c->h_units.size() * sizeof(int32_t));
 }
 
 }  // namespace
@@ -739,9 +735,10 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
     const double* src0 = X + col_begin * ld;
     const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
-    // default: page-lock the source when it is large enough to pay for the registration; mode 3 = the caller of
+    // default: page-lock the source unless it is small enough for the runtime's staging path (see kLockMin in
+    // icikt_host.h: HIP's own pinning of pageable memory is what this avoids); mode 3 = the caller of
     // this function has page-locked the matrix already (icikt_multi: once for all devices)
-    int mode = c->h2d_mode < 0 ? ((span >= ((size_t)4 << 20)) ? 1 : 0) : c->h2d_mode;
+    int mode = c->h2d_mode < 0 ? ((span >= kLockMin) ? 1 : 0) : c->h2d_mode;
     bool registered = false;
     if (mode == 1) {
       registered = hipHostRegister(const_cast<double*>(src0), span, hipHostRegisterDefault) == hipSuccess;
@@ -807,10 +804,31 @@ void prebuild_units(icikt_ctx* c) {
   }
 }
 
+int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return ICIKT_SUCCESS;
+  const bool locked = bytes >= kLockMin && hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterDefault) == hipSuccess;
+  if (bytes >= kLockMin && !locked) (void)hipGetLastError();   // e.g. already page-locked by the caller: fine
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  const hipError_t es = hipStreamSynchronize(c->stream);       // the host range must outlive the copy
+  if (locked) (void)hipHostUnregister(const_cast<void*>(src));
+  if (e == hipSuccess) e = es;
+  if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D copy: ") + hipGetErrorString(e));
+  return ICIKT_SUCCESS;
+}
+
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
+  if (bytes >= kLockMin) {
+    if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) c->locked_out.push_back(dst);
+    else (void)hipGetLastError();                              // already page-locked (caller, or an overlapping range)
+  }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   return ICIKT_SUCCESS;
+}
+
+void finish_downloads(icikt_ctx* c) {
+  for (void* p : c->locked_out) (void)hipHostUnregister(p);
+  c->locked_out.clear();
 }
 
 }  // namespace host
@@ -890,6 +908,7 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
   rc = body();
   // success or not: nothing may still be reading or writing the caller's buffers when this returns
   const hipError_t es = hipStreamSynchronize(c->stream);
+  icikt::host::finish_downloads(c);
   finish_upload();
   if (rc) return rc;
   if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(es));
@@ -954,11 +973,13 @@ int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int6
       if (!r && reasons) r = icikt::host::download(c, reasons + first, c->d_reasons.p, (size_t)m * sizeof(int32_t));
       if (r) return r;
       HIPCHK(c, hipStreamSynchronize(c->stream));  // the chunk's buffers are reused by the next one
+      icikt::host::finish_downloads(c);
     }
     return ICIKT_SUCCESS;
   };
   rc = body();
   const hipError_t es = hipStreamSynchronize(c->stream);
+  icikt::host::finish_downloads(c);
   all_pi.release();
   all_pj.release();
   if (rc) return rc;
@@ -1013,6 +1034,7 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
   };
   rc = body();
   const hipError_t es = hipStreamSynchronize(c->stream);
+  icikt::host::finish_downloads(c);
   if (rc) return rc;
   if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("missingness: ") + hipGetErrorString(es));
   return ICIKT_SUCCESS;

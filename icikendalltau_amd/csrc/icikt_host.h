@@ -65,6 +65,9 @@ struct icikt_ctx {
   DevBuf<int> d_task_ctr;  // persistent pair kernel: one task counter per XCD group, zeroed before every launch
   std::vector<int32_t> h_pi, h_pj, h_units;
   bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
+  // result buffers of the caller that were page-locked for a D2H copy (icikt::host::download): released by
+  // finish_downloads() once the stream has been synchronised
+  std::vector<void*> locked_out;
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
   hipStream_t copy_stream = nullptr;
@@ -123,7 +126,17 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
                        int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr);
 // Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).
 void prebuild_units(icikt_ctx* c);
-// D2H of a result array into a pageable host buffer on c->stream (not synchronised)
+// Host <-> device copies of pageable host memory.  HIP pins pageable memory on the fly for copies of 1 MB and more;
+// that path faulted intermittently (a GPU memory-access fault at a host heap address, under load, in the one parity
+// test whose matrix falls between 1 MB and the old 4 MB registration threshold).  Every copy of kLockMin bytes or
+// more therefore page-locks the caller's memory itself (hipHostRegister), for the time of the copy; smaller copies
+// take the runtime's staging path, which does not touch the caller's pages from the GPU.
+constexpr size_t kLockMin = (size_t)256 << 10;
+// H2D on c->stream, complete (and the host range released) on return
+int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes);
+// after the stream that carries download() copies has been synchronised: end the page-locking of their targets
+void finish_downloads(icikt_ctx* c);
+// D2H of a result array into a pageable host buffer on c->stream (not synchronised; finish_downloads afterwards)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 
 }  // namespace host

@@ -289,7 +289,9 @@ void rank_main(Call& a, int r) {
       if (a.counts) RANKCHK(icikt::host::download(c, a.counts, m->root_counts, (size_t)a.P * ICIKT_CNT_FIELDS * sizeof(int64_t)));
       if (a.reasons) RANKCHK(icikt::host::download(c, a.reasons, m->root_reasons, (size_t)a.P * sizeof(int32_t)));
     }
-    RANKCHK_HIP(hipStreamSynchronize(c->stream));
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    icikt::host::finish_downloads(c);
+    RANKCHK_HIP(es);
   };
   phase_c();
   if (r == 0) m->phase_ms[ICIKT_MULTI_PHASE_GATHER] = now_ms() - t_prev;

@@ -1451,7 +1451,7 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
 // Per 64 rows and two pairs: the hot step + ~35 + 8 per distance instructions (round 2 before: one 32-row segment
 // per call, an unpacked all-pairs chain, ~10 instructions per distance and pair).
 template <int HI>
-__device__ __attribute__((noinline)) SegCounts half_mixed64_step(const SegState st, const unsigned long long F_in,
+__device__ __forceinline__ SegCounts half_mixed64_step(const SegState st, const unsigned long long F_in,
                                                                  const int nact_in, const uint32_t rk0, const uint32_t rk1,
                                                                  const uint32_t lane, const uint32_t partner_addr) {
   constexpr int H = (HI > 0 ? HI : 1);

@@ -1544,7 +1544,7 @@ __device__ __forceinline__ SegCounts half_mixed64_step(const SegState st, const 
 // group list when the group closes (close_group_ties).  A single-step group of a row-mode pair needs no pend at
 // all: its rows are inserted into `seen` directly and "after - before" cancels the rows of earlier groups.
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) SegCounts seg_group_step(const SegState st, const int nact_in, const bool single_in,
+__device__ __forceinline__ SegCounts seg_group_step(const SegState st, const int nact_in, const bool single_in,
                                                               const bool closes_in, const bool rowmode, const uint32_t rk,
                                                               const uint32_t hi_in, const uint32_t cfill, const int IT_in,
                                                               const uint32_t magic_in, const uint32_t lane) {

@@ -1440,49 +1440,25 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
 // Splitting "rows before my group" into "rows before me" minus "rows of my group before me" separates the work:
 //  (1) rows before me with q < lo_me: what the hot step counts -- prefix query + the packed in-step chain on two
 //      32-row sub-steps per pair -- and it does not look at the groups at all (the sub-steps need not end where
-//      groups end).  Lanes past the step's rows carry q = 0x3FFF, lo = 0: they never count, are never counted,
-//      their query is 0, and only their insertion is masked.
-//  (2) pairs inside a group, in the row layout (lane = row of the streamed column, both pairs' values in the lane):
-//      d = 1 .. largest group - 1 whole-wave shifts of X = (0x3FFF - q) | (0x4000 + lo) << 16 added to the lane's
-//      own X with its halves swapped give, in bits 15 and 31, [q_prev < lo_me] and [q_me < lo_prev]; one bit vector
-//      per pair collects them (one bit per distance).  A lane's group reaches idx rows back, so the vector masked
-//      to distances <= idx holds the lane's spurious counts (first flag) and, where neither flag is set, its joint
-//      ties: lo_prev == lo_me, because tie groups of the gathered column are disjoint ranges.
+//      groups end).  The caller therefore runs the HOT STEP ITSELF on the step's rows; lanes past them carry
+//      q = 64 W (a position in the guard word of `seen`, above every real one) and lo = 0: they never count, are
+//      never counted, their query is 0, and what they insert is a bit no query ever reaches.
+//  (2) pairs inside a group (this function), in the row layout (lane = row of the streamed column, both pairs'
+//      values in the lane): d = 1 .. largest group - 1 whole-wave shifts of X = (0x3FFF - q) | (0x4000 + lo) << 16
+//      added to the lane's own X with its halves swapped give, in bits 15 and 31, [q_prev < lo_me] and
+//      [q_me < lo_prev]; one bit vector per pair collects them (one bit per distance).  A lane's group reaches idx
+//      rows back, so the vector masked to distances <= idx holds the lane's spurious counts (first flag) and, where
+//      neither flag is set, its joint ties: lo_prev == lo_me, because tie groups of the gathered column are disjoint
+//      ranges.
 // Per 64 rows and two pairs: the hot step + ~35 + 8 per distance instructions (round 2 before: one 32-row segment
 // per call, an unpacked all-pairs chain, ~10 instructions per distance and pair).
-template <int HI>
-__device__ __forceinline__ SegCounts half_mixed64_step(const SegState st, const unsigned long long F_in,
-                                                                 const int nact_in, const uint32_t rk0, const uint32_t rk1,
-                                                                 const uint32_t lane, const uint32_t partner_addr) {
-  constexpr int H = (HI > 0 ? HI : 1);
+__device__ __forceinline__ SegCounts half_mixed64_corr(const unsigned long long F_in, const int nact_in, const uint32_t v0,
+                                                       const uint32_t v1, const uint32_t lane) {
   const unsigned long long F = uniform_u64(F_in);
   const int nact = __builtin_amdgcn_readfirstlane(nact_in);
-  unsigned long long* seen = (unsigned long long*)st.seen;
-  uint16_t* spre = (uint16_t*)st.spre;
-  const uint32_t l32 = lane & 31u;
   const bool valid = (int)lane < nact;
-  const uint32_t none = 0x00003FFFu;   // q = 0x3FFF, lo = 0
-  const uint32_t v0 = valid ? rk0 : none, v1 = valid ? rk1 : none;
   SegCounts c;
   c.tie2 = 0; c.cfill = 0;
-  // ---- (1) the hot step on masked rows ------------------------------------------------------------------------
-  const auto sw = __builtin_amdgcn_permlane32_swap(v0, v1, false, false);
-  uint32_t pos_cnt = half_step_count(sw[0], sw[1], lane, partner_addr), neg_cnt = 0;
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    if (sub == 1 && nact <= 32) break;   // wave-uniform
-    const uint32_t r = sub ? sw[1] : sw[0];
-    const uint32_t qh = r & 0xFFFFu, loh = r >> 16;
-    const bool vs = (int)(l32 + 32u * (uint32_t)sub) < nact;
-    const uint32_t w = loh >> 6;
-    pos_cnt += (uint32_t)spre[half_pre_index<H>(w)];
-    neg_cnt = bcnt64_acc(seen[w] >> (loh & 63u), neg_cnt);
-    wave_lds_fence();
-    if (vs) seen_insert(seen, qh);
-    wave_lds_fence();
-    rebuild_prefix_half<H>(seen, spre, l32);
-    wave_lds_fence();
-  }
   // ---- (2) pairs inside a group ---------------------------------------------------------------------------------
   int dmax = 0;   // longest run of rows that continue a group = largest group - 1 (wave-uniform, from the flags)
   {
@@ -1532,8 +1508,8 @@ __device__ __forceinline__ SegCounts half_mixed64_step(const SegState st, const 
   const auto st2 = __builtin_amdgcn_permlane32_swap(spur_tie, spur_tie, false, false);
   const uint32_t a = (lane < 32u) ? (st2[0] & 0xFFFFu) : (st2[0] >> 16);
   const uint32_t b = (lane < 32u) ? (st2[1] & 0xFFFFu) : (st2[1] >> 16);
-  c.dis = pos_cnt;
-  c.neg = neg_cnt + (a & 0xFFu) + (b & 0xFFu);
+  c.dis = 0;
+  c.neg = (a & 0xFFu) + (b & 0xFFu);
   c.tie = (a >> 8) + (b >> 8);
   return c;
 }
@@ -2103,7 +2079,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       }
       SegCounts c;
       if (kind == 1) {
-        if constexpr (half_mode) c = half_mixed64_step<HI>(st, F, nact, rk[0], rk[NP - 1], lane_t, partner_addr);
+        if constexpr (half_mode) {
+          // the hot step on the step's rows (lanes past them: a position in the guard word, lo = 0), then the pairs
+          // inside the groups
+          uint32_t rkm[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) rkm[k] = ((int)lane_t < nact) ? rk[k] : ((uint32_t)W << 6);
+          hot_step(rkm);
+          c = half_mixed64_corr(F, nact, rkm[0], rkm[NP - 1], lane_t);
+        }
         else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {
         // last position of the row's tie group in the gathered column

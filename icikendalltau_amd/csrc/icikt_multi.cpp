@@ -294,6 +294,10 @@ void rank_main(Call& a, int r) {
     RANKCHK_HIP(es);
   };
   phase_c();
+  if (!c->locked_out.empty()) {   // phase C left early: nothing may still write the caller's arrays
+    (void)hipStreamSynchronize(c->stream);
+    icikt::host::finish_downloads(c);
+  }
   if (r == 0) m->phase_ms[ICIKT_MULTI_PHASE_GATHER] = now_ms() - t_prev;
   a.bar->wait();  // "copy" exchange: nobody returns (and lets its buffers be reused) while rank 0 still reads them
 }

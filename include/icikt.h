@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICIKT_VERSION 200 /* 0.2.0 */
+#define ICIKT_VERSION 201 /* 0.2.1: wide columns (ICIKT_MAX_FEATURES_WIDE) */
 
 /* status codes */
 #define ICIKT_SUCCESS 0

@@ -170,3 +170,21 @@ def test_sharded_prepass_sequence_world_2(scenario):
     else:
         # one rank cannot: BOTH fall back (no rank is left alone inside a collective) and say so
         assert all((not o["ok"]) and o["mode"] == "replicated" for o in outs)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_prepass_sequence_world_4():
+    """Four ranks, seven columns: shards of two columns, the last one ragged (one column), and a rank's complement in
+    two pieces (columns before and after its shard); 11 pairs in blocks of 3, the last block short."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_sharding_worker, args=(4, _free_port(), d, "ok"), nprocs=4, join=True)
+        outs = [pickle.load(open(os.path.join(d, f"s{r}.pkl"), "rb")) for r in range(4)]
+    assert all(o["ok"] and o["mode"] == "sharded+allgather" and o["complete"] for o in outs)
+    assert [o["prepared"][0] for o in outs] == [(0, 2, 8), (2, 4, 8), (4, 6, 8), (6, 7, 8)]
+    assert outs[0]["expanded"] == [(2, 7)] and outs[3]["expanded"] == [(0, 6)]
+    assert outs[1]["expanded"] == [(0, 2), (4, 7)] and outs[2]["expanded"] == [(0, 4), (6, 7)]
+    for r, o in enumerate(outs):
+        assert np.array_equal(o["gather_all"][:, 0], np.arange(11.0))
+        assert (o["gather_root"] is None) == (r != 0)
+    assert np.array_equal(outs[0]["gather_root"][:, 3], np.arange(11.0))

@@ -107,9 +107,9 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   int np = half_ok ? 2 : 1;
   // few pairs: twice the waves hide the latency of a step better than two pairs per wave share their loads while
   // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
-  // 2 016 pairs, 0.255 vs 0.267 ms, two pairs per wave from 3 160 pairs on, 0.299 vs 0.350 ms; all 4 560 pairs:
-  // 0.352 vs 0.419 ms)
-  if (n_pairs <= (int64_t)10 * n_cu) np = 1;
+  // 780 pairs, 0.209 vs 0.230 ms, two pairs per wave from 1 128 pairs on, 0.231 vs 0.242 ms; all 4 560 pairs:
+  // 0.337 vs 0.416 ms)
+  if (n_pairs <= (int64_t)4 * n_cu) np = 1;
   {
     const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2) + icikt::K1_TL_BYTES;  // seen, pend, ppre + counts
     pl.pend_global = !half_ok && full * 20 > lds_cap;

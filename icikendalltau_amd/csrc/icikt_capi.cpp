@@ -98,7 +98,7 @@ struct K1Plan {
 K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
-  // n <= 14 272 (a half wave rebuilds a prefix with <= 7 words per lane): two pairs per wave, one per half,
+  // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per half,
   // pend in LDS.  Longer columns: one pair per wave on all 64 lanes (measured crossover between n = 10 000 and
   // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 20 waves per CU (n <~ 25 000), beyond
   // that the LDS state is what limits occupancy and pend moves to a per-wave slot in global memory (slower
@@ -137,7 +137,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2) + icikt::K1_HALF_PRE);  // seen, pend, ppre + prefix slots
+  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2) + icikt::k1_half_pre(pl.half_items));  // seen, pend, ppre + prefix slots
   else  // one pair per wave: seen [, pend], the two-level counts [, ppre]
     pl.perpair_bytes = (int)((size_t)pl.stride * (pl.pend_global ? 8 : (8 + 8 + 2)) + icikt::K1_TL_BYTES);
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));

@@ -79,14 +79,20 @@ struct PrepView {
 // one pair per wave: bytes of the counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32, locg 64 x 4 x u16)
 constexpr int K1_TL_BYTES = 2048 + 256 + 256 + 512;
 
-// half-wave kernels: bytes of a pair's prefix slots (32 lanes x 8 x u16, one aligned 16-byte slot per lane)
-constexpr int K1_HALF_PRE = 32 * 8 * 2;
+// half-wave kernels: bytes of a pair's prefix slots (32 lanes x one aligned slot of 8 u16 -- 16 u16 above 8 words per
+// lane)
+__host__ __device__ inline int k1_half_pre(int half_items) { return 32 * (half_items > 8 ? 16 : 8) * 2; }
 
-// half-wave K1 kernels exist for 1..7 words per lane of a half's prefix rebuild: n <= 14 272 (the packed in-step
-// compares of those kernels need positions below 2^14; 8 words per lane put the lanes' words at a 64-byte stride,
-// an 8-way LDS bank conflict per read: measured at half the speed of one pair per wave)
-constexpr int ICIKT_HALF_ITEMS_MAX = 7;
-__host__ __device__ inline int k1_half_items(int Wp) { return (Wp + 31) >> 5; }
+// half-wave K1 kernels exist for 1..7 and 9 words per lane of a half's prefix rebuild: n <= 18 336 (the packed
+// in-step compares of those kernels need positions below 2^15).  8 words per lane put the lanes' words at a 64-byte
+// stride, an 8-way LDS bank conflict per read (measured at half the speed of one pair per wave), so such columns
+// run the 9-word kernel.  11 and 13 words per lane were built and measured too: +2 % at n = 20 000, -6 % at 24 000
+// against one pair per wave (20 popcounts and more per rebuild, 2 waves per SIMD) -- not kept.
+constexpr int ICIKT_HALF_ITEMS_MAX = 9;
+__host__ __device__ inline int k1_half_items(int Wp) {
+  const int hi = (Wp + 31) >> 5;
+  return hi == 8 ? 9 : hi;
+}
 
 // Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan.  The
 // arrays are padded so that the hot steps' prefix rebuilds run without predicates:

@@ -907,7 +907,7 @@ __device__ __forceinline__ uint32_t half_partner_addr(uint32_t lane) {
 __device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane, uint32_t partner_addr) {
   const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
   const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
-  const uint32_t A = 0x3FFF3FFFu - Q, B = 0x40004000u + LO;
+  const uint32_t A = 0x7FFF7FFFu - Q, B = LO;
   const uint32_t offer = (lane & 16u) ? B : A;
   // the partners' offers come through the LDS crossbar (no memory is touched): the LDS unit has slack, the vector
   // unit has none (permlane16_swap + rotate + select were 7 issue slots)
@@ -1156,12 +1156,12 @@ __device__ __forceinline__ uint32_t half_incl_scan(uint32_t v) {
 // values at a stride of 2*HI bytes made one misaligned 8-byte store plus a 2-byte one, and that store alone kept
 // the LDS unit busy.  Word w lives in slot w / HI, entry w % HI.  A query is
 // `entry - popcount(word >> bit)`: the shift takes its count from the low six bits of the position, no mask is built.
-constexpr int K1_HALF_SLOT = 8;                       // u16 entries per lane slot
-constexpr int K1_HALF_PRE_BYTES = 32 * K1_HALF_SLOT * 2;
+template <int HI> constexpr int k1_half_slot() { return HI > 8 ? 16 : 8; }   // u16 entries per lane slot
+template <int HI> constexpr int k1_half_pre_bytes() { return 32 * k1_half_slot<HI>() * 2; }
 template <int HI>
 __device__ __forceinline__ uint32_t half_pre_index(uint32_t w) {
   const uint32_t o = w / (uint32_t)HI;
-  return o * (uint32_t)K1_HALF_SLOT + (w - o * (uint32_t)HI);
+  return o * (uint32_t)k1_half_slot<HI>() + (w - o * (uint32_t)HI);
 }
 template <int HI>
 __device__ __forceinline__ uint32_t prefix_query_half(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
@@ -1174,15 +1174,16 @@ template <int HI>
 __device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32_t incl, const uint32_t (&cw)[HI]) {
   const uint32_t excl = incl - cw[HI - 1];
   const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: counts < 2^14)
-  uint32_t v[4] = {0u, 0u, 0u, 0u};
+  uint32_t v[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     if (HI == 2 * i + 1) v[i] = incl;                                     // the lane's last word, alone in its dword
     if (HI >= 2 * i + 2) v[i] = pack16(cw[(2 * i + 1) % HI], cw[(2 * i) % HI]) + both;
   }
-  uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)K1_HALF_SLOT);
-  if (HI > 4) *slot = make_uint4(v[0], v[1], v[2], v[3]);
+  uint4* slot = reinterpret_cast<uint4*>(pre + l * (uint32_t)k1_half_slot<HI>());
+  if (HI > 4) slot[0] = make_uint4(v[0], v[1], v[2], v[3]);
   else *reinterpret_cast<uint2*>(slot) = make_uint2(v[0], v[1]);
+  if (HI > 8) slot[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
 template <int HI>
 __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bits, uint16_t* pre, uint32_t l) {
@@ -1518,8 +1519,8 @@ __device__ __forceinline__ SegCounts half_mixed64_corr(const unsigned long long 
   }
   uint32_t spur_tie = 0;   // row layout: pair 0's counts in bits 0..15, pair 1's in bits 16..31 (spur | tie << 8)
   if (dmax > 0) {
-    const uint32_t X0 = 0x40003FFFu + (v0 & 0xFFFF0000u) - (v0 & 0xFFFFu);
-    const uint32_t X1 = 0x40003FFFu + (v1 & 0xFFFF0000u) - (v1 & 0xFFFFu);
+    const uint32_t X0 = 0x00007FFFu + (v0 & 0xFFFF0000u) - (v0 & 0xFFFFu);
+    const uint32_t X1 = 0x00007FFFu + (v1 & 0xFFFF0000u) - (v1 & 0xFFFFu);
     const uint32_t Y0 = __builtin_amdgcn_alignbit(X0, X0, 16), Y1 = __builtin_amdgcn_alignbit(X1, X1, 16);
     const uint32_t M16 = 0x80008000u;
     // one vector holds 16 distances (a 17th shift would move the upper flags into the lower half): distances
@@ -1669,7 +1670,7 @@ __device__ __attribute__((noinline)) void seg_group_close(const SegState st, con
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, bool PG, int HI>
-__global__ void __launch_bounds__(512, (HI > 5 ? 4 : 6))  // 6 waves per SIMD (<= 80 VGPRs); HI > 5: the LDS state allows 4
+__global__ void __launch_bounds__(512, (HI > 8 ? 3 : HI > 5 ? 4 : 6))  // 6 waves per SIMD (<= 80 VGPRs); HI > 5 / > 8: the LDS state allows 4 / 3
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
          int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
@@ -1790,10 +1791,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // half-wave kernels: seen | pend | prefix slots of seen (32 lanes x 16 B) | ppre
       Pg[k].bits = S[k].L.seen + Wp4;
       S[k].L.spre = reinterpret_cast<uint16_t*>(Pg[k].bits + Wp4);
-      Pg[k].pre16 = S[k].L.spre + K1_HALF_PRE_BYTES / 2;
+      Pg[k].pre16 = S[k].L.spre + k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2;
       Pg[k].pre = nullptr;
       for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; Pg[k].pre16[w] = 0; }
-      for (int w = lane; w < K1_HALF_PRE_BYTES / 2; w += 64) S[k].L.spre[w] = 0;
+      for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
@@ -1903,12 +1904,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // (addresses in bytes: slot w / H at 16 bytes, entry w % H at 2 -> 2 w + (16 - 2 H) (w / H); the word index of q
         //  is a bit field of the gathered value)
         const uint32_t wlo = r >> 22;
-        const uint32_t dlo = (wlo * (65536u / (uint32_t)H + 1u)) >> 16;     // w / H for w < 256, H <= 7
+        const uint32_t dlo = (wlo * (65536u / (uint32_t)H + 1u)) >> 16;     // w / H for w < 32 H, H <= 13
         const uint32_t pre_lo = (uint32_t)*reinterpret_cast<const uint16_t*>(
-            reinterpret_cast<const unsigned char*>(spreH) + 2u * wlo + (16u - 2u * (uint32_t)H) * dlo);
+            reinterpret_cast<const unsigned char*>(spreH) + 2u * wlo + (2u * (uint32_t)k1_half_slot<H>() - 2u * (uint32_t)H) * dlo);
         const unsigned long long word_lo = seenH[wlo];
         wave_lds_fence();
-        atomicOr(reinterpret_cast<uint32_t*>(seenH) + __builtin_amdgcn_ubfe(r, 5, 9), 1u << (qh & 31u));
+        atomicOr(reinterpret_cast<uint32_t*>(seenH) + __builtin_amdgcn_ubfe(r, 5, 10), 1u << (qh & 31u));
         wave_lds_fence();
         unsigned long long wv[H];
 #pragma unroll
@@ -2768,6 +2769,7 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       case 5: return &k1_pairs<2, false, 5>;
       case 6: return &k1_pairs<2, false, 6>;
       case 7: return &k1_pairs<2, false, 7>;
+      case 9: return &k1_pairs<2, false, 9>;
       default: break;
     }
   }

@@ -168,6 +168,31 @@ def test_half_wave_six_and_seven_words_per_lane(plan_ctx, n):
             assert float(np.nanmax(np.abs(out - ref))) <= ATOL
 
 
+@pytest.mark.parametrize("n", [14273, 16320, 16321, 17000, 18336, 18337])
+def test_half_wave_nine_words_per_lane(plan_ctx, n):
+    """k1_pairs<2, false, 9> (14 273 .. 18 336 rows; eight words per lane run the nine-word kernel), 15-bit fields in
+    the packed in-step compares, 32-byte prefix slots; and the first length past it (one pair per wave)."""
+    rng = np.random.default_rng(n)
+    S = 6
+    X = rng.standard_normal((n, S))
+    X[:, 2] = np.round(X[:, 2] * 500)
+    X[:, 4] = np.round(X[:, 4] * 3)
+    k = n // 15
+    idx = np.argpartition(X, k, axis=0)[:k]
+    np.put_along_axis(X, idx, np.nan, axis=0)
+    X[rng.random(n) < 0.25, 5] = np.nan
+    O = _oracle()
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    for plan in ({"np": 2}, None):
+        plan_ctx.debug_set_plan(plan)
+        for perspective in ("global", "local"):
+            out, cnt, rsn = plan_ctx.pairs(X, perspective=perspective)
+            ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, perspective)
+            assert np.array_equal(rsn, rrsn)
+            assert np.array_equal(cnt, rcnt[:, :cnt.shape[1]])
+            assert float(np.nanmax(np.abs(out - ref))) <= ATOL
+
+
 def test_half_wave_five_words_natural_plan(hip_ctx):
     """10 000 x 128 = 8 128 pairs: enough pairs for the plan to choose two pairs per wave by itself."""
     from bench import make_matrix

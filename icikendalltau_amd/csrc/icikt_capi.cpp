@@ -100,7 +100,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   const size_t lds_cap = 160 * 1024;
   // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per half,
   // pend in LDS.  Longer columns: one pair per wave on all 64 lanes (measured crossover between n = 10 000 and
-  // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 20 waves per CU (n <~ 25 000), beyond
+  // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 12 waves per CU (n <~ 32 000), beyond
   // that the LDS state is what limits occupancy and pend moves to a per-wave slot in global memory (slower
   // steps when the streamed column has tie groups).
   const bool half_ok = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
@@ -112,7 +112,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   if (n_pairs <= (int64_t)4 * n_cu) np = 1;
   {
     const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2) + icikt::K1_TL_BYTES;  // seen, pend, ppre + counts
-    pl.pend_global = !half_ok && full * 20 > lds_cap;
+    pl.pend_global = !half_ok && full * 12 > lds_cap;   // measured: LDS wins at 20 000 (+10 %) and 30 000, global from 35 000 on
   }
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable);
   // a plan without a kernel variant falls back to one pair per wave

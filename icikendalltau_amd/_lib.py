@@ -48,6 +48,7 @@ EXPORTS = (
     "icikt_pair_f64", "icikt_pairs_complete_f64", "icikt_missingness_f64", "icikt_selftest", "icikt_debug_set_plan",
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
+    "icikt_matrix_f64", "icikt_matrix_multi_f64", "icikt_multi_rank_phase_ms", "icikt_multi_ranks_used",
 )
 
 
@@ -142,6 +143,11 @@ def lib():
     L.icikt_pairs_multi_f64.argtypes = L.icikt_pairs_f64.argtypes
     L.icikt_multi_phase_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double)]
     L.icikt_multi_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
+    L.icikt_matrix_f64.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int,
+                                   c_u32, c_int, c_int, c_vp, c_vp, c_vp]
+    L.icikt_matrix_multi_f64.argtypes = L.icikt_matrix_f64.argtypes
+    L.icikt_multi_rank_phase_ms.argtypes = [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]
+    L.icikt_multi_ranks_used.argtypes = [c_vp]
     for name in EXPORTS:
         if getattr(L, name).restype is not None and name not in ("icikt_last_error", "icikt_num_pairs",
                                                                    "icikt_multi_last_error"):
@@ -158,6 +164,30 @@ def device_count() -> int:
 
 def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _matrix_call(fn, handle, chk, X, global_na, pi, pj, perspective, alternative, continuity, flags, scale_max,
+                 diag_good, want_keep):
+    """icikt_matrix_f64 / icikt_matrix_multi_f64: (out5 [5, S, S], keep [S, n_feat] bool or None, reason_counts [5])."""
+    if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.f_contiguous):
+        X = np.asfortranarray(X, dtype=np.float64)
+    n_feat, n_samp = X.shape
+    gna = np.ascontiguousarray([] if global_na is None else np.atleast_1d(global_na), dtype=np.float64)
+    if pi is None:
+        pi_a = pj_a = None
+        P = 0
+    else:
+        pi_a = np.ascontiguousarray(pi, dtype=np.int32)
+        pj_a = np.ascontiguousarray(pj, dtype=np.int32)
+        P = pi_a.shape[0]
+    out5 = np.empty((5, n_samp, n_samp), dtype=np.float64)
+    keep = np.empty((n_samp, n_feat), dtype=np.uint8) if want_keep else None
+    rc5 = np.zeros(5, dtype=np.int64)
+    alt = ALTERNATIVE.get(alternative, ALT_OTHER)
+    chk(fn(handle, _ptr(X), n_feat, n_samp, max(n_feat, 0), _ptr(gna) if gna.size else None, int(gna.size), _ptr(pi_a),
+           _ptr(pj_a), P, PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, int(bool(scale_max)),
+           int(bool(diag_good)), _ptr(out5), _ptr(keep), _ptr(rc5)), fn.__name__)
+    return out5, (keep.view(np.bool_) if keep is not None else None), rc5
 
 
 class Context:
@@ -290,6 +320,14 @@ class Context:
                                         _ptr(cnt), _ptr(rsn)), "icikt_pairs_f64")
         return out, cnt, rsn
 
+    def matrix(self, X, global_na=None, pi=None, pj=None, perspective="global", alternative="two.sided",
+               continuity=False, flags: int = 0, scale_max=True, diag_good=True, want_keep=True):
+        """ici_kendalltau() below its argument checks in ONE call (icikt_matrix_f64): the exclusion rule, the pair
+        kernels and scale_and_reshape all run on the device.  X: raw data (features x samples, F-ordered float64 is
+        taken as is); global_na: the values setup_missing_matrix excludes (NaN = NA, Inf, finite values)."""
+        return _matrix_call(lib().icikt_matrix_f64, self._h, self._chk, X, global_na, pi, pj, perspective, alternative,
+                            continuity, flags, scale_max, diag_good, want_keep)
+
     def pairs_complete(self, X, pi, pj, alternative="two.sided", continuity=False, flags: int = 0,
                        want_counts: bool = False):
         """kt_fast(use = "pairwise.complete.obs"): per pair, rows with a missing value in either vector are dropped."""
@@ -376,9 +414,30 @@ class MultiContext:
         self._chk(lib().icikt_multi_debug_set_plan(self._h, (spec or "").encode()), "icikt_multi_debug_set_plan")
 
     def phase_ms(self) -> dict:
+        """Phases of the last call, the maximum over the ranks."""
         ms = (ctypes.c_double * len(MULTI_PHASES))()
         self._chk(lib().icikt_multi_phase_ms(self._h, ms), "icikt_multi_phase_ms")
         return dict(zip(MULTI_PHASES, list(ms)))
+
+    def rank_phase_ms(self) -> list:
+        """Per rank: its own phases and the time it waited for the others at the barriers ("wait")."""
+        out = []
+        for r in range(len(self.devices)):
+            ms = (ctypes.c_double * (len(MULTI_PHASES) + 1))()
+            self._chk(lib().icikt_multi_rank_phase_ms(self._h, r, ms), "icikt_multi_rank_phase_ms")
+            out.append(dict(zip(MULTI_PHASES + ("wait",), list(ms))))
+        return out
+
+    @property
+    def ranks_used(self) -> int:
+        """Ranks the last call really used (1: too small to split, or wide columns: the first device alone)."""
+        return int(lib().icikt_multi_ranks_used(self._h))
+
+    def matrix(self, X, global_na=None, pi=None, pj=None, perspective="global", alternative="two.sided",
+               continuity=False, flags: int = 0, scale_max=True, diag_good=True, want_keep=True):
+        """Same contract as Context.matrix()."""
+        return _matrix_call(lib().icikt_matrix_multi_f64, self._h, self._chk, X, global_na, pi, pj, perspective,
+                            alternative, continuity, flags, scale_max, diag_good, want_keep)
 
     def pairs(self, X, pi=None, pj=None, perspective="global", alternative="two.sided", continuity=False,
               flags: int = 0, want_counts: bool = True):

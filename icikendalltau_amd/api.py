@@ -51,6 +51,13 @@ class HipEngine:
     def missingness(self, X, pi, pj):
         return self.ctx.missingness(X, pi, pj)
 
+    def matrix(self, data_matrix, global_na, pi, pj, perspective, alternative, continuity, scale_max, diag_good):
+        """The whole of ici_kendalltau() below its argument checks in one library call (icikt_matrix_f64 /
+        icikt_matrix_multi_f64): exclusion rule, pair kernels and scale_and_reshape on the device.  Returns
+        (out5 [5, S, S]: cor, raw, pvalue, taumax, completeness; keep [S, n_feat] bool; pairs per reason code [5])."""
+        return self.ctx.matrix(data_matrix, global_na, pi, pj, perspective, alternative, continuity, self.flags,
+                               scale_max, diag_good, want_keep=True)
+
     def pairs_complete(self, X, pi, pj):
         """kt_fast(use = "pairwise.complete.obs") on the device: (out4, reasons)."""
         out, _cnt, rsn = self.ctx.pairs_complete(X, pi, pj, "two.sided", False, self.flags)
@@ -310,18 +317,29 @@ def setup_comparisons(samples, include_only=None, diag_good=True, ncore=1, inclu
             include_only = list(include_only.values())
         if _is_vector_like(include_only):
             inc = {_r_str(v) for v in np.atleast_1d(np.asarray(include_only, dtype=object))}
-            s1_in = np.fromiter((names[i] in inc for i in pi), dtype=bool, count=len(pi))
-            s2_in = np.fromiter((names[j] in inc for j in pj), dtype=bool, count=len(pj))
-            keep = s1_in | s2_in  # R/kendalltau.R:210-212
+            col_in = np.fromiter((nm in inc for nm in names), dtype=bool, count=n_sample)   # per SAMPLE, not per pair
+            keep = col_in[pi] | col_in[pj]  # R/kendalltau.R:210-212
         elif isinstance(include_only, (list, tuple)):
             if len(include_only) == 2:
                 l1 = [_r_str(v) for v in np.atleast_1d(np.asarray(include_only[0], dtype=object))]
                 l2 = [_r_str(v) for v in np.atleast_1d(np.asarray(include_only[1], dtype=object))]
                 m = max(len(l1), len(l2))
                 l1r, l2r = _recycle(l1, m), _recycle(l2, m)  # paste0 recycles
-                allowed = {f"{a}-{b}" for a, b in zip(l1r, l2r)} | {f"{b}-{a}" for a, b in zip(l1r, l2r)}
-                keep = np.fromiter((f"{names[i]}-{names[j]}" in allowed for i, j in zip(pi, pj)), dtype=bool,
-                                   count=len(pi))
+                # "a-b" strings of the reference (:213-229) as index pairs: a listed name that is no sample matches
+                # nothing; names holding "-" could make two different name pairs paste to one string -- those lists
+                # keep the reference's string comparison
+                if any("-" in str(nm) for nm in names) or any("-" in v for v in l1r + l2r):
+                    allowed = {f"{a}-{b}" for a, b in zip(l1r, l2r)} | {f"{b}-{a}" for a, b in zip(l1r, l2r)}
+                    keep = np.fromiter((f"{names[i]}-{names[j]}" in allowed for i, j in zip(pi, pj)), dtype=bool,
+                                       count=len(pi))
+                else:
+                    index = {str(nm): k for k, nm in reversed(list(enumerate(names)))}   # first occurrence wins
+                    ia = np.array([index.get(a, -1) for a in l1r], dtype=np.int64)
+                    ib = np.array([index.get(b, -1) for b in l2r], dtype=np.int64)
+                    ok = (ia >= 0) & (ib >= 0)
+                    ia, ib = ia[ok], ib[ok]
+                    codes = np.concatenate([ia * n_sample + ib, ib * n_sample + ia])
+                    keep = np.isin(pi.astype(np.int64) * n_sample + pj, codes)
             else:
                 raise ValueError(
                     f"`{include_arg}` must be a vector, a data.frame with two columns, or list of two vectors. "
@@ -414,9 +432,7 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
     for a bare ndarray).
     """
     data_matrix, names = _as_matrix(data_matrix, colnames, "data_matrix")
-    exclude_loc = setup_missing_matrix(data_matrix, global_na)
-    exclude_data = _masked_fortran(data_matrix, exclude_loc)
-    n_sample = exclude_data.shape[1]
+    n_sample = data_matrix.shape[1]
 
     _dist, _rank, world = _dist_info()
     ncore = world
@@ -424,6 +440,34 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
         engine = _multi_engine(n_gpu, devices)
         ncore = len(engine.ctx.devices)
     eng = engine or _default_engine()
+
+    if return_matrix and not check_timing and world == 1 and hasattr(eng, "matrix"):
+        # One library call does everything below the argument checks on the device (icikt_matrix_f64): the exclusion
+        # rule of setup_missing_matrix inside the pre-pass (no masked copy of the matrix on the host), the pair
+        # kernels, scale_and_reshape, one copy of the five matrices back.  All pairs of the upper triangle need no
+        # pair list at all; include_only / diag_good = FALSE hand over the filtered list.
+        if include_only is None and diag_good:
+            if n_sample < 2:
+                raise ValueError("No comparisons to do. Check the list of column names in "
+                                 "`include_only` vs those in the samples.")  # R/kendalltau.R:240-247
+            pi = pj = None
+        else:
+            pi, pj, _core = setup_comparisons(names, include_only, diag_good, ncore=ncore)
+        t1 = time.perf_counter()
+        out5, keep, rcounts = eng.matrix(data_matrix, global_na, pi, pj, perspective, alternative, continuity,
+                                         scale_max, diag_good)
+        t_diff = time.perf_counter() - t1
+        for code in (_lib.REASON_SHORT, _lib.REASON_SINGLE_UNIQUE, _lib.REASON_TIES_EQ_TOTAL):
+            for _ in range(int(rcounts[code])):   # one warning per offending pair, as ici_split raises them
+                _warn_reason(code)
+        res = {key: _named_matrix(out5[k], names)
+               for k, key in enumerate(("cor", "raw", "pvalue", "taumax", "completeness"))}
+        res["keep"] = keep
+        res["run_time"] = t_diff
+        return res
+
+    exclude_loc = setup_missing_matrix(data_matrix, global_na)
+    exclude_data = _masked_fortran(data_matrix, exclude_loc)
     pi, pj, core = setup_comparisons(names, include_only, diag_good, ncore=ncore)
     n_todo = len(pi)
 

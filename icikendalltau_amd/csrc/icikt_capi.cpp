@@ -284,6 +284,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
+  c->d_out5.release(); c->d_keep.release(); c->d_red.release(); c->d_pi_all.release(); c->d_pj_all.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
     for (auto& p : c->ev_pool[k]) {
       if (p.a) (void)hipEventDestroy(p.a);
@@ -424,7 +425,7 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
     const int64_t chunk = std::max(1, c->sort_chunk);
     for (int64_t c0 = col_begin; c0 < col_end; c0 += chunk) {
       const int nc = (int)std::min<int64_t>(chunk, col_end - c0);
-      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->stream));
+      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->k0_mask, c->k0_keep, c->stream));
     }
   }
   return ICIKT_SUCCESS;
@@ -650,6 +651,9 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
       const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
       const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
       blocks = (int)std::min<int64_t>(want, mult * resident);
+      // test hook: a grid far smaller than the task list makes every persistent wave run many tasks in a row
+      // (slot reuse, the per-XCD task counters, the in-order fetch) whatever the chip would hold
+      if (c->plan_ov.grid_cap > 0) blocks = std::min(blocks, c->plan_ov.grid_cap);
     }
     blocks = std::max(blocks, 1);
     if (c->plan_ov.verbose)
@@ -712,14 +716,48 @@ int icikt_reset_timers(icikt_ctx* c) {
 namespace icikt {
 namespace host {
 
+// true when the byte at p lies in host memory that is page-locked already (hipHostRegister or hipHostMalloc by the caller)
+static bool pinned_already(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();   // plain malloc memory: "invalid value" on this runtime
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
+  if (c->force_reg_fail) return HostLock::Refused;
+  if (hipHostRegister(const_cast<void*>(p), bytes, flags) == hipSuccess) return HostLock::Locked;
+  (void)hipGetLastError();
+  // refused: fine if the caller has page-locked the range itself -- every probe of it (both ends and one per MB) must
+  // say so; anything else goes through the library's own pinned buffers
+  bool all = pinned_already(p) && pinned_already(static_cast<const char*>(p) + bytes - 1);
+  for (size_t off = (size_t)1 << 20; all && off < bytes; off += (size_t)1 << 20)
+    all = pinned_already(static_cast<const char*>(p) + off);
+  return all ? HostLock::Already : HostLock::Refused;
+}
+
+int ensure_bounce(icikt_ctx* c, size_t need) {
+  if (c->pinned_bytes >= need) return ICIKT_SUCCESS;
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  c->pinned = nullptr;
+  c->pinned_bytes = 0;
+  HIPCHK(c, hipHostMalloc(&c->pinned, need, hipHostMallocDefault));
+  c->pinned_bytes = need;
+  return ICIKT_SUCCESS;
+}
+
 // H2D of columns [col_begin, col_end) + K0 over them.  The copies run on the context's copy stream in column
 // chunks and K0 of a chunk waits only for its own chunk (an event per chunk), so the pre-pass of chunk i runs
 // while chunk i + 1 crosses PCIe.  The source is the caller's (pageable) matrix:
 //   mode 1 (default)  the source range is page-locked for the duration of the call (hipHostRegister): the copies
-//                     are true DMA from the caller's memory, no staging copy; falls back to mode 0 if refused
-//   mode 0            pageable copies (the runtime stages them through its own pinned buffers)
+//                     are true DMA from the caller's memory, no staging copy.  Refused because the caller has
+//                     page-locked it already: the same copies; refused for any other reason: mode 2
 //   mode 2            staged by this library through a pinned double buffer (a host memcpy per chunk)
 //   mode 3            the matrix is page-locked already (by the multi-device driver, once for all devices)
+//   mode 0            pageable copies through the runtime's own staging path: only for matrices below kLockMin
+//                     bytes, never selected for larger ones (icikt_host.h)
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
                        int64_t col_end, uint32_t flags, const void** deferred_unregister) {
   if (deferred_unregister) *deferred_unregister = nullptr;
@@ -735,23 +773,16 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
     const double* src0 = X + col_begin * ld;
     const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
-    // default: page-lock the source unless it is small enough for the runtime's staging path (see kLockMin in
-    // icikt_host.h: HIP's own pinning of pageable memory is what this avoids); mode 3 = the caller of
-    // this function has page-locked the matrix already (icikt_multi: once for all devices)
-    int mode = c->h2d_mode < 0 ? ((span >= kLockMin) ? 1 : 0) : c->h2d_mode;
+    int mode = (span < kLockMin) ? 0 : (c->h2d_mode < 0 ? 1 : c->h2d_mode);
     bool registered = false;
     if (mode == 1) {
-      registered = hipHostRegister(const_cast<double*>(src0), span, hipHostRegisterDefault) == hipSuccess;
-      if (!registered) { (void)hipGetLastError(); mode = 0; }
+      const HostLock lk = lock_host(c, src0, span, hipHostRegisterDefault);
+      registered = lk == HostLock::Locked;
+      if (lk == HostLock::Refused) mode = 2;   // never a copy from pageable memory of this size
     }
     if (mode == 2) {
-      const size_t need = 2 * (size_t)chunk * col_bytes;
-      if (c->pinned_bytes < need) {
-        if (c->pinned) (void)hipHostFree(c->pinned);
-        c->pinned = nullptr; c->pinned_bytes = 0;
-        if (hipHostMalloc(&c->pinned, need, hipHostMallocDefault) == hipSuccess) c->pinned_bytes = need;
-        else { (void)hipGetLastError(); mode = 0; }
-      }
+      rc = ensure_bounce(c, 2 * (size_t)chunk * col_bytes);
+      if (rc) return rc;
     }
     // the copy stream must not overwrite d_X while earlier work on the compute stream still reads it
     hipError_t e = hipEventRecord(c->ev_copy[0], c->stream);
@@ -779,8 +810,9 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
       // the caller goes on with host work while the copies run, and ends the registration itself
       // (finish_upload) once it has waited for them
       *deferred_unregister = src0;
-    } else if (registered || mode == 0 || e != hipSuccess || rc) {
-      // the caller's buffer must stay page-locked (and alive) until the last copy has read it
+    } else if (registered || mode == 0 || mode == 2 || e != hipSuccess || rc) {
+      // the caller's buffer must stay page-locked (and alive) until the last copy has read it; the staging buffer
+      // of mode 2 serves the later transfers of the call as their bounce buffer
       (void)hipStreamSynchronize(c->copy_stream);
       if (registered) (void)hipHostUnregister(const_cast<double*>(src0));
     }
@@ -806,11 +838,25 @@ void prebuild_units(icikt_ctx* c) {
 
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
-  const bool locked = bytes >= kLockMin && hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterDefault) == hipSuccess;
-  if (bytes >= kLockMin && !locked) (void)hipGetLastError();   // e.g. already page-locked by the caller: fine
+  const HostLock lk = bytes >= kLockMin ? lock_host(c, src, bytes, hipHostRegisterDefault) : HostLock::Already;
+  if (lk == HostLock::Refused) {
+    // through the library's pinned bounce buffer, a chunk at a time
+    const size_t cap = (size_t)8 << 20;
+    int rc = ensure_bounce(c, std::min(bytes, cap));
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += cap) {
+      const size_t m = std::min(cap, bytes - off);
+      memcpy(c->pinned, static_cast<const char*>(src) + off, m);
+      hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, c->pinned, m, hipMemcpyHostToDevice, c->stream);
+      const hipError_t es = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = es;
+      if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D copy (staged): ") + hipGetErrorString(e));
+    }
+    return ICIKT_SUCCESS;
+  }
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   const hipError_t es = hipStreamSynchronize(c->stream);       // the host range must outlive the copy
-  if (locked) (void)hipHostUnregister(const_cast<void*>(src));
+  if (lk == HostLock::Locked) (void)hipHostUnregister(const_cast<void*>(src));
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D copy: ") + hipGetErrorString(e));
   return ICIKT_SUCCESS;
@@ -819,16 +865,30 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
   if (bytes >= kLockMin) {
-    if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) c->locked_out.push_back(dst);
-    else (void)hipGetLastError();                              // already page-locked (caller, or an overlapping range)
+    const HostLock lk = lock_host(c, dst, bytes, hipHostRegisterDefault);
+    if (lk == HostLock::Locked) c->locked_out.push_back(dst);
+    if (lk == HostLock::Refused) {
+      // into a pinned allocation of the library's; finish_downloads() moves it to the caller's array
+      icikt_ctx::Bounce b{nullptr, dst, bytes};
+      HIPCHK(c, hipHostMalloc(&b.pinned, bytes, hipHostMallocDefault));
+      c->bounced_out.push_back(b);
+      HIPCHK(c, hipMemcpyAsync(b.pinned, src, bytes, hipMemcpyDeviceToHost, c->stream));
+      return ICIKT_SUCCESS;
+    }
   }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   return ICIKT_SUCCESS;
 }
 
-void finish_downloads(icikt_ctx* c) {
+// (the stream has been synchronised; `ok` = it ended without an error, i.e. the bounced bytes are the results)
+void finish_downloads(icikt_ctx* c, bool ok) {
   for (void* p : c->locked_out) (void)hipHostUnregister(p);
   c->locked_out.clear();
+  for (auto& b : c->bounced_out) {
+    if (ok) memcpy(b.dst, b.pinned, b.bytes);
+    (void)hipHostFree(b.pinned);
+  }
+  c->bounced_out.clear();
 }
 
 }  // namespace host
@@ -908,12 +968,123 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
   rc = body();
   // success or not: nothing may still be reading or writing the caller's buffers when this returns
   const hipError_t es = hipStreamSynchronize(c->stream);
-  icikt::host::finish_downloads(c);
+  icikt::host::finish_downloads(c, rc == 0 && es == hipSuccess);
   finish_upload();
   if (rc) return rc;
   if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(es));
   return ICIKT_SUCCESS;
 }
+
+}  // extern "C"
+
+namespace icikt {
+namespace host {
+
+// global_na (R/utils.R:1-23) -> the pre-pass's exclusion rule
+int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt::MaskSpec* ms) {
+  *ms = icikt::MaskSpec{};
+  if (n_global_na < 0 || (n_global_na > 0 && !global_na)) return fail(c, ICIKT_E_INVALID, "matrix: bad global_na");
+  for (int k = 0; k < n_global_na; ++k) {
+    const double v = global_na[k];
+    if (v != v) ms->mask_nan = 1;
+    else if (v - v != 0.0) ms->mask_inf = 1;   // +-Inf
+    else {
+      bool dup = false;
+      for (int q = 0; q < ms->n_vals; ++q) dup = dup || ms->vals[q] == v;
+      if (dup) continue;
+      if (ms->n_vals == icikt::ICIKT_MASK_VALS)
+        return fail(c, ICIKT_E_INVALID, "matrix: more than 6 finite values in global_na");
+      ms->vals[ms->n_vals++] = v;
+    }
+  }
+  return ICIKT_SUCCESS;
+}
+
+}  // namespace host
+}  // namespace icikt
+
+extern "C" {
+
+// ici_kendalltau() below the argument checks, in one call: exclusion rule + pre-pass + pair kernel + epilogue +
+// scale_and_reshape on the device, one D2H of the five matrices.
+int icikt_matrix_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, const double* global_na,
+                     int n_global_na, const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective,
+                     int alternative, int continuity, uint32_t flags, int scale_max, int diag_good, double* out5,
+                     uint8_t* keep, int64_t* reason_counts) {
+  if (!c) return ICIKT_E_INVALID;
+  int rc = check_shape(c, "matrix", n_feat, n_samp, ld);
+  if (rc) return rc;
+  if (n_feat > 0 && n_samp > 0 && !X) return fail(c, ICIKT_E_INVALID, "matrix: null matrix");
+  if (pi == nullptr) {
+    if (pj != nullptr) return fail(c, ICIKT_E_INVALID, "matrix: pi is null but pj is not");
+    n_pairs = n_samp * (n_samp - 1) / 2;
+  } else {
+    rc = check_pair_list(c, "matrix", pi, pj, n_pairs, n_samp);
+    if (rc) return rc;
+  }
+  if (n_samp > 0 && !out5) return fail(c, ICIKT_E_INVALID, "matrix: null output");
+  if (perspective != ICIKT_PERSPECTIVE_LOCAL && perspective != ICIKT_PERSPECTIVE_GLOBAL)
+    return fail(c, ICIKT_E_INVALID, "matrix: perspective must be local (0) or global (1)");
+  if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return fail(c, ICIKT_E_INVALID, "matrix: bad alternative code");
+  icikt::MaskSpec ms;
+  rc = icikt::host::make_mask_spec(c, global_na, n_global_na, &ms);
+  if (rc) return rc;
+  if (reason_counts) for (int k = 0; k < 5; ++k) reason_counts[k] = 0;
+  if (n_samp == 0) return ICIKT_SUCCESS;
+  rc = use_device(c);
+  if (rc) return rc;
+  rc = pi ? icikt_set_pairs(c, pi, pj, n_pairs) : icikt_set_pairs_combn(c, n_samp, 0, n_pairs);
+  if (rc) return rc;
+  rc = prepare_alloc(c, n_feat, n_samp, n_samp, n_samp);
+  if (rc) return rc;
+  const size_t S = (size_t)n_samp, P = (size_t)c->n_pairs;
+  const size_t keep_bytes = keep ? S * (size_t)n_feat : 0;
+  if (keep_bytes) HIPCHK(c, c->d_keep.reserve(keep_bytes));
+  HIPCHK(c, c->d_out5.reserve(5 * S * S));
+  HIPCHK(c, c->d_red.reserve(8));
+  HIPCHK(c, c->d_out4.reserve(std::max<size_t>(P, 1) * 4));
+  HIPCHK(c, c->d_reasons.reserve(std::max<size_t>(P, 1)));
+  const void* registered_src = nullptr;
+  c->k0_mask = &ms;
+  c->k0_keep = keep_bytes ? c->d_keep.p : nullptr;
+  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags, &registered_src);
+  c->k0_mask = nullptr;
+  c->k0_keep = nullptr;
+  auto finish_upload = [&]() {
+    if (registered_src) {
+      (void)hipStreamSynchronize(c->copy_stream);
+      (void)hipHostUnregister(const_cast<void*>(registered_src));
+      registered_src = nullptr;
+    }
+  };
+  if (rc) { finish_upload(); return rc; }
+  c->prepared = true;
+  icikt::host::prebuild_units(c);
+  unsigned long long red[8] = {};
+  auto body = [&]() -> int {
+    int r = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, nullptr, c->d_reasons.p);
+    if (r) return r;
+    HIPCHK(c, icikt::launch_out_stats(c->pv, c->d_out4.p, c->d_reasons.p, (int64_t)P, nullptr, c->d_red.p, c->stream));
+    HIPCHK(c, icikt::launch_assemble(c->pv, c->d_out4.p, c->d_pi.p, c->d_pj.p, (int64_t)P, nullptr, c->d_red.p,
+                                     scale_max ? 1 : 0, diag_good ? 1 : 0, c->d_out5.p, c->stream));
+    r = icikt::host::download(c, out5, c->d_out5.p, 5 * S * S * sizeof(double));
+    if (!r && keep_bytes) r = icikt::host::download(c, keep, c->d_keep.p, keep_bytes);
+    if (!r) r = icikt::host::download(c, red, c->d_red.p, sizeof(red));
+    return r;
+  };
+  rc = body();
+  const hipError_t es = hipStreamSynchronize(c->stream);
+  icikt::host::finish_downloads(c, rc == 0 && es == hipSuccess);
+  finish_upload();
+  if (rc) return rc;
+  if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("matrix: ") + hipGetErrorString(es));
+  if (reason_counts) for (int k = 0; k < 5; ++k) reason_counts[k] = (int64_t)red[1 + k];
+  return ICIKT_SUCCESS;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // kt_fast(use = "pairwise.complete.obs"): every pair gets its own two columns with the rows that miss either value
 // masked in both (k_mask_pairs), sorted (K0) and counted (K1, one pair per wave) on the device; the perspective is
@@ -972,14 +1143,17 @@ int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int6
       if (!r && counts) r = icikt::host::download(c, counts + ICIKT_CNT_FIELDS * first, c->d_counts.p, (size_t)m * ICIKT_CNT_FIELDS * sizeof(int64_t));
       if (!r && reasons) r = icikt::host::download(c, reasons + first, c->d_reasons.p, (size_t)m * sizeof(int32_t));
       if (r) return r;
-      HIPCHK(c, hipStreamSynchronize(c->stream));  // the chunk's buffers are reused by the next one
-      icikt::host::finish_downloads(c);
+      {  // the chunk's buffers are reused by the next one
+        const hipError_t ec = hipStreamSynchronize(c->stream);
+        icikt::host::finish_downloads(c, ec == hipSuccess);
+        HIPCHK(c, ec);
+      }
     }
     return ICIKT_SUCCESS;
   };
   rc = body();
   const hipError_t es = hipStreamSynchronize(c->stream);
-  icikt::host::finish_downloads(c);
+  icikt::host::finish_downloads(c, rc == 0 && es == hipSuccess);
   all_pi.release();
   all_pj.release();
   if (rc) return rc;
@@ -1034,7 +1208,7 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
   };
   rc = body();
   const hipError_t es = hipStreamSynchronize(c->stream);
-  icikt::host::finish_downloads(c);
+  icikt::host::finish_downloads(c, rc == 0 && es == hipSuccess);
   if (rc) return rc;
   if (es != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("missingness: ") + hipGetErrorString(es));
   return ICIKT_SUCCESS;
@@ -1043,12 +1217,15 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 // Development / test hook: "key=value,key=value" overrides of the pair kernel's launch plan and of the host
 // path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
 // wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), gridmult (persistent grid as a
-// multiple of the resident waves, always), h2d (plain | register | stage),
+// multiple of the resident waves, always), gridcap (persistent grid: at most this many workgroups),
+// h2d (register | stage: how a host matrix of 256 KB or more is read), regfail (0 | 1: behave as if every
+// hipHostRegister were refused -- the transfers then go through the library's pinned buffers),
 // verbose (0 | 1: print the plan to stderr).
 int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   if (!c) return ICIKT_E_INVALID;
   icikt_ctx::PlanOverride ov;
   int h2d = -1;
+  bool regfail = false;
   std::string sp = spec ? spec : "";
   size_t pos = 0;
   while (pos < sp.size()) {
@@ -1068,12 +1245,15 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
-    else if (key == "h2d") h2d = (val == "plain") ? 0 : (val == "register") ? 1 : (val == "stage") ? 2 : -2;
+    else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());
+    else if (key == "regfail") regfail = (val[0] == '1');
+    else if (key == "h2d") h2d = (val == "register") ? 1 : (val == "stage") ? 2 : -2;
     else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
-    if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be plain, register or stage");
+    if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be register or stage");
   }
   c->plan_ov = ov;
   c->h2d_mode = h2d;
+  c->force_reg_fail = regfail;
   c->raw_valid = false;
   c->wpb = 0;  // tasks are rebuilt for the new plan
   return ICIKT_SUCCESS;

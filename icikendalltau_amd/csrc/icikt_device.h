@@ -21,7 +21,26 @@ struct ColStats {
   uint32_t ntg;      // tie groups of size >= 2 (length of the column's tgroups list)
   long long e0, e1, e2;  // the same sums exactly
   double fill;           // min - 0.1
+  long long nexcl;       // rows excluded by the caller's global_na rule (MaskSpec): exclude_loc of R/utils.R:1-23.
+                         // == nna unless the data hold NaN and NaN is not in global_na
 };
+
+// setup_missing_matrix (R/utils.R:1-23) on the device: which cells of the data matrix are excluded (become NA,
+// R/kendalltau.R:119-121) before the pre-pass.  The pre-pass applies it while it reads the matrix, so the masked copy
+// `exclude_data` never exists.  A NaN in the data is missing for ici_kt whether or not NaN is in global_na
+// (Rcpp is_na, src/kendallc.cpp:181), but counts as excluded (n_good, keep) only when it is.
+constexpr int ICIKT_MASK_VALS = 6;
+struct MaskSpec {
+  int mask_nan;                  // global_na holds NA
+  int mask_inf;                  // global_na holds Inf: is.infinite(), both signs
+  int n_vals;                    // the other global_na values, compared with ==
+  double vals[ICIKT_MASK_VALS];
+};
+__host__ __device__ inline bool mask_excluded(const MaskSpec& ms, double v) {
+  bool ex = (ms.mask_nan && v != v) || (ms.mask_inf && (v - v != 0.0) && v == v);   // v - v: NaN for +-Inf, 0 otherwise
+  for (int k = 0; k < ICIKT_MASK_VALS; ++k) ex = ex || (k < ms.n_vals && v == ms.vals[k]);
+  return ex;
+}
 
 // Per-pair integers produced by K1 for the global perspective.
 struct PairRaw {
@@ -32,7 +51,7 @@ struct PairRaw {
 };
 
 // Device pointers + sizes of the prepared matrix (HBM layout).
-static_assert(sizeof(ColStats) == 64, "ColStats is 8 words of a column's meta record");
+static_assert(sizeof(ColStats) == 72, "ColStats is 9 words of a column's meta record");
 
 struct PrepView {
   int n;       // n_feat (rows per column)
@@ -48,11 +67,11 @@ struct PrepView {
                      // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
   uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
   // per column, stride Wp
-  // per column one record of mstride = 3 * Wp + 8 words (one array: one collective moves it between ranks):
+  // per column one record of mstride = 3 * Wp + 9 words (one array: one collective moves it between ranks):
   //   [Wp] mask      missing rows
   //   [Wp] fillmask  rows in the fill group
   //   [Wp] gflag     bit k: processing position k starts a tie group
-  //   [8]  ColStats
+  //   [9]  ColStats
   unsigned long long* meta;
   int mstride;
   __host__ __device__ unsigned long long* col_mask(int c) const { return meta + (int64_t)c * mstride; }
@@ -104,7 +123,20 @@ __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
   return 64 * ((items + 1) & ~1);
 }
 
-hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
+// ms: cells to exclude while reading dX (nullptr: NaN = missing, nothing else); keep: optional [n_samp][n] bytes,
+// 1 = not excluded (the reference's `keep = t(!exclude_loc)`, R/kendalltau.R:417)
+hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, const MaskSpec* ms,
+                     uint8_t* keep, hipStream_t s);
+// Full-matrix assembly (scale_and_reshape, R/kendalltau.R:357-421) on the device.
+//   launch_out_stats: red[0] = max(taumax) over the pairs, NaN skipped, as a sortable key (0 = none); red[1..5] =
+//     pairs per reason code; red[6] = max(n_good)
+//   launch_assemble:  five S x S matrices (cor, raw, pvalue, taumax, completeness), symmetric, diagonal rows
+// pi / pj == nullptr: pair p is pair `first + p` of combn(S, 2) order.  n_good == nullptr: n - ColStats::nexcl.
+hipError_t launch_out_stats(const PrepView& pv, const double* out4, const int32_t* reasons, int64_t n_pairs,
+                            const int64_t* n_good, unsigned long long* red, hipStream_t s);
+hipError_t launch_assemble(const PrepView& pv, const double* out4, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                           const int64_t* n_good, const unsigned long long* red, int scale_max, int diag_good,
+                           double* out5, hipStream_t s);
 // wide columns: one wave per pair, grid of `blocks` single-wave workgroups that fetch pairs from *task_ctr
 hipError_t launch_k1_wide(const PrepView& pv, const int32_t* pi, const int32_t* pj, PairRaw* raw, int64_t n_pairs,
                           int blocks, size_t lds_bytes, int* task_ctr, hipStream_t s);

@@ -68,21 +68,34 @@ struct icikt_ctx {
   // result buffers of the caller that were page-locked for a D2H copy (icikt::host::download): released by
   // finish_downloads() once the stream has been synchronised
   std::vector<void*> locked_out;
+  // ... and result copies that could not be page-locked in place: a pinned bounce allocation per copy, moved to the
+  // caller's array (and freed) by finish_downloads()
+  struct Bounce { void* pinned; void* dst; size_t bytes; };
+  std::vector<Bounce> bounced_out;
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copy[4] = {};
-  void* pinned = nullptr;   // pinned staging area (h2d mode "stage")
+  void* pinned = nullptr;   // pinned staging area (h2d mode "stage", and every transfer whose page-locking was refused)
   size_t pinned_bytes = 0;
-  int h2d_mode = -1;        // -1: library default; 0 plain (pageable source), 1 register the caller's buffer, 2 stage
+  int h2d_mode = -1;        // -1: library default; 1 register the caller's buffer, 2 stage, 3 page-locked by the caller
+  bool force_reg_fail = false;  // test hook (icikt_debug_set_plan "regfail=1"): behave as if every hipHostRegister failed
   DevBuf<double> d_X, d_out4, d_Xp;  // d_Xp: masked column pairs of icikt_pairs_complete_f64
+  // full-matrix entry (icikt_matrix_f64): the exclusion rule the pre-pass applies while it reads the matrix and the
+  // optional keep bytes it writes (both only for the duration of that call), the assembled matrices, the reduction
+  DevBuf<double> d_out5;
+  DevBuf<uint8_t> d_keep;
+  DevBuf<unsigned long long> d_red;
+  DevBuf<int32_t> d_pi_all, d_pj_all;     // icikt_matrix_multi_f64, explicit pair list: the whole list on the first device
+  const icikt::MaskSpec* k0_mask = nullptr;
+  uint8_t* k0_keep = nullptr;
   DevBuf<int64_t> d_counts;
   DevBuf<int32_t> d_reasons;
   DevBuf<uint32_t> d_self;
 
   // launch-plan overrides of the pair kernel (icikt_debug_set_plan; -1 = the library's choice)
   struct PlanOverride {
-    int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1;
+    int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1, grid_cap = -1;
     bool has_tgmax = false;
     int tgmax = 0;
     bool verbose = false;
@@ -124,18 +137,29 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
 // caller synchronises c->copy_stream and calls hipHostUnregister(*deferred_unregister) itself.
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
                        int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr);
+// global_na values (NaN = NA, +-Inf = Inf, anything else compared with ==) -> the pre-pass's exclusion rule
+int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt::MaskSpec* ms);
 // Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).
 void prebuild_units(icikt_ctx* c);
 // Host <-> device copies of pageable host memory.  HIP pins pageable memory on the fly for copies of 1 MB and more;
-// that path faulted intermittently (a GPU memory-access fault at a host heap address, under load, in the one parity
-// test whose matrix falls between 1 MB and the old 4 MB registration threshold).  Every copy of kLockMin bytes or
-// more therefore page-locks the caller's memory itself (hipHostRegister), for the time of the copy; smaller copies
-// take the runtime's staging path, which does not touch the caller's pages from the GPU.
+// that path faulted intermittently (a GPU memory-access fault at a host heap address, under load, in parity tests
+// whose matrices fall between 1 MB and the old 4 MB registration threshold: DESIGN.md section 6).  The library
+// therefore NEVER hands pageable memory of kLockMin bytes or more to a copy, synchronous or not:
+//   * it page-locks the caller's range itself for the time of the copy (hipHostRegister), or
+//   * finds it page-locked already (registered or allocated pinned by the caller: hipPointerGetAttributes), or
+//   * when the registration is refused for any other reason, moves the bytes through its OWN pinned buffers
+//     (a bounce buffer in chunks for uploads; a pinned allocation per array for result downloads).
+// Smaller copies take the runtime's staging path, which does not touch the caller's pages from the GPU.
 constexpr size_t kLockMin = (size_t)256 << 10;
+enum class HostLock { Locked /* by this call: unregister afterwards */, Already /* pinned by the caller */, Refused };
+HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags);
+// grow c->pinned to at least `need` bytes (no copy may be in flight from or into it)
+int ensure_bounce(icikt_ctx* c, size_t need);
 // H2D on c->stream, complete (and the host range released) on return
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes);
-// after the stream that carries download() copies has been synchronised: end the page-locking of their targets
-void finish_downloads(icikt_ctx* c);
+// after the stream that carries download() copies has been synchronised: end the page-locking of their targets and
+// deliver the bounced ones
+void finish_downloads(icikt_ctx* c, bool ok = true);
 // D2H of a result array into a pageable host buffer on c->stream (not synchronised; finish_downloads afterwards)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 

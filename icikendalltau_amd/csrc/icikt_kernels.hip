@@ -16,6 +16,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "icikt_device.h"
 
 namespace icikt {
@@ -228,7 +230,8 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
 // memory (they outgrow the static LDS), no tie-group list and no rec staging.
 template <bool WIDE>
 __global__ void __launch_bounds__(K0_THREADS)
-k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin) {
+k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms,
+           uint8_t* __restrict__ keep) {
   __shared__ long long sh_ll[K0_THREADS];
   __shared__ int sh_i[K0_THREADS];
   __shared__ unsigned long long sh_bits_lds[1024];  // fill-group bitset, W <= 1024 words
@@ -263,12 +266,18 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
   uint32_t* hi32 = WIDE ? pv.hi32 + (int64_t)c * pv.n_pad : nullptr;
 
   // ---- phase 1: NA bitset, NA count, min of the non-missing values (kendallc.cpp:187-218) --------
+  // The caller's global_na rule (setup_missing_matrix, R/utils.R:1-23) is applied HERE, while the column is read:
+  // an excluded cell is missing (R/kendalltau.R:119-121), and so is every NaN (Rcpp is_na, kendallc.cpp:181).
   double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
-  int nna = 0;
+  int nna = 0, nexcl = 0;
+  uint8_t* keep_c = keep ? keep + (int64_t)c * n : nullptr;
   for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
     const int i = base + tid;
     const double v = (i < n) ? col[i] : 0.0;
-    const bool isna = (i < n) && (v != v);
+    const bool excl = (i < n) && mask_excluded(ms, v);
+    const bool isna = (i < n) && (excl || v != v);
+    nexcl += excl ? 1 : 0;
+    if (keep_c && i < n) keep_c[i] = excl ? 0 : 1;
     const unsigned long long b = __ballot(isna);
     if (lane == 0 && (i >> 6) < W) mask[i >> 6] = b;
     if (i < n && !isna) tmin = (v < tmin) ? v : tmin;
@@ -288,6 +297,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     __syncthreads();
   }
   nna = block_reduce<int>(nna, sh_i, [](int a, int b) { return a + b; });
+  nexcl = block_reduce<int>(nexcl, sh_i, [](int a, int b) { return a + b; });
   const double fill = tmin - 0.1;  // kendallc.cpp:214-215, double arithmetic
 
   // ---- phase 1b: sortable keys ------------------------------------------------------------------
@@ -296,7 +306,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     uint32_t id = 0xFFFFFFFFu;
     if (i < n) {
       double v = col[i];
-      if (v != v) v = fill;
+      if (v != v || mask_excluded(ms, v)) v = fill;
       k = sortable_key(v);
       id = (uint32_t)i;
     }
@@ -558,6 +568,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin)
     st.s0 = s0; st.s1 = s1; st.s2 = s2; st.ntg = (uint32_t)ntg;
     st.e0 = e0; st.e1 = e1; st.e2 = e2;
     st.fill = fill;
+    st.nexcl = nexcl;
     *pv.col_stats(c) = st;
   }
 }
@@ -1173,7 +1184,7 @@ __device__ __forceinline__ uint32_t prefix_query_half(const unsigned long long* 
 template <int HI>
 __device__ __forceinline__ void half_pre_store(uint16_t* pre, uint32_t l, uint32_t incl, const uint32_t (&cw)[HI]) {
   const uint32_t excl = incl - cw[HI - 1];
-  const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: counts < 2^14)
+  const uint32_t both = excl * 0x10001u;              // added to two packed counts at once (no carry: a count is at most n <= 18 336 < 2^16)
   uint32_t v[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -2732,9 +2743,138 @@ __global__ void k_selftest(uint32_t* out) {
 // ------------------------------------------------------------------------------------------------
 // launchers (called from icikt_capi.cpp; keeps <<<>>> syntax inside the .hip translation unit)
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s) {
-  if (pv.wide) hipLaunchKernelGGL(k0_prepare<true>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
-  else hipLaunchKernelGGL(k0_prepare<false>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin);
+hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, const MaskSpec* msp,
+                     uint8_t* keep, hipStream_t s) {
+  MaskSpec ms{};
+  if (msp) ms = *msp;
+  if (pv.wide) hipLaunchKernelGGL(k0_prepare<true>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
+  else hipLaunchKernelGGL(k0_prepare<false>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full-matrix assembly: scale_and_reshape (R/kendalltau.R:357-421) on the device
+// ------------------------------------------------------------------------------------------------
+// The reference row-binds the chunks' data.frames, divides raw by max(taumax, na.rm = TRUE) (:368-373), appends one
+// row per sample for the diagonal (raw = cor = n_good / max(n_good), pvalue 0, taumax 1, completeness =
+// n_good / n_feature, :375-386) and fills five S x S matrices symmetrically by name pair (:390-415): on the host that
+// is a 523 776-row data.frame and ten indexed assignments at c4.  Here: one reduction kernel, one scatter kernel,
+// one D2H of 5 S^2 doubles.
+__device__ __forceinline__ unsigned long long dbl_sortable(double v) {   // monotone in v; 0 is below every double
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dbl_unsortable(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+__device__ __forceinline__ long long col_n_good(const PrepView& pv, const int64_t* n_good, int c) {
+  return n_good ? (long long)n_good[c] : (long long)pv.n - pv.col_stats(c)->nexcl;
+}
+
+// red[0] = max over the pairs of the sortable key of taumax (NaN skipped; 0 = no pair had one), red[1 + r] = pairs
+// with reason code r (0..4), red[6] = max(n_good)
+__global__ void __launch_bounds__(256)
+k_out_stats(PrepView pv, const double* __restrict__ out4, const int32_t* __restrict__ reasons, int64_t n_pairs,
+            const int64_t* __restrict__ n_good, unsigned long long* __restrict__ red) {
+  __shared__ unsigned long long sh[8];
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long mx = 0ull, mg = 0ull;
+  uint32_t rc[5] = {0u, 0u, 0u, 0u, 0u};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += stride) {
+    const double t = out4[4 * p + 2];
+    if (t == t) mx = max(mx, dbl_sortable(t));
+    const int r = reasons ? reasons[p] : 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) rc[k] += (r == k) ? 1u : 0u;
+  }
+  for (int64_t cc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cc < pv.n_samp; cc += stride)
+    mg = max(mg, (unsigned long long)max(0ll, col_n_good(pv, n_good, (int)cc)));
+  atomicMax(&sh[0], mx);
+  atomicMax(&sh[6], mg);
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    if (rc[k]) atomicAdd(&sh[1 + k], (unsigned long long)rc[k]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&red[0], sh[0]);
+    atomicMax(&red[6], sh[6]);
+  }
+  if (threadIdx.x >= 1 && threadIdx.x <= 5 && sh[threadIdx.x]) atomicAdd(&red[threadIdx.x], sh[threadIdx.x]);
+}
+
+// out5: five S x S matrices, zero-filled by the caller; a thread per pair writes both triangles, then a thread per
+// sample the diagonal (the diagonal rows come AFTER the pairs in the reference: they win over a self pair of the list)
+__global__ void __launch_bounds__(256)
+k_assemble(PrepView pv, const double* __restrict__ out4, const int32_t* __restrict__ pi, const int32_t* __restrict__ pj,
+           int64_t n_pairs, const int64_t* __restrict__ n_good, const unsigned long long* __restrict__ red, int scale_max,
+           int diag_good, double* __restrict__ out5) {
+  const int64_t S = pv.n_samp, SS = S * S;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_pairs) {
+    int64_t i, j;
+    if (pi) {
+      i = pi[t]; j = pj[t];
+    } else {
+      // pair t of combn(S, 2): row i holds the pairs (i, i+1 .. S-1) and starts at offset i (2S - i - 1) / 2
+      const double b = 2.0 * (double)S - 1.0;
+      i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+      i = max((int64_t)0, min(i, S - 2));
+      while (i > 0 && i * (2 * S - i - 1) / 2 > t) --i;
+      while ((i + 1) * (2 * S - i - 2) / 2 <= t) ++i;
+      j = i + 1 + (t - i * (2 * S - i - 1) / 2);
+    }
+    const double raw = out4[4 * t + 0], pval = out4[4 * t + 1], tmax = out4[4 * t + 2], comp = out4[4 * t + 3];
+    // max(numeric(0), na.rm = TRUE) is -Inf in R
+    const double max_cor = red[0] ? dbl_unsortable(red[0]) : -__longlong_as_double(0x7FF0000000000000ll);
+    const double cor = scale_max ? raw / max_cor : raw;
+    const int64_t a = i + j * S, b2 = j + i * S;
+    out5[a] = cor;            out5[b2] = cor;
+    out5[SS + a] = raw;       out5[SS + b2] = raw;
+    out5[2 * SS + a] = pval;  out5[2 * SS + b2] = pval;
+    out5[3 * SS + a] = tmax;  out5[3 * SS + b2] = tmax;
+    out5[4 * SS + a] = comp;  out5[4 * SS + b2] = comp;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_assemble_diag(PrepView pv, const int64_t* __restrict__ n_good, const unsigned long long* __restrict__ red,
+                double* __restrict__ out5) {
+  const int64_t S = pv.n_samp, SS = S * S;
+  const int64_t cc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= S) return;
+  const double g = (double)col_n_good(pv, n_good, (int)cc);
+  const double d = g / (double)red[6];                       // n_good / max(n_good)  (0 / 0 = NaN, as in R)
+  const int64_t a = cc + cc * S;
+  out5[a] = d;
+  out5[SS + a] = d;
+  out5[2 * SS + a] = 0.0;
+  out5[3 * SS + a] = 1.0;
+  out5[4 * SS + a] = g / (double)pv.n;                       // frac_complete = n_good / nrow
+}
+
+hipError_t launch_out_stats(const PrepView& pv, const double* out4, const int32_t* reasons, int64_t n_pairs,
+                            const int64_t* n_good, unsigned long long* red, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(red, 0, 8 * sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  const int64_t work = std::max<int64_t>(n_pairs, pv.n_samp);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (work + 255) / 256));
+  hipLaunchKernelGGL(k_out_stats, dim3(blocks), dim3(256), 0, s, pv, out4, reasons, n_pairs, n_good, red);
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble(const PrepView& pv, const double* out4, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                           const int64_t* n_good, const unsigned long long* red, int scale_max, int diag_good,
+                           double* out5, hipStream_t s) {
+  const size_t S = (size_t)pv.n_samp;
+  if (S == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(out5, 0, 5 * S * S * sizeof(double), s);
+  if (e != hipSuccess) return e;
+  if (n_pairs > 0)
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, pv, out4, pi, pj, n_pairs,
+                       n_good, red, scale_max, diag_good, out5);
+  if (diag_good)
+    hipLaunchKernelGGL(k_assemble_diag, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, pv, n_good, red, out5);
   return hipGetLastError();
 }
 

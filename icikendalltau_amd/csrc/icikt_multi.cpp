@@ -76,7 +76,9 @@ struct icikt_multi {
   bool rccl = false;
   std::vector<ncclComm_t> comms;
   std::string err;
-  double phase_ms[ICIKT_MULTI_PHASES] = {};
+  double phase_ms[ICIKT_MULTI_PHASES] = {};          // of the last call: maximum over the ranks
+  std::vector<double> rank_ms;                        // [rank][ICIKT_MULTI_PHASES + 1]: its phases, then its barrier waits
+  int ranks_used = 0;                                 // of the last call: n, or 1 when it ran on the first device alone
   // rank 0's gather targets
   void* root_out4 = nullptr;
   void* root_counts = nullptr;
@@ -112,6 +114,14 @@ struct Call {
   std::vector<double*> out4_dev;
   std::vector<int64_t*> counts_dev;
   std::vector<int32_t*> reasons_dev;
+  // icikt_matrix_multi_f64: the pre-pass applies the exclusion rule, every rank returns the keep bytes of ITS columns,
+  // the first rank assembles the five matrices from the gathered results
+  bool matrix = false;
+  icikt::MaskSpec mask{};
+  uint8_t* keep = nullptr;
+  double* out5 = nullptr;
+  int scale_max = 1, diag_good = 1;
+  unsigned long long red[8] = {};
 };
 
 bool all_ok(Call& a) {
@@ -177,13 +187,21 @@ void rank_main(Call& a, int r) {
   const int64_t begin = std::min(a.P, (int64_t)r * a.n_each), end = std::min(a.P, (int64_t)(r + 1) * a.n_each);
   const int64_t P_local = end - begin;
   double t_prev = now_ms();
-  auto mark = [&](int phase) {  // rank 0 keeps the wall clock of the phases (with ICIKT_FLAG_TIMING: after a sync)
+  double* my_ms = m->rank_ms.data() + (size_t)r * (ICIKT_MULTI_PHASES + 1);
+  // every rank keeps the wall clock of ITS phases (with ICIKT_FLAG_TIMING: after a stream synchronisation, so the
+  // figures are device time) and, apart from them, the time it spent waiting for the other ranks at the barriers:
+  // an imbalance between the ranks shows as a spread of the per-rank figures, not as a long next phase of rank 0
+  auto mark = [&](int phase) {
     if (a.timing) (void)hipStreamSynchronize(c->stream);
-    if (r == 0) {
-      const double t = now_ms();
-      m->phase_ms[phase] = t - t_prev;
-      t_prev = t;
-    }
+    const double t = now_ms();
+    my_ms[phase] += t - t_prev;
+    t_prev = t;
+  };
+  auto rendezvous = [&]() {
+    a.bar->wait();
+    const double t = now_ms();
+    my_ms[ICIKT_MULTI_PHASES] += t - t_prev;
+    t_prev = t;
   };
   size_t order_slice = 0, meta_slice = 0;
 
@@ -193,11 +211,33 @@ void rank_main(Call& a, int r) {
     if (a.pi) RANKCHK(icikt_set_pairs(c, a.pi + begin, a.pj + begin, P_local));
     else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
     RANKCHK(icikt::host::prepare_alloc(c, a.n_feat, S, a.alloc_cols, std::max<int64_t>(c1 - c0, 1)));
-    RANKCHK(icikt::host::upload_and_prepare(c, a.X, a.n_feat, S, a.ld, c0, c1, a.flags & ~ICIKT_FLAG_TIMING));
+    if (a.matrix) {
+      c->k0_mask = &a.mask;
+      if (a.keep) {
+        RANKCHK_HIP(c->d_keep.reserve((size_t)S * (size_t)a.n_feat));
+        c->k0_keep = c->d_keep.p;
+      }
+    }
+    const int rc_up = icikt::host::upload_and_prepare(c, a.X, a.n_feat, S, a.ld, c0, c1, a.flags & ~ICIKT_FLAG_TIMING);
+    c->k0_mask = nullptr;
+    c->k0_keep = nullptr;
+    RANKCHK(rc_up);
     icikt::host::prebuild_units(c);   // the task list of this rank's pair block, while its columns are copied
     RANKCHK_HIP(c->d_out4.reserve((size_t)std::max<int64_t>(a.n_each, 1) * 4));
     if (a.counts) RANKCHK_HIP(c->d_counts.reserve((size_t)std::max<int64_t>(a.n_each, 1) * ICIKT_CNT_FIELDS));
     if (a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));
+    if (a.matrix && !a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));
+    if (r == 0 && a.matrix) {
+      RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.n_each * sizeof(int32_t)));
+      RANKCHK_HIP(c->d_out5.reserve(5 * (size_t)S * (size_t)S));
+      RANKCHK_HIP(c->d_red.reserve(8));
+      if (a.pi) {   // the assembly needs the WHOLE pair list on the first device (combn order is computed)
+        RANKCHK_HIP(c->d_pi_all.reserve((size_t)a.P));
+        RANKCHK_HIP(c->d_pj_all.reserve((size_t)a.P));
+        RANKCHK(icikt::host::upload_sync(c, c->d_pi_all.p, a.pi, (size_t)a.P * sizeof(int32_t)));
+        RANKCHK(icikt::host::upload_sync(c, c->d_pj_all.p, a.pj, (size_t)a.P * sizeof(int32_t)));
+      }
+    }
     if (r == 0) {
       RANKCHK_HIP(grow(&m->root_out4, &m->root_out4_bytes, (size_t)G * a.n_each * 4 * sizeof(double)));
       if (a.counts)
@@ -215,7 +255,7 @@ void rank_main(Call& a, int r) {
   };
   phase_a();
   mark(ICIKT_MULTI_PHASE_PREPARE);
-  a.bar->wait();
+  rendezvous();
   if (!all_ok(a)) {
     (void)hipStreamSynchronize(c->stream);
     return;
@@ -241,17 +281,14 @@ void rank_main(Call& a, int r) {
     c->prepared = true;
     if (c0 > 0) RANKCHK(icikt_expand_cols_dev(c, 0, c0, 0));
     if (c1 < S) RANKCHK(icikt_expand_cols_dev(c, c1, S, 0));
-    if (a.timing) {
-      (void)hipStreamSynchronize(c->stream);
-      if (r == 0) { const double t = now_ms(); m->phase_ms[ICIKT_MULTI_PHASE_EXCHANGE] = t - t_prev; t_prev = t; }
-    }
+    if (a.timing) mark(ICIKT_MULTI_PHASE_EXCHANGE);   // (without the flag the exchange is only enqueued: counted with the pairs)
     RANKCHK(icikt_run_dev(c, a.perspective, a.alternative, a.continuity, a.flags & ~ICIKT_FLAG_TIMING, c->d_out4.p,
-                          a.counts ? c->d_counts.p : nullptr, a.reasons ? c->d_reasons.p : nullptr));
+                          a.counts ? c->d_counts.p : nullptr, (a.reasons || a.matrix) ? c->d_reasons.p : nullptr));
     if (!m->rccl) RANKCHK_HIP(hipStreamSynchronize(c->stream));  // rank 0 reads the results after the barrier
   };
   phase_b();
   mark(ICIKT_MULTI_PHASE_PAIRS);
-  a.bar->wait();
+  rendezvous();
   // NB: a rank that failed inside phase B may have left its peers inside a collective that it never entered;
   // everything that can fail for reasons of its own (allocation, argument checks) happens in phase A for that
   // reason, and phase B failures are launch failures that hit every rank alike.
@@ -268,7 +305,7 @@ void rank_main(Call& a, int r) {
       if (a.counts)
         RANKCHK_NCCL(ncclGather(c->d_counts.p, m->root_counts, (size_t)a.n_each * ICIKT_CNT_FIELDS, ncclInt64, 0,
                                 m->comms[(size_t)r], c->stream));
-      if (a.reasons)
+      if (a.reasons || a.matrix)
         RANKCHK_NCCL(ncclGather(c->d_reasons.p, m->root_reasons, (size_t)a.n_each, ncclInt32, 0, m->comms[(size_t)r], c->stream));
     } else if (r == 0) {
       for (int p = 0; p < G; ++p) {
@@ -278,28 +315,43 @@ void rank_main(Call& a, int r) {
           RANKCHK_HIP(peer_copy(static_cast<int64_t*>(m->root_counts) + (size_t)p * a.n_each * ICIKT_CNT_FIELDS, m->devices[0],
                                 a.counts_dev[(size_t)p], m->devices[(size_t)p],
                                 (size_t)a.n_each * ICIKT_CNT_FIELDS * sizeof(int64_t), c->stream));
-        if (a.reasons)
+        if (a.reasons || a.matrix)
           RANKCHK_HIP(peer_copy(static_cast<int32_t*>(m->root_reasons) + (size_t)p * a.n_each, m->devices[0],
                                 a.reasons_dev[(size_t)p], m->devices[(size_t)p], (size_t)a.n_each * sizeof(int32_t), c->stream));
       }
     }
-    if (r == 0) {
+    if (a.matrix) {
+      // the keep bytes of this rank's columns; on the first rank the assembly over the gathered results (the blocks
+      // are consecutive and only the last one is short: the first P records ARE the pair list's results, in order)
+      if (a.keep && c1 > c0)
+        RANKCHK(icikt::host::download(c, a.keep + (size_t)c0 * (size_t)a.n_feat, c->d_keep.p + (size_t)c0 * (size_t)a.n_feat,
+                                      (size_t)(c1 - c0) * (size_t)a.n_feat));
+      if (r == 0) {
+        RANKCHK_HIP(icikt::launch_out_stats(c->pv, static_cast<const double*>(m->root_out4),
+                                            static_cast<const int32_t*>(m->root_reasons), a.P, nullptr, c->d_red.p, c->stream));
+        RANKCHK_HIP(icikt::launch_assemble(c->pv, static_cast<const double*>(m->root_out4), a.pi ? c->d_pi_all.p : nullptr,
+                                           a.pi ? c->d_pj_all.p : nullptr, a.P, nullptr, c->d_red.p, a.scale_max, a.diag_good,
+                                           c->d_out5.p, c->stream));
+        RANKCHK(icikt::host::download(c, a.out5, c->d_out5.p, 5 * (size_t)S * (size_t)S * sizeof(double)));
+        RANKCHK(icikt::host::download(c, a.red, c->d_red.p, sizeof(a.red)));
+      }
+    } else if (r == 0) {
       // blocks are consecutive and only the last one is short: the first P records of the gathered array
       RANKCHK(icikt::host::download(c, a.out4, m->root_out4, (size_t)a.P * 4 * sizeof(double)));
       if (a.counts) RANKCHK(icikt::host::download(c, a.counts, m->root_counts, (size_t)a.P * ICIKT_CNT_FIELDS * sizeof(int64_t)));
       if (a.reasons) RANKCHK(icikt::host::download(c, a.reasons, m->root_reasons, (size_t)a.P * sizeof(int32_t)));
     }
     const hipError_t es = hipStreamSynchronize(c->stream);
-    icikt::host::finish_downloads(c);
+    icikt::host::finish_downloads(c, es == hipSuccess);
     RANKCHK_HIP(es);
   };
   phase_c();
-  if (!c->locked_out.empty()) {   // phase C left early: nothing may still write the caller's arrays
+  if (!c->locked_out.empty() || !c->bounced_out.empty()) {   // phase C left early: nothing may still write the caller's arrays
     (void)hipStreamSynchronize(c->stream);
-    icikt::host::finish_downloads(c);
+    icikt::host::finish_downloads(c, false);
   }
-  if (r == 0) m->phase_ms[ICIKT_MULTI_PHASE_GATHER] = now_ms() - t_prev;
-  a.bar->wait();  // "copy" exchange: nobody returns (and lets its buffers be reused) while rank 0 still reads them
+  mark(ICIKT_MULTI_PHASE_GATHER);
+  rendezvous();  // "copy" exchange: nobody returns (and lets its buffers be reused) while rank 0 still reads them
 }
 
 }  // namespace
@@ -379,6 +431,15 @@ int icikt_multi_phase_ms(const icikt_multi* m, double* ms) {
   return ICIKT_SUCCESS;
 }
 
+int icikt_multi_rank_phase_ms(const icikt_multi* m, int rank, double* ms) {
+  if (!m || !ms || rank < 0 || rank >= m->n) return ICIKT_E_INVALID;
+  for (int k = 0; k <= ICIKT_MULTI_PHASES; ++k)
+    ms[k] = (rank < m->ranks_used) ? m->rank_ms[(size_t)rank * (ICIKT_MULTI_PHASES + 1) + (size_t)k] : 0.0;
+  return ICIKT_SUCCESS;
+}
+
+int icikt_multi_ranks_used(const icikt_multi* m) { return m ? m->ranks_used : 0; }
+
 int icikt_multi_debug_set_plan(icikt_multi* m, const char* spec) {
   if (!m) return ICIKT_E_INVALID;
   for (icikt_ctx* c : m->ctx) {
@@ -389,11 +450,26 @@ int icikt_multi_debug_set_plan(icikt_multi* m, const char* spec) {
   return ICIKT_SUCCESS;
 }
 
-int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
-                          const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
-                          int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
+}  // extern "C"
+
+namespace {
+
+// what icikt_matrix_multi_f64 adds to the arguments of icikt_pairs_multi_f64
+struct MatrixArgs {
+  const double* global_na;
+  int n_global_na, scale_max, diag_good;
+  double* out5;
+  uint8_t* keep;
+  int64_t* reason_counts;
+};
+
+int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+               const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
+               int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons, const MatrixArgs* mx) {
   if (!m) return ICIKT_E_INVALID;
   for (double& v : m->phase_ms) v = 0.0;
+  m->rank_ms.assign((size_t)m->n * (ICIKT_MULTI_PHASES + 1), 0.0);
+  m->ranks_used = 0;
   if (n_feat < 0 || n_samp < 0 || ld < n_feat) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad matrix shape");
   if (pi == nullptr) {
     if (pj != nullptr) return mfail(m, ICIKT_E_INVALID, "pairs_multi: pi is null but pj is not");
@@ -409,10 +485,16 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
     icikt_ctx* c = m->ctx[0];
     const int saved = c->h2d_mode;
     c->h2d_mode = -1;
-    const int rc = icikt_pairs_f64(c, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags,
-                                   out4, counts, reasons);
+    const double t0 = now_ms();
+    const int rc = mx ? icikt_matrix_f64(c, X, n_feat, n_samp, ld, mx->global_na, mx->n_global_na, pi, pj, n_pairs, perspective,
+                                         alternative, continuity, flags, mx->scale_max, mx->diag_good, mx->out5, mx->keep,
+                                         mx->reason_counts)
+                      : icikt_pairs_f64(c, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags,
+                                        out4, counts, reasons);
     c->h2d_mode = saved;
     if (rc) return mfail(m, rc, icikt_last_error(c));
+    m->ranks_used = 1;   // the caller can tell (icikt_multi_ranks_used); the whole call is booked as the pairs phase
+    m->phase_ms[ICIKT_MULTI_PHASE_PAIRS] = m->rank_ms[ICIKT_MULTI_PHASE_PAIRS] = now_ms() - t0;
     return ICIKT_SUCCESS;
   }
   // argument checks (the ranks run unchecked): same texts as the single-device path
@@ -422,7 +504,7 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
     for (int64_t p = 0; p < n_pairs; ++p)
       if (pi[p] < 0 || pi[p] >= n_samp || pj[p] < 0 || pj[p] >= n_samp)
         return mfail(m, ICIKT_E_INVALID, "pairs_multi: column index out of range");
-  if (!out4) return mfail(m, ICIKT_E_INVALID, "pairs_multi: null output");
+  if (mx ? !mx->out5 : !out4) return mfail(m, ICIKT_E_INVALID, "pairs_multi: null output");
   if (perspective != ICIKT_PERSPECTIVE_LOCAL && perspective != ICIKT_PERSPECTIVE_GLOBAL)
     return mfail(m, ICIKT_E_INVALID, "pairs_multi: perspective must be local (0) or global (1)");
   if (alternative < 0 || alternative > ICIKT_ALT_OTHER) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad alternative code");
@@ -435,6 +517,13 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
   a.cols_per = 2 * ((n_samp + 2 * G - 1) / (2 * G));  // even: the rec table interleaves column pairs
   a.alloc_cols = a.cols_per * G;
   a.timing = (flags & ICIKT_FLAG_TIMING) != 0;
+  if (mx) {
+    a.matrix = true;
+    const int rcm = icikt::host::make_mask_spec(m->ctx[0], mx->global_na, mx->n_global_na, &a.mask);
+    if (rcm) return mfail(m, rcm, icikt_last_error(m->ctx[0]));
+    a.keep = mx->keep; a.out5 = mx->out5; a.scale_max = mx->scale_max ? 1 : 0; a.diag_good = mx->diag_good ? 1 : 0;
+    if (mx->reason_counts) for (int k = 0; k < 5; ++k) mx->reason_counts[k] = 0;
+  }
   Barrier bar(G);
   a.bar = &bar;
   a.rc.assign((size_t)G, ICIKT_SUCCESS);
@@ -442,15 +531,17 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
   a.order_base.assign((size_t)G, nullptr); a.meta_base.assign((size_t)G, nullptr);
   a.out4_dev.assign((size_t)G, nullptr); a.counts_dev.assign((size_t)G, nullptr); a.reasons_dev.assign((size_t)G, nullptr);
 
-  // page-lock the caller's matrix once: every rank then DMAs its columns straight out of it
+  // page-lock the caller's matrix once: every rank then DMAs its columns straight out of it.  Refused (and not
+  // because the caller has page-locked it already): every rank stages its columns through its own pinned buffer --
+  // never an asynchronous copy from pageable memory (icikt_host.h)
   const size_t span = ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
   bool registered = false;
   int rank_mode = m->ctx[0]->h2d_mode;
   if (rank_mode == 3 || rank_mode == 1) {
     (void)hipSetDevice(m->devices[0]);
-    registered = hipHostRegister(const_cast<double*>(X), span, hipHostRegisterPortable) == hipSuccess;
-    if (!registered) (void)hipGetLastError();
-    rank_mode = registered ? 3 : 0;
+    const icikt::host::HostLock lk = icikt::host::lock_host(m->ctx[0], X, span, hipHostRegisterPortable);
+    registered = lk == icikt::host::HostLock::Locked;
+    rank_mode = (lk == icikt::host::HostLock::Refused) ? 2 : 3;
   }
   std::vector<int> saved_modes;
   for (icikt_ctx* c : m->ctx) { saved_modes.push_back(c->h2d_mode); c->h2d_mode = rank_mode; }
@@ -474,11 +565,36 @@ int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64
     (void)hipSetDevice(m->devices[0]);
     (void)hipHostUnregister(const_cast<double*>(X));
   }
+  m->ranks_used = G;
+  for (int r = 0; r < G; ++r)
+    for (int k = 0; k < ICIKT_MULTI_PHASES; ++k)
+      m->phase_ms[k] = std::max(m->phase_ms[k], m->rank_ms[(size_t)r * (ICIKT_MULTI_PHASES + 1) + (size_t)k]);
   for (int r = 0; r < G; ++r)
     if (a.rc[(size_t)r] != ICIKT_SUCCESS)
       return mfail(m, a.rc[(size_t)r], "rank " + std::to_string(r) + " (device " + std::to_string(m->devices[(size_t)r]) +
                                            "): " + a.msg[(size_t)r]);
+  if (mx && mx->reason_counts) for (int k = 0; k < 5; ++k) mx->reason_counts[k] = (int64_t)a.red[1 + k];
   return ICIKT_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icikt_pairs_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                          const int32_t* pi, const int32_t* pj, int64_t n_pairs, int perspective, int alternative,
+                          int continuity, uint32_t flags, double* out4, int64_t* counts, int32_t* reasons) {
+  return multi_impl(m, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags, out4, counts,
+                    reasons, nullptr);
+}
+
+int icikt_matrix_multi_f64(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           const double* global_na, int n_global_na, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
+                           int perspective, int alternative, int continuity, uint32_t flags, int scale_max, int diag_good,
+                           double* out5, uint8_t* keep, int64_t* reason_counts) {
+  const MatrixArgs mx{global_na, n_global_na, scale_max, diag_good, out5, keep, reason_counts};
+  return multi_impl(m, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags, nullptr, nullptr,
+                    nullptr, &mx);
 }
 
 }  // extern "C"

@@ -118,7 +118,9 @@ class ShardedPrepass:
         for full, nbytes in self.shards:
             mine = full[self.rank * nbytes:(self.rank + 1) * nbytes]
             if not self.via_host:
-                self.dist.all_gather_into_tensor(full, mine.clone())
+                # in place: the rank's slice already sits where the collective would put it (RCCL's in-place form,
+                # sendbuff == recvbuff + rank * count: no copy of the slice per step)
+                self.dist.all_gather_into_tensor(full, mine)
             else:
                 parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
                 self.dist.all_gather(parts, mine.cpu())

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICIKT_VERSION 201 /* 0.2.1: wide columns (ICIKT_MAX_FEATURES_WIDE) */
+#define ICIKT_VERSION 300 /* 0.3.0: icikt_matrix_f64 (device-side full-matrix assembly), per-rank phase times */
 
 /* status codes */
 #define ICIKT_SUCCESS 0
@@ -182,6 +182,30 @@ int icikt_pair_f64(icikt_ctx *ctx, const double *x, const double *y, int64_t n, 
                    int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
                    int32_t *reason);
 
+/* ---- the whole matrix behind one call (what the R glue binds for ici_kendalltau(return_matrix = TRUE)) ----------
+ *
+ * ici_kendalltau() below its argument checks (R/kendalltau.R:117-176), with NOTHING left to the host:
+ *   setup_missing_matrix (R/utils.R:1-23)     global_na is applied by the pre-pass while it reads X: a cell is
+ *                                             excluded if it is NaN and global_na holds a NaN, infinite and global_na
+ *                                             holds an Inf, or == any other global_na value (at most 6 of those).  The
+ *                                             masked copy `exclude_data` (R/kendalltau.R:119-121) never exists.  A
+ *                                             NaN in X is missing for ici_kt whatever global_na says (Rcpp is_na,
+ *                                             src/kendallc.cpp:181) but counts as excluded only under the rule, as in R.
+ *   ici_split over the pair list (:158)       pi == NULL: all C(n_samp, 2) pairs in combn order; else the caller's list
+ *                                             (setup_comparisons' include_only filter, self pairs when !diag_good)
+ *   scale_and_reshape (:357-421)              cor = raw / max(taumax, na.rm = TRUE) over the computed pairs when
+ *                                             scale_max; diag_good: raw = cor = n_good / max(n_good), pvalue 0,
+ *                                             taumax 1, completeness = n_good / n_feat on the diagonal, n_good =
+ *                                             colSums(!exclude_loc); symmetric fill, cells never computed stay 0
+ * out5: [5][n_samp][n_samp] doubles -- cor, raw, pvalue, taumax, completeness (symmetric: either major order).
+ * keep (optional): [n_samp][n_feat] bytes, 1 = not excluded -- the reference's `keep = t(!exclude_loc)` (:417).
+ * reason_counts (optional): [5] pairs per reason code ICIKT_OK .. ICIKT_NA_TIES_EQ_TOTAL; the host raises the
+ * reference's warning once per pair of codes 2..4, as ici_split does.  Same error contract as icikt_pairs_f64. */
+int icikt_matrix_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                     const double *global_na, int n_global_na, const int32_t *pi, const int32_t *pj, int64_t n_pairs,
+                     int perspective, int alternative, int continuity, uint32_t flags, int scale_max, int diag_good,
+                     double *out5, uint8_t *keep, int64_t *reason_counts);
+
 /* ---- several GPUs behind one call (what the R glue binds when n_gpu > 1) ----------------------
  *
  * Replaces the reference's worker fan-out, computation$split_fun(split_comparisons, ici_split, ...)
@@ -207,16 +231,31 @@ int icikt_pairs_multi_f64(icikt_multi *m, const double *X, int64_t n_feat, int64
                           const int32_t *pi, const int32_t *pj, int64_t n_pairs, int perspective,
                           int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
                           int32_t *reasons);
-/* Wall-clock milliseconds of the last call's phases as seen by rank 0: H2D + pre-pass of the rank's columns,
- * exchange (all-gather + local rebuild), pair kernel + epilogue, gather + D2H.  With ICIKT_FLAG_TIMING each
+/* icikt_matrix_f64 on several GPUs: the ranks apply the exclusion rule to their own columns and return their rows
+ * of `keep`; the first device assembles the five matrices from the gathered pair results and copies them out once. */
+int icikt_matrix_multi_f64(icikt_multi *m, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
+                           const double *global_na, int n_global_na, const int32_t *pi, const int32_t *pj,
+                           int64_t n_pairs, int perspective, int alternative, int continuity, uint32_t flags,
+                           int scale_max, int diag_good, double *out5, uint8_t *keep, int64_t *reason_counts);
+/* Wall-clock milliseconds of the last call's phases, the MAXIMUM over the ranks: H2D + pre-pass of the rank's
+ * columns, exchange (all-gather + local rebuild), pair kernel + epilogue, gather + D2H.  With ICIKT_FLAG_TIMING each
  * phase ends with a stream synchronisation, so the figures are device time; without it they are host-side
- * enqueue times except the last, which absorbs everything still in flight. */
+ * enqueue times except the last, which absorbs everything still in flight.  The time a rank waits for the others
+ * at the barriers between the phases is kept apart (icikt_multi_rank_phase_ms). */
 #define ICIKT_MULTI_PHASE_PREPARE 0
 #define ICIKT_MULTI_PHASE_EXCHANGE 1
 #define ICIKT_MULTI_PHASE_PAIRS 2
 #define ICIKT_MULTI_PHASE_GATHER 3
 #define ICIKT_MULTI_PHASES 4
 int icikt_multi_phase_ms(const icikt_multi *m, double *ms);
+/* One rank's figures of the last call: ms[0 .. ICIKT_MULTI_PHASES-1] its phases, ms[ICIKT_MULTI_PHASES] the time it
+ * waited for the other ranks at the barriers (ICIKT_MULTI_PHASES + 1 doubles): a spread between the ranks is
+ * the imbalance of the partition. */
+int icikt_multi_rank_phase_ms(const icikt_multi *m, int rank, double *ms);
+/* Ranks the last icikt_pairs_multi_f64 call really used: n_gpu, or 1 when the job was too small to split (fewer
+ * than two columns or 64 pairs per rank, no rows) or had wide columns (n_feat > ICIKT_MAX_FEATURES) and ran on the
+ * first device alone; 0 after a call that failed its argument checks. */
+int icikt_multi_ranks_used(const icikt_multi *m);
 /* icikt_debug_set_plan() on every rank's context. */
 int icikt_multi_debug_set_plan(icikt_multi *m, const char *spec);
 
@@ -238,7 +277,9 @@ int icikt_selftest(icikt_ctx *ctx);
 /* Development / test hook (the product path reads no environment variable): "key=value,key=value" overrides of
  * the pair kernel's launch plan and of the host path's H2D mode on this context; NULL or "" restores the library's
  * choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g: open-group bitset in LDS | global memory), wpb (waves
- * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), h2d (plain | register | stage),
+ * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), gridmult / gridcap (persistent grid
+ * of the long-column kernel: a multiple of the resident workgroups / at most this many), h2d (register | stage: how
+ * a host matrix of 256 KB or more is read), regfail (0 | 1: behave as if page-locking the caller's memory were refused),
  * verbose (0 | 1: print the chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
 

@@ -24,7 +24,7 @@ def test_header_functions_are_exported():
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/icikt.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert L.icikt_version() == 201
+    assert L.icikt_version() == 300
 
 
 def test_constants_match_header():

@@ -1,0 +1,216 @@
+"""The full-matrix entry icikt_matrix_f64 / icikt_matrix_multi_f64 under -m gpu: setup_missing_matrix (R/utils.R:1-23)
+applied inside the pre-pass, the pair kernels, and scale_and_reshape (R/kendalltau.R:357-421) on the device, against
+ (a) the host assembly of the same pair results (api.ici_kendalltau's pair-list path: bit for bit), and
+ (b) the whole front-end run on the oracle engine (1e-10, the north_star tolerance).
+Also: the transfers when page-locking the caller's memory is refused (the library's own pinned buffers), and the
+per-rank figures of the multi-device driver."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-10
+KEYS = ("cor", "raw", "pvalue", "taumax", "completeness")
+
+
+def _data(n, S, seed, with_nan=True):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, S))
+    X[rng.random((n, S)) < 0.07] = 0.0                    # the default global_na excludes zeros ...
+    X[rng.random((n, S)) < 0.01] = np.inf                 # ... infinities (either sign) ...
+    X[rng.random((n, S)) < 0.01] = -np.inf
+    if with_nan:
+        X[rng.random((n, S)) < 0.03] = np.nan             # ... and NA
+    X[:, 2] = np.round(X[:, 2] * 3)                       # ties (and more zeros)
+    X[:, 5] = np.where(rng.random(n) < 0.6, 0.0, X[:, 5])  # a mostly excluded column
+    return np.asfortranarray(X)
+
+
+def _host_path(X, names, **kw):
+    """The pair-list path of the front-end on the HIP engine: host masking, icikt_pairs_f64, host scale_and_reshape."""
+    from icikendalltau_amd import api
+
+    class PairsOnly(api.HipEngine):       # no .matrix attribute -> api takes the pair-list route
+        def __getattribute__(self, name):
+            if name == "matrix":
+                raise AttributeError(name)
+            return super().__getattribute__(name)
+
+    return api.ici_kendalltau(X, colnames=names, engine=PairsOnly(), **kw)
+
+
+def _same(a, b, exact):
+    for k in KEYS:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        assert x.shape == y.shape
+        assert np.array_equal(np.isnan(x), np.isnan(y)), k
+        if exact:
+            assert np.array_equal(x, y, equal_nan=True), (k, np.nanmax(np.abs(x - y)))
+        else:
+            d = np.nanmax(np.abs(x - y)) if np.any(~np.isnan(x)) else 0.0
+            assert d <= ATOL, (k, d)
+    assert np.array_equal(np.asarray(a["keep"]), np.asarray(b["keep"]))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(perspective="local"),
+    dict(scale_max=False),
+    dict(diag_good=False),
+    dict(global_na=(0,)),                       # NaN in the data stays missing for ici_kt but is NOT excluded: n_good differs
+    dict(global_na=None),
+    dict(global_na=(float("nan"), 0, -1.0, 2.0)),
+    dict(alternative="greater", continuity=True),
+    dict(include_only=["s1", "s4", "nope"]),
+    dict(include_only=[["s0", "s3", "s7"], ["s2", "s9", "s1"]], diag_good=False),
+])
+def test_matrix_entry_equals_host_assembly_and_oracle(hip_ctx, kw):
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+    n, S = 1200, 12
+    X = _data(n, S, seed=len(repr(kw)))
+    X[X == 2.0] = 2.5
+    X[5, 3], X[7, 4] = -1.0, 2.0                           # values the fourth rule excludes
+    names = [f"s{i}" for i in range(S)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fast = api.ici_kendalltau(X, colnames=names, engine=api.HipEngine(), **kw)       # icikt_matrix_f64
+        host = _host_path(X, names, **kw)
+        orac = api.ici_kendalltau(X, colnames=names, engine=OracleEngine(), **kw)
+    _same(fast, host, exact=True)
+    _same(fast, orac, exact=False)
+    assert fast["run_time"] > 0
+
+
+def test_matrix_entry_degenerate_columns_and_warnings(hip_ctx):
+    """All-excluded and constant columns: NA cells, the reference's warning once per offending pair, max(taumax)
+    with na.rm = TRUE over what is left."""
+    from icikendalltau_amd import api
+    n, S = 300, 7
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((n, S)) + 3.0
+    X[:, 1] = 0.0                                          # excluded everywhere: silent NA (reason 1)
+    X[:, 2] = 4.25                                         # constant: "single unique value" (reason 3)
+    X[rng.random(n) < 0.2, 4] = np.nan
+    names = [f"s{i}" for i in range(S)]
+    with warnings.catch_warnings(record=True) as wf:
+        warnings.simplefilter("always")
+        fast = api.ici_kendalltau(X, colnames=names, engine=api.HipEngine())
+    with warnings.catch_warnings(record=True) as wh:
+        warnings.simplefilter("always")
+        host = _host_path(X, names)
+    assert len(wf) == len(wh) == S - 2                     # column 2 against every column but itself and the all-NA one
+    assert sorted(str(w.message) for w in wf) == sorted(str(w.message) for w in wh)
+    _same(fast, host, exact=True)
+    assert np.isnan(np.asarray(fast["raw"])[1, 3]) and np.asarray(fast["raw"])[1, 1] == 0.0   # n_good = 0 on the diagonal
+
+
+def test_matrix_entry_c3_shape(hip_ctx):
+    """c3's shape through the one-call entry: every cell equal to the host assembly of icikt_pairs_f64's results."""
+    from bench import make_matrix
+    from icikendalltau_amd import api
+    n, S = 10000, 256
+    X = make_matrix(n, S, 500, seed=3)
+    names = [f"s{i}" for i in range(S)]
+    fast = api.ici_kendalltau(X, colnames=names, engine=api.HipEngine())
+    host = _host_path(X, names)
+    _same(fast, host, exact=True)
+    assert np.asarray(fast["keep"]).shape == (S, n)
+    assert float(np.abs(np.asarray(fast["cor"])).max()) <= 1.0 + 1e-12
+
+
+def test_matrix_c_abi_contract(hip_ctx):
+    import ctypes
+    from icikendalltau_amd import _lib
+    L = _lib.lib()
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((50, 4)))
+    out5 = np.empty((5, 4, 4))
+    gna = np.array([np.nan, 0.0])
+    args = lambda **o: [hip_ctx._h, o.get("X", X.ctypes.data), 50, 4, o.get("ld", 50), o.get("gna", gna.ctypes.data),
+                        o.get("ngna", 2), None, None, 0, o.get("persp", 1), 0, 0, 0, 1, 1, o.get("out", out5.ctypes.data),
+                        None, None]
+    assert L.icikt_matrix_f64(*args()) == 0
+    assert L.icikt_matrix_f64(*args(X=None)) == -1 and b"null matrix" in L.icikt_last_error(hip_ctx._h)
+    assert L.icikt_matrix_f64(*args(out=None)) == -1
+    assert L.icikt_matrix_f64(*args(ld=49)) == -1
+    assert L.icikt_matrix_f64(*args(persp=7)) == -1
+    many = np.arange(1.0, 9.0)
+    assert L.icikt_matrix_f64(*args(gna=many.ctypes.data, ngna=8)) == -1 and b"global_na" in L.icikt_last_error(hip_ctx._h)
+    assert L.icikt_matrix_f64(*args(gna=None, ngna=0)) == 0
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_matrix_multi_equals_single(hip_ctx, devices):
+    """icikt_matrix_multi_f64: rank threads apply the exclusion rule to their own columns, return their rows of keep,
+    the first device assembles.  One rank = real RCCL on a one-rank communicator; a device listed more than once =
+    device copies in place of the collectives (ragged column shards and pair blocks)."""
+    from icikendalltau_amd import _lib
+    n, S = 2000, 26
+    X = _data(n, S, seed=77)
+    gna = (float("nan"), float("inf"), 0.0)
+    ref5, refk, refc = hip_ctx.matrix(X, gna)
+    m = _lib.MultiContext(devices)
+    try:
+        out5, keep, rc = m.matrix(X, gna)
+        assert m.ranks_used == len(devices)
+        assert np.array_equal(out5, ref5, equal_nan=True) and np.array_equal(keep, refk) and np.array_equal(rc, refc)
+        per_rank = m.rank_phase_ms()
+        assert len(per_rank) == len(devices) and all(set(p) == {"prepare", "exchange", "pairs", "gather", "wait"} for p in per_rank)
+        mx = m.phase_ms()
+        assert all(abs(mx[k] - max(p[k] for p in per_rank)) < 1e-9 for k in mx)
+        # an explicit list (self pairs, no diagonal rows)
+        iu, ju = np.triu_indices(S, k=0)
+        o2, k2, _ = m.matrix(X, gna, iu.astype(np.int32), ju.astype(np.int32), diag_good=False)
+        r2, rk2, _ = hip_ctx.matrix(X, gna, iu.astype(np.int32), ju.astype(np.int32), diag_good=False)
+        assert np.array_equal(o2, r2, equal_nan=True) and np.array_equal(k2, rk2)
+        # too small to split: the first device alone, and the caller can tell
+        o3, _k, _c = m.matrix(X[:, :3], gna)
+        assert m.ranks_used == (1 if len(devices) > 1 else len(devices))
+        r3, _k, _c = hip_ctx.matrix(np.asfortranarray(X[:, :3]), gna)
+        assert np.array_equal(o3, r3, equal_nan=True)
+    finally:
+        m.close()
+
+
+def test_transfers_when_page_locking_is_refused(plan_ctx):
+    """icikt_debug_set_plan("regfail=1") makes the library behave as if every hipHostRegister were refused: the
+    matrix (21 MB), the pair and task lists and the result arrays then go through the library's own pinned buffers
+    (staging double buffer, bounce chunks, a pinned allocation per result array) -- never an asynchronous copy from
+    or into pageable memory.  Same bytes out as on the default path; both host entries and the multi-device one."""
+    from icikendalltau_amd import _lib
+    rng = np.random.default_rng(5)
+    n, S = 9000, 300
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random((n, S)) < 0.05] = np.nan
+    plan_ctx.debug_set_plan(None)
+    ref = plan_ctx.pairs(X, perspective="global")
+    ref5 = plan_ctx.matrix(X, (float("nan"),))
+    plan_ctx.debug_set_plan({"regfail": 1})
+    got = plan_ctx.pairs(X, perspective="global")
+    got5 = plan_ctx.matrix(X, (float("nan"),))
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref5, got5))
+    plan_ctx.debug_set_plan({"h2d": "stage"})
+    got = plan_ctx.pairs(X, perspective="global")
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    # a caller that has page-locked its matrix itself: the library's registration is refused, the range is found
+    # pinned, the copies run straight from it
+    import torch
+    cudart = torch.cuda.cudart()
+    plan_ctx.debug_set_plan(None)
+    assert int(cudart.cudaHostRegister(X.ctypes.data, X.nbytes, 0)) == 0
+    try:
+        got = plan_ctx.pairs(X, perspective="global")
+    finally:
+        cudart.cudaHostUnregister(X.ctypes.data)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    m = _lib.MultiContext([0, 0])
+    try:
+        m.debug_set_plan({"regfail": 1})
+        got = m.pairs(X, perspective="global")
+        assert m.ranks_used == 2
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    finally:
+        m.close()

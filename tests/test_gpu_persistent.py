@@ -1,0 +1,151 @@
+"""The long-column pair kernel k1_pairs<1, true, 0> under -m gpu: `pend` in global memory, a persistent grid whose
+waves FETCH many tasks in order from per-XCD counters and reuse one pend slot that every task must leave all zero
+(icikt_capi.cpp: icikt_run_dev, "pend_global"; icikt_kernels.hip: the task loop of k1_pairs).  The natural plan of
+the small matrices an oracle can afford gives every wave at most one task, so the grid is capped through
+icikt_debug_set_plan("gridcap=...") -- every wave then runs ten or more tasks back to back -- plus one natural-plan
+case with more tasks than resident waves, the c4b configuration (Bernoulli(0.1) missingness,
+a fifth of the columns in the reference's int32-wrap regime, src/kendallc.cpp:112-114) and the column lengths on
+either side of the 15-bit packed two-step count of the one-pair kernels (n = 32 768)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-10
+
+
+def _oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _tied_matrix(n, S, seed):
+    """Columns that exercise every step kind of the pair kernel: continuous, many small tie groups, a few huge ones,
+    left-censored missing values (the closed-form last group), scattered missing values, half-missing."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, S))
+    for c in range(S):
+        kind = c % 6
+        if kind == 1:
+            X[:, c] = np.round(X[:, c] * 300)            # ~1 800 distinct values: groups inside a step
+        elif kind == 2:
+            X[:, c] = np.round(X[:, c] * 3)              # ~20 distinct values: groups of thousands of rows
+        elif kind == 3:
+            k = n // 25                                  # left-censored: the missing rows are the last tie group
+            X[np.argpartition(X[:, c], k)[:k], c] = np.nan
+        elif kind == 4:
+            X[rng.random(n) < 0.3, c] = np.nan           # scattered
+            X[:, c] = np.round(X[:, c] * 40)             # ... and tied
+        elif kind == 5:
+            X[rng.random(n) < 0.5, c] = np.nan           # half missing, otherwise continuous
+    return np.asfortranarray(X)
+
+
+def _all_pairs_vs_oracle(ctx, X, perspectives=("global", "local")):
+    O = _oracle()
+    S = X.shape[1]
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    for perspective in perspectives:
+        out, cnt, rsn = ctx.pairs(X, perspective=perspective)
+        ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, perspective)
+        assert np.array_equal(rsn, rrsn)
+        assert np.array_equal(cnt, rcnt[:, :cnt.shape[1]]), "integer counts differ from the oracle"
+        assert np.array_equal(np.isnan(out), np.isnan(ref))
+        assert float(np.nanmax(np.abs(out - ref))) <= ATOL
+
+
+@pytest.mark.parametrize("n", [33000, 50000, 65535])
+def test_persistent_waves_run_many_tasks(plan_ctx, n):
+    """276 pairs on a grid capped at 8 workgroups = 32 waves: every wave fetches eight or nine tasks in a row from its
+    XCD group's counter and reuses its global pend slot after tasks that opened, extended and merged tie groups.
+    All pairs, both perspectives, counts bit-exact.  Then a matrix of another length on the SAME context: a new
+    stride meets whatever the earlier tasks left in the slots."""
+    plan_ctx.debug_set_plan({"np": 1, "pend": "g", "gridcap": 8})
+    X = _tied_matrix(n, 24, seed=n)
+    _all_pairs_vs_oracle(plan_ctx, X)
+    plan_ctx.debug_set_plan({"np": 1, "pend": "g", "gridcap": 3})      # fewer groups than XCD counters
+    X2 = _tied_matrix(41000 if n != 50000 else 36111, 12, seed=n + 1)
+    _all_pairs_vs_oracle(plan_ctx, X2)
+    # and the first matrix again with the library's own grid: same numbers as under the cap
+    plan_ctx.debug_set_plan(None)
+    capped = plan_ctx.pairs(X, perspective="global")
+    plan_ctx.debug_set_plan({"gridcap": 1})                             # one workgroup, one counter: four waves do it all
+    one = plan_ctx.pairs(X, perspective="global")
+    assert np.array_equal(capped[0], one[0]) and np.array_equal(capped[1], one[1])
+
+
+def test_persistent_grid_natural_plan(hip_ctx):
+    """36 000 x 128 = 8 128 tasks against the ~5 000 waves the chip holds at that length: the library's own plan
+    makes waves take a second task.  Oracle on 300 sampled pairs, count identities on all."""
+    from bench import make_matrix
+    from tests.test_gpu_configs import _properties, _sample_check
+    n, S, n_na = 36000, 128, 720
+    X = make_matrix(n, S, n_na, seed=36)
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    for perspective in ("global", "local"):
+        out, cnt, rsn = hip_ctx.pairs(X, perspective=perspective)
+        _properties(n, n_na, out, cnt, rsn, perspective)
+        _sample_check(X, pi, pj, out, cnt, rsn, perspective, 300, seed=360)
+
+
+def test_config_c4b(hip_ctx):
+    """c4b (BASELINE.md section 3 / SURVEY.md section 8(d)): the c4 matrix with Bernoulli(0.1) missingness instead of
+    exactly 1 000 missing rows per column.  About a fifth of the columns then have a fill group of >= 1 024 rows, where
+    the reference's int32 t(t-1)(2t+5) wraps (src/kendallc.cpp:112-114): the default mode must reproduce the wrap, the
+    ICIKT_FLAG_EXACT_INT64 mode must not.  Full size (523 776 pairs), 2 000 sampled pairs per mode against the
+    oracle's two modes."""
+    O = _oracle()
+    n, S = 10000, 1024
+    rng = np.random.default_rng(4)
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random((n, S)) < 0.1] = np.nan
+    nna = np.isnan(X).sum(axis=0)
+    wrap_cols = int((nna >= 1024).sum())
+    assert 100 < wrap_cols < 400, wrap_cols               # ~21 % of the columns are in the wrap regime
+    pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+    sel = np.random.default_rng(404).choice(len(pi), size=2000, replace=False)
+    in_wrap = (nna[pi[sel]] >= 1024) | (nna[pj[sel]] >= 1024)
+    assert in_wrap.sum() > 400
+    res = {}
+    for flags in (0, 1):
+        out, cnt, rsn = hip_ctx.pairs(X, perspective="global", flags=flags)
+        assert out.shape == (len(pi), 4) and np.all(rsn == 0) and not np.isnan(out).any()
+        ref, rcnt, rrsn = O.ici_pairs(X, pi[sel], pj[sel], "global", int32_compat=(flags == 0))
+        assert np.all(rrsn == 0)
+        assert np.array_equal(cnt[sel], rcnt[:, :cnt.shape[1]]), "integer counts differ from the oracle"
+        assert float(np.max(np.abs(out[sel] - ref))) <= ATOL
+        res[flags] = (out, cnt)
+    # tau, tau_max and completeness do not depend on the mode (the wrap reaches x1 / y1 only, i.e. the variance)
+    assert np.array_equal(res[0][0][:, [0, 2, 3]], res[1][0][:, [0, 2, 3]])
+    differs = np.any(res[0][1] != res[1][1], axis=1)
+    col_wrap = nna >= 1024
+    assert np.array_equal(differs, col_wrap[pi] | col_wrap[pj])      # exactly the pairs that touch a wrapping column
+    # local on a column block that holds wrapping columns: K2 re-derives the shrunken fill group in the same arithmetic
+    sub = np.concatenate([np.nonzero(col_wrap)[0][:12], np.nonzero(~col_wrap)[0][:12]])
+    Xs = np.asfortranarray(X[:, sub])
+    qi, qj = (a.astype(np.int32) for a in np.triu_indices(len(sub), k=1))
+    for flags in (0, 1):
+        out, cnt, rsn = hip_ctx.pairs(Xs, perspective="local", flags=flags)
+        ref, rcnt, rrsn = O.ici_pairs(Xs, qi, qj, "local", int32_compat=(flags == 0))
+        assert np.array_equal(rsn, rrsn) and np.array_equal(cnt, rcnt[:, :cnt.shape[1]])
+        assert float(np.max(np.abs(out - ref))) <= ATOL
+
+
+@pytest.mark.parametrize("n", [32704, 32767, 32768, 32769])
+def test_packed_two_step_count_at_its_limit(plan_ctx, n):
+    """One pair per wave counts the in-step pairs of two hot steps in one packed chain while positions fit 15 bits
+    (n <= 32 768: wave_allpairs_packed2, A = 0x7FFF - q, B = lo).  Columns without ties or missing values, so that q
+    and lo reach n - 1 (A = 0 and B = 0x7FFF at n = 32 768) and the hot loop covers the whole column -- 511 steps at
+    32 767 (an odd step out), 512 at 32 768, the unpacked compare at 32 769; plus columns whose hot region ends early
+    (missing rows) at an odd and an even step count.  pend in LDS and in global memory."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 6))
+    X[:, 1] = -X[:, 0] + 1e-3 * X[:, 1]                     # strongly discordant with column 0: many flags set
+    X[:, 2] = np.arange(n, dtype=np.float64)                # sorted: q = row
+    X[np.argpartition(X[:, 3], 64 * 3 + 5)[:64 * 3 + 5], 3] = np.nan     # hot region n - 197 rows
+    X[np.argpartition(X[:, 4], 64 * 4 + 9)[:64 * 4 + 9], 4] = np.nan     # hot region n - 265 rows
+    X[:, 5] = np.round(X[:, 5] * 1000)                      # tie groups inside steps: the packed loop is left early
+    X = np.asfortranarray(X)
+    for plan in ({"np": 1, "pend": "l"}, {"np": 1, "pend": "g", "gridcap": 2}):
+        plan_ctx.debug_set_plan(plan)
+        _all_pairs_vs_oracle(plan_ctx, X)

@@ -12,7 +12,7 @@ X = make_matrix(n, S, na, seed)
 P = S * (S - 1) // 2
 ctx = _lib.Context(0)
 ref = None
-for mode in ("plain", "register", "stage", ""):
+for mode in ("register", "stage", ""):
     ctx.debug_set_plan({"h2d": mode})
     ts = []
     for _ in range(4):

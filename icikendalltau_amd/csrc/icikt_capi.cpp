@@ -726,16 +726,25 @@ static bool pinned_already(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
-  if (c->force_reg_fail) return HostLock::Refused;
-  if (hipHostRegister(const_cast<void*>(p), bytes, flags) == hipSuccess) return HostLock::Locked;
-  (void)hipGetLastError();
-  // refused: fine if the caller has page-locked the range itself -- every probe of it (both ends and one per MB) must
-  // say so; anything else goes through the library's own pinned buffers
+// every probe of the range (both ends and one per MB) lies in memory that is page-locked already
+static bool range_pinned_already(const void* p, size_t bytes) {
   bool all = pinned_already(p) && pinned_already(static_cast<const char*>(p) + bytes - 1);
   for (size_t off = (size_t)1 << 20; all && off < bytes; off += (size_t)1 << 20)
     all = pinned_already(static_cast<const char*>(p) + off);
-  return all ? HostLock::Already : HostLock::Refused;
+  return all;
+}
+
+HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
+  if (c->force_reg_fail) return HostLock::Refused;
+  // A range the caller has page-locked itself is used as it is.  (Asked first: this runtime ACCEPTS a second
+  // hipHostRegister of a registered range, and the hipHostUnregister that ends it takes the caller's registration
+  // away with it -- seen as "pointer does not correspond to a registered memory region" on the caller's own
+  // unregister.)
+  if (range_pinned_already(p, bytes)) return HostLock::Already;
+  if (hipHostRegister(const_cast<void*>(p), bytes, flags) == hipSuccess) return HostLock::Locked;
+  (void)hipGetLastError();
+  // refused for any other reason: the bytes go through the library's own pinned buffers
+  return HostLock::Refused;
 }
 
 int ensure_bounce(icikt_ctx* c, size_t need) {

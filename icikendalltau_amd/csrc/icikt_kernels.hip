@@ -2743,8 +2743,11 @@ __global__ void k_selftest(uint32_t* out) {
 // ------------------------------------------------------------------------------------------------
 // launchers (called from icikt_capi.cpp; keeps <<<>>> syntax inside the .hip translation unit)
 // ------------------------------------------------------------------------------------------------
+// (every launcher first drops whatever error an earlier, unrelated HIP call of the calling thread left behind: the
+//  hipGetLastError() after the launch must report THIS launch)
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, const MaskSpec* msp,
                      uint8_t* keep, hipStream_t s) {
+  (void)hipGetLastError();
   MaskSpec ms{};
   if (msp) ms = *msp;
   if (pv.wide) hipLaunchKernelGGL(k0_prepare<true>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
@@ -2855,6 +2858,7 @@ k_assemble_diag(PrepView pv, const int64_t* __restrict__ n_good, const unsigned 
 
 hipError_t launch_out_stats(const PrepView& pv, const double* out4, const int32_t* reasons, int64_t n_pairs,
                             const int64_t* n_good, unsigned long long* red, hipStream_t s) {
+  (void)hipGetLastError();
   hipError_t e = hipMemsetAsync(red, 0, 8 * sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
   const int64_t work = std::max<int64_t>(n_pairs, pv.n_samp);
@@ -2868,6 +2872,7 @@ hipError_t launch_assemble(const PrepView& pv, const double* out4, const int32_t
                            double* out5, hipStream_t s) {
   const size_t S = (size_t)pv.n_samp;
   if (S == 0) return hipSuccess;
+  (void)hipGetLastError();
   hipError_t e = hipMemsetAsync(out5, 0, 5 * S * S * sizeof(double), s);
   if (e != hipSuccess) return e;
   if (n_pairs > 0)
@@ -2881,6 +2886,7 @@ hipError_t launch_assemble(const PrepView& pv, const double* out4, const int32_t
 hipError_t launch_k1_wide(const PrepView& pv, const int32_t* pi, const int32_t* pj, PairRaw* raw, int64_t n_pairs,
                           int blocks, size_t lds_bytes, int* task_ctr, hipStream_t s) {
   if (n_pairs <= 0 || blocks <= 0) return hipSuccess;
+  (void)hipGetLastError();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -2924,6 +2930,7 @@ hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, cons
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
   k1_fn_t fn = k1_select(np, pend_global, half_items);
   if (!fn) return hipErrorInvalidValue;
+  (void)hipGetLastError();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
@@ -2946,6 +2953,7 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
                      int64_t n_pairs, int perspective, int alternative, int continuity, int exact64,
                      double* out4, int64_t* counts, int32_t* reasons, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
+  (void)hipGetLastError();
   const int threads = 256;
   const int64_t blocks = (n_pairs + threads - 1) / threads;
   hipLaunchKernelGGL(k2_epilogue, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, raw, n_pairs,
@@ -2955,6 +2963,7 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
 
 hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s) {
   if (ncols <= 0 || pv.n <= 0) return hipSuccess;
+  (void)hipGetLastError();
   const int staged = (pv.n_pad <= 16384) ? 1 : 0;
   const size_t lds = staged ? (size_t)pv.n_pad * 6 : 0;
   if (staged) {
@@ -2968,6 +2977,7 @@ hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStr
 hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
                               int64_t* missing, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
+  (void)hipGetLastError();
   const int threads = 256;
   const int64_t blocks = (n_pairs * 64 + threads - 1) / threads;
   hipLaunchKernelGGL(k_missingness, dim3((unsigned)blocks), dim3(threads), 0, s, pv, pi, pj, n_pairs, missing);
@@ -2977,12 +2987,14 @@ hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32
 hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,
                              int64_t npairs, double* dXp, hipStream_t s) {
   if (npairs <= 0 || n <= 0) return hipSuccess;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(k_mask_pairs, dim3((unsigned)((n + 255) / 256), (unsigned)npairs), dim3(256), 0, s, dX, ld, n, pi,
                      pj, first, dXp);
   return hipGetLastError();
 }
 
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t s) {
+  (void)hipGetLastError();
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
   return hipGetLastError();
 }

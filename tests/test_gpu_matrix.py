@@ -101,8 +101,9 @@ def test_matrix_entry_degenerate_columns_and_warnings(hip_ctx):
     with warnings.catch_warnings(record=True) as wh:
         warnings.simplefilter("always")
         host = _host_path(X, names)
-    assert len(wf) == len(wh) == S - 2                     # column 2 against every column but itself and the all-NA one
-    assert sorted(str(w.message) for w in wf) == sorted(str(w.message) for w in wh)
+    mf = sorted(str(w.message) for w in wf if "NA returned" in str(w.message))
+    mh = sorted(str(w.message) for w in wh if "NA returned" in str(w.message))
+    assert len(mf) == S - 2 and mf == mh, (mf, [str(w.message) for w in wh])   # column 2 against every column but itself and the all-NA one
     _same(fast, host, exact=True)
     assert np.isnan(np.asarray(fast["raw"])[1, 3]) and np.asarray(fast["raw"])[1, 1] == 0.0   # n_good = 0 on the diagonal
 
@@ -195,8 +196,8 @@ def test_transfers_when_page_locking_is_refused(plan_ctx):
     plan_ctx.debug_set_plan({"h2d": "stage"})
     got = plan_ctx.pairs(X, perspective="global")
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
-    # a caller that has page-locked its matrix itself: the library's registration is refused, the range is found
-    # pinned, the copies run straight from it
+    # a caller that has page-locked its matrix itself: the library finds the range pinned, copies straight from it and
+    # leaves the caller's registration alone (the caller's own unregister must still succeed afterwards)
     import torch
     cudart = torch.cuda.cudart()
     plan_ctx.debug_set_plan(None)
@@ -204,7 +205,8 @@ def test_transfers_when_page_locking_is_refused(plan_ctx):
     try:
         got = plan_ctx.pairs(X, perspective="global")
     finally:
-        cudart.cudaHostUnregister(X.ctypes.data)
+        rc_unreg = int(cudart.cudaHostUnregister(X.ctypes.data))
+    assert rc_unreg == 0
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
     m = _lib.MultiContext([0, 0])
     try:

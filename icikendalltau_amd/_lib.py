@@ -49,6 +49,7 @@ EXPORTS = (
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
     "icikt_matrix_f64", "icikt_matrix_multi_f64", "icikt_multi_rank_phase_ms", "icikt_multi_ranks_used",
+    "icikt_debug_step_stats",
 )
 
 
@@ -63,21 +64,22 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP kernels + C ABI for gfx950 into icikendalltau_amd/libicikt_hip.so."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile the HIP kernels + C ABI for gfx950 into icikendalltau_amd/libicikt_hip.so (or, for the development
+    tools, a variant build with extra_flags into `out`: loaded through ICIKT_LIB)."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     hipcc = os.environ.get("HIPCC", os.path.join(rocm, "bin", "hipcc"))
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", *extra_flags,
            "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_PKG, "csrc"),
-           "-o", LIB_PATH] + SOURCES + ["-L", os.path.join(rocm, "lib"), "-lrccl", "-pthread"]
+           "-o", out or LIB_PATH] + SOURCES + ["-L", os.path.join(rocm, "lib"), "-lrccl", "-pthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise IciktError("hipcc failed:\n" + res.stdout + res.stderr)
     if verbose:
         print(" ".join(cmd))
-    return LIB_PATH
+    return out or LIB_PATH
 
 
 _lib = None
@@ -148,6 +150,7 @@ def lib():
     L.icikt_matrix_multi_f64.argtypes = L.icikt_matrix_f64.argtypes
     L.icikt_multi_rank_phase_ms.argtypes = [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]
     L.icikt_multi_ranks_used.argtypes = [c_vp]
+    L.icikt_debug_step_stats.argtypes = [c_vp, c_vp, c_int]
     for name in EXPORTS:
         if getattr(L, name).restype is not None and name not in ("icikt_last_error", "icikt_num_pairs",
                                                                    "icikt_multi_last_error"):
@@ -289,6 +292,13 @@ class Context:
 
     def selftest(self):
         self._chk(lib().icikt_selftest(self._h), "icikt_selftest")
+
+    def step_stats(self, reset: bool = True):
+        """Diagnostic builds only (-DICIKT_STEP_STATS): {kind: (steps, rows, wave cycles)} of the pair kernel."""
+        buf = np.zeros(24, dtype=np.uint64)
+        self._chk(lib().icikt_debug_step_stats(self._h, _ptr(buf), int(reset)), "icikt_debug_step_stats")
+        kinds = ("hot_loop", "hot_in_main", "mixed", "group", "general", "tail", "setup")
+        return {k: (int(buf[i]), int(buf[8 + i]), int(buf[16 + i])) for i, k in enumerate(kinds)}
 
     def debug_set_plan(self, spec: str | dict | None = None):
         """Test / experiment hook: override the pair kernel's launch plan ("np=1,pend=g,..." or a dict; None resets)."""

@@ -1268,6 +1268,21 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   return ICIKT_SUCCESS;
 }
 
+// Development hook: per step kind of the pair kernel [steps x 8 | rows x 8 | wave cycles x 8] since the last reset.
+// Only a diagnostic build (-DICIKT_STEP_STATS) counts; the product build answers ICIKT_E_STATE.
+int icikt_debug_step_stats(icikt_ctx* c, uint64_t* out24, int reset) {
+  if (!c || !out24) return ICIKT_E_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long tmp[24];
+  const hipError_t e = icikt::read_step_stats(tmp, reset);
+  if (e == hipErrorNotSupported) { (void)hipGetLastError(); return fail(c, ICIKT_E_STATE, "debug_step_stats: not a -DICIKT_STEP_STATS build"); }
+  HIPCHK(c, e);
+  for (int i = 0; i < 24; ++i) out24[i] = tmp[i];
+  return ICIKT_SUCCESS;
+}
+
 int icikt_selftest(icikt_ctx* c) {
   if (!c) return ICIKT_E_INVALID;
   int rc = use_device(c);

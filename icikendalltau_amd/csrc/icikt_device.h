@@ -21,9 +21,11 @@ struct ColStats {
   uint32_t ntg;      // tie groups of size >= 2 (length of the column's tgroups list)
   long long e0, e1, e2;  // the same sums exactly
   double fill;           // min - 0.1
-  long long nexcl;       // rows excluded by the caller's global_na rule (MaskSpec): exclude_loc of R/utils.R:1-23.
+  int32_t nexcl;         // rows excluded by the caller's global_na rule (MaskSpec): exclude_loc of R/utils.R:1-23.
                          // == nna unless the data hold NaN and NaN is not in global_na
+  int32_t flags;         // COL_ODD_TIE: some tie group of >= 2 rows starts at an ODD ascending position
 };
+constexpr int COL_ODD_TIE = 1;
 
 // setup_missing_matrix (R/utils.R:1-23) on the device: which cells of the data matrix are excluded (become NA,
 // R/kendalltau.R:119-121) before the pre-pass.  The pre-pass applies it while it reads the matrix, so the masked copy
@@ -156,6 +158,7 @@ hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32
 hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,
                              int64_t npairs, double* dXp, hipStream_t s);
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t s);
+hipError_t read_step_stats(unsigned long long* out24, int reset);
 
 }  // namespace icikt
 #endif

@@ -460,7 +460,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   };
 
   // per-thread tie statistics over the groups that START at my positions
-  int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0;
+  int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0, oddtie = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
   long long e0 = 0, e1 = 0, e2 = 0;     // exact
   for (int base = 0; base < n; base += K0_THREADS) {
@@ -488,6 +488,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
         if (lo == 0) tfill = t;
         if (t >= 2) {
           ++ntg_local;
+          oddtie |= lo & 1;
           const uint32_t ut = (uint32_t)t;
           const uint32_t tt1 = ut * (ut - 1u);
           s0 += tt1;
@@ -552,6 +553,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });
   maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; });
   tfill = block_reduce<int>(tfill, sh_i, [](int a, int b) { return a > b ? a : b; });
+  oddtie = block_reduce<int>(oddtie, sh_i, [](int a, int b) { return a | b; });
   s0 = (uint32_t)block_reduce<int>((int)s0, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
   s1 = (uint32_t)block_reduce<int>((int)s1, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
   s2 = (uint32_t)block_reduce<int>((int)s2, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
@@ -569,6 +571,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     st.e0 = e0; st.e1 = e1; st.e2 = e2;
     st.fill = fill;
     st.nexcl = nexcl;
+    st.flags = oddtie ? COL_ODD_TIE : 0;
     *pv.col_stats(c) = st;
   }
 }
@@ -1675,6 +1678,28 @@ __device__ __attribute__((noinline)) void seg_group_close(const SegState st, con
   wave_lds_fence();
 }
 
+// Diagnostic build only (-DICIKT_STEP_STATS, tools/step_stats.py; in the product build no stamp executes): per step
+// kind the steps taken, their rows and the wave cycles (s_memtime) spent in them, summed over all waves.
+//   kind 0 hot loop   1 hot step met in the main loop   2 MIXED   3 GROUP (with its closes)   4 general step (pend in
+//   global memory)    5 closed-form tail   6 task set-up and final reductions
+#ifdef ICIKT_STEP_STATS
+__device__ unsigned long long g_step_stats[24];
+#define ICIKT_ST_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(); \
+  unsigned long long st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0, st_c4 = 0, st_c5 = 0, st_c6 = 0; \
+  unsigned st_s0 = 0, st_s1 = 0, st_s2 = 0, st_s3 = 0, st_s4 = 0, st_s5 = 0, st_s6 = 0; \
+  unsigned st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_r4 = 0, st_r5 = 0, st_r6 = 0;
+#define ICIKT_ST_MARK(K, ROWS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_c##K += t_ - st_t; st_t = t_; \
+  st_s##K += 1u; st_r##K += (unsigned)(ROWS); }
+#define ICIKT_ST_FLUSH1(K) { atomicAdd(&g_step_stats[K], (unsigned long long)st_s##K); atomicAdd(&g_step_stats[8 + K], (unsigned long long)st_r##K); \
+  atomicAdd(&g_step_stats[16 + K], st_c##K); }
+#define ICIKT_ST_FLUSH if (lane == 0u) { ICIKT_ST_FLUSH1(0) ICIKT_ST_FLUSH1(1) ICIKT_ST_FLUSH1(2) ICIKT_ST_FLUSH1(3) ICIKT_ST_FLUSH1(4) \
+  ICIKT_ST_FLUSH1(5) ICIKT_ST_FLUSH1(6) }
+#else
+#define ICIKT_ST_DECL
+#define ICIKT_ST_MARK(K, ROWS)
+#define ICIKT_ST_FLUSH
+#endif
+
 // Variants: <1, PG, 0> one pair per wave (any n; PG = pend in global memory) and <2, false, HI> two pairs per
 // wave, one per half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild.
 // A task is (pair, pair or -1).  The two pairs of a task share their STREAMED column (pj) and their gathered
@@ -1740,6 +1765,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   }
   if (task >= t_hi) return;
   do {
+  ICIKT_ST_DECL
   int pidx[NP];
   pidx[0] = __builtin_amdgcn_readfirstlane(tasks[2 * task]);
   const int p_second = __builtin_amdgcn_readfirstlane(tasks[2 * task + 1]);
@@ -1762,6 +1788,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   PairState S[NP];
   PendG Pg[NP];
   uint32_t cb[NP], gg[NP];
+  bool g_oddtie = false;       // the (first) gathered column has a tie group that starts at an odd position
   const uint32_t* rec_blk;
   {
     const int g0 = __builtin_amdgcn_readfirstlane(pi[pidx[0]]);
@@ -1775,6 +1802,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
     ntgB[k] = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
+    if (k == 0) g_oddtie = (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
 
@@ -1870,6 +1898,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   uint32_t seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
   bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
   int pos = 0;
+  ICIKT_ST_MARK(6, 0)
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
   // the ring moves on by a 64-row step: next step's rows are in r1 already -> gather its rec values now
@@ -1962,7 +1991,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     if (pos + 64 <= hot_until) {
       // The singleton region (on continuous data: everything but the rows missing in the streamed column): a loop
       // of its own, so that the tie steps' state does not live in (or get merged into) the hot loop's registers.
-      const bool pack2 = (NP == 1) && (n <= 32768);
+      // ... and on longer columns too, with HALVED positions: the chain compares q >> 1 with (lo + 1) >> 1, 15 bits each,
+      // and  q >> 1 < (lo + 1) >> 1  <=>  q < lo + (lo & 1):  exactly q < lo unless q == lo with lo odd -- another row at
+      // the first position of the row's own tie group, i.e. a tie group of >= 2 rows that starts at an odd position.
+      // Columns without one (K0 notes it: COL_ODD_TIE; continuous data never have one, the fill group starts at 0)
+      // take the packed chain at any length; the others keep the two-instruction compare above 32 768 rows.
+      const bool halved = (NP == 1) && (n > 32768) && !g_oddtie;
+      const bool pack2 = (NP == 1) && ((n <= 32768) || halved);
       bool have_prev = false;      // wave-uniform
       uint32_t rk_prev = 0;
       defer_allpairs = pack2;
@@ -1982,10 +2017,18 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         advance64();
         hot_step(rk);
         if (pack2) {
-          if (have_prev) S[0].dis += wave_allpairs_packed2(rk_prev, rk[0], lane);
+          if (have_prev) {
+            uint32_t ka = rk_prev, kb = rk[0];
+            if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
+              ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
+              kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+            }
+            S[0].dis += wave_allpairs_packed2(ka, kb, lane);
+          }
           else rk_prev = rk[0];
           have_prev = !have_prev;
         }
+        ICIKT_ST_MARK(0, 64)
       } while (pos + 64 <= hot_until);
       if (pack2 && have_prev) S[0].dis += wave_allpairs(rk_prev & 0xFFFFu, rk_prev >> 16, lane);   // an odd step out
       defer_allpairs = false;
@@ -2129,6 +2172,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 
     if (all_fast) {
       hot_step(rk);
+      ICIKT_ST_MARK(1, 64)
       continue;
     }
 
@@ -2204,6 +2248,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
       }
       dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
+      if (kind == 1) { ICIKT_ST_MARK(2, nact) } else { ICIKT_ST_MARK(3, nact) }
     } else {
     // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
     {
@@ -2223,6 +2268,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
                                               hiG[k], tgB[k], ntgB[k], Wp, items, lane);
       S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
     }
+    ICIKT_ST_MARK(4, nact)
     }  // general step
   }
 
@@ -2277,6 +2323,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const unsigned long long m = (unsigned long long)(n - last_start);
       corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
     }
+    ICIKT_ST_MARK(5, n - last_start)
   }
 
 #pragma unroll
@@ -2298,6 +2345,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
   }
   wave_lds_fence();
+  ICIKT_ST_MARK(6, 0)
+  ICIKT_ST_FLUSH
     if (PG) {
       int t = 0;
       if (lane == 0u) t = atomicAdd(my_ctr, 1);
@@ -2991,6 +3040,21 @@ hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t*
   hipLaunchKernelGGL(k_mask_pairs, dim3((unsigned)((n + 255) / 256), (unsigned)npairs), dim3(256), 0, s, dX, ld, n, pi,
                      pj, first, dXp);
   return hipGetLastError();
+}
+
+// diagnostic build: copy out (and optionally clear) the step statistics; hipErrorNotSupported in the product build
+hipError_t read_step_stats(unsigned long long* out24, int reset) {
+#ifdef ICIKT_STEP_STATS
+  hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_step_stats), 24 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[24] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_step_stats), z, sizeof(z));
+  }
+  return e;
+#else
+  (void)out24; (void)reset;
+  return hipErrorNotSupported;
+#endif
 }
 
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t s) {

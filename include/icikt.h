@@ -282,6 +282,11 @@ int icikt_selftest(icikt_ctx *ctx);
  * a host matrix of 256 KB or more is read), regfail (0 | 1: behave as if page-locking the caller's memory were refused),
  * verbose (0 | 1: print the chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
+/* Development hook: per step kind of the pair kernel (hot loop, hot step in the main loop, MIXED, GROUP, general,
+ * closed-form tail, set-up) the steps taken, their rows and the wave cycles spent, as out24 = [steps x 8 | rows x 8 |
+ * cycles x 8] since the last reset.  Counted only by a diagnostic build of the library (-DICIKT_STEP_STATS,
+ * tools/step_stats.py); the product build executes no stamp and answers ICIKT_E_STATE. */
+int icikt_debug_step_stats(icikt_ctx *ctx, uint64_t *out24, int reset);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,35 @@ def test_packed_two_step_count_at_its_limit(plan_ctx, n):
     for plan in ({"np": 1, "pend": "l"}, {"np": 1, "pend": "g", "gridcap": 2}):
         plan_ctx.debug_set_plan(plan)
         _all_pairs_vs_oracle(plan_ctx, X)
+
+
+@pytest.mark.parametrize("n", [32770, 40001, 65535])
+def test_halved_positions_in_the_packed_chain(plan_ctx, n):
+    """Above 32 768 rows the one-pair kernels pack two hot steps with HALVED positions (q >> 1 against (lo + 1) >> 1),
+    exact as long as no tie group of the gathered column starts at an odd position (K0: COL_ODD_TIE).  Gathered columns:
+    continuous (flag clear: halved chain), continuous with missing rows (fill group at position 0: clear), tie groups of
+    two rows that ALL start at even positions (clear: the chain meets q == lo with lo even), the same shifted by one row
+    (every group starts at an odd position: flag set, the unpacked compare), strongly correlated columns (rows adjacent
+    in both orders share steps: q = lo - 1 and q = lo + 1 inside a step)."""
+    rng = np.random.default_rng(n)
+    base = rng.standard_normal(n)
+    X = np.empty((n, 7))
+    X[:, 0] = base
+    X[:, 1] = base + 1e-4 * rng.standard_normal(n)               # near-identical order: neighbours in A are neighbours in B
+    X[:, 2] = -base + 1e-4 * rng.standard_normal(n)              # ... and reversed
+    r = np.argsort(np.argsort(rng.standard_normal(n)))           # ranks 0 .. n-1
+    X[:, 3] = r // 2                                             # pairs (0,1), (2,3), ...: every tie group starts even
+    X[:, 4] = (r + 1) // 2                                       # (1,2), (3,4), ...: every tie group starts odd
+    X[:, 5] = rng.standard_normal(n)
+    X[np.argpartition(X[:, 5], 777)[:777], 5] = np.nan           # left-censored: the fill group starts at 0
+    X[:, 6] = np.where(rng.random(n) < 0.4, np.nan, base + 0.5 * rng.standard_normal(n))
+    X = np.asfortranarray(X)
+    for plan in ({"np": 1, "pend": "g"}, {"np": 1, "pend": "g", "gridcap": 2}, {"np": 1, "pend": "l"}):
+        plan_ctx.debug_set_plan(plan)
+        _all_pairs_vs_oracle(plan_ctx, X)
+        # both orientations of every pair: each column is the gathered one somewhere
+        S = X.shape[1]
+        pi, pj = (a.astype(np.int32) for a in np.triu_indices(S, k=1))
+        out, cnt, rsn = plan_ctx.pairs(X, pj, pi, "global")
+        ref, rcnt, rrsn = _oracle().ici_pairs(X, pj, pi, "global")
+        assert np.array_equal(cnt, rcnt[:, :cnt.shape[1]]) and float(np.nanmax(np.abs(out - ref))) <= ATOL

@@ -226,6 +226,70 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
 #undef ICIKT_CE
 }
 
+// ---- the tie program of a column (PrepView::tprog) ----------------------------------------------------------------
+// From where a column's tie groups begin, the pair kernel walks it in steps cut at group boundaries: 64 singleton
+// rows (HOT), up to 64 rows of COMPLETE groups of at most 32 rows (MIXED), or up to 64 rows of ONE longer group (GROUP;
+// `closes`: the step holds the group's last row).  The cut depends on the streamed column alone, so it is made here,
+// once per column, by one wave (scalar code: every lane computes the same values, lane 0 stores), instead of by every
+// pair that streams the column -- S - 1 times, on the scalar unit of the pair kernel, with the flag words fetched from
+// memory inside its step loop.  gf: the column's group-start flags in PROCESSING order, W words + a zero guard word.
+// The program starts at pos0 = 64 floor(hot_until / 64), where the pair kernel's singleton loop ends, and runs to n.
+constexpr int TPROG_KS = 32;   // == k1_ks(true): MIXED steps take groups of up to this many rows
+__device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W, uint32_t* prog, uint32_t lane) {
+  // (agent-scope loads: in the pre-pass the flags were stored a moment ago by other waves of this workgroup)
+  auto ld = [gf](int w) { return __hip_atomic_load(&gf[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  int first_cont = n;   // first position that continues a group
+  for (int w = (int)lane; w < W; w += 64) {
+    unsigned long long z = ~ld(w);
+    if (w == W - 1 && (n & 63)) z &= (1ull << (n & 63)) - 1ull;
+    if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
+  }
+  first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
+  const int hot_until = (first_cont < n) ? first_cont - 1 : n;
+  int pos = (hot_until >> 6) << 6;
+  int ne = 0;
+  while (pos < n) {
+    const int wc = pos >> 6, fb = pos & 63;
+    const unsigned long long w0 = ld(min(wc, W)), w1 = ld(min(wc + 1, W));
+    unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+    const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
+    const int remaining = n - pos;
+    if (remaining < 64) F &= (1ull << remaining) - 1ull;
+    const int avail = (remaining <= 64) ? remaining : 64;
+    const bool endbit = fnbit || remaining == 64;            // row 64 of the window starts a group / is the end
+    uint32_t nact, kind, closes = 1u, dmax = 0u;
+    if (avail == 64 && F == ~0ull && endbit) {
+      nact = 64u; kind = TPROG_KIND_HOT;
+    } else {
+      const unsigned long long Fz = (avail < 64) ? (F | (~0ull << avail)) : F;   // the end of the data ends the last group
+      const unsigned long long Fr = Fz & ~1ull;
+      const int next = (Fr != 0ull) ? (int)__builtin_ctzll(Fr) : (endbit ? 64 : 65);   // end of the group at pos
+      if ((F & 1ull) == 0ull || next > TPROG_KS) {
+        kind = TPROG_KIND_GROUP;
+        const int glim = min(remaining, 64);
+        nact = (uint32_t)min(next, glim);
+        closes = (next <= glim) ? 1u : 0u;
+      } else {
+        kind = TPROG_KIND_MIXED;
+        unsigned long long r = ~Fz;                           // rows that continue a group
+        r &= r >> 1; r &= r >> 2; r &= r >> 4; r &= r >> 8; r &= r >> 16;   // bit i: rows i .. i + 31 continue: > 32 rows
+        int s0 = 64;                                          // start of the first group the step must not take
+        if (r != 0ull) s0 = 63 - (int)__builtin_clzll(Fz & ((1ull << __builtin_ctzll(r)) - 1ull));
+        if (avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));   // cut by the window
+        const int upper = min(min(remaining, 64), s0);
+        const int na = (upper >= 64) ? 64 : (63 - (int)__builtin_clzll(Fz & ((2ull << upper) - 1ull) & ~1ull));
+        nact = (uint32_t)na;
+        unsigned long long z = ~F & ((na >= 64) ? ~0ull : ((1ull << na) - 1ull));
+        while (z != 0ull) { z &= z >> 1; ++dmax; }            // largest group of the step - 1
+      }
+    }
+    if (lane == 0u) prog[ne] = nact | (kind << 7) | (closes << 9) | (dmax << 10);
+    ++ne;
+    pos += (int)nact;
+  }
+  if (lane == 0u) prog[ne] = 0u;
+}
+
 // WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
 // memory (they outgrow the static LDS), no tie-group list and no rec staging.
 template <bool WIDE>
@@ -260,6 +324,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
   uint16_t* hirow = WIDE ? nullptr : pv.hirow + (int64_t)c * pv.n_pad;
   uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
+  uint8_t* gidx_c = (!WIDE && pv.tp_stride > 0) ? pv.gidx + (int64_t)c * pv.n_ord : nullptr;
   uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* lo32 = WIDE ? pv.lo32 + (int64_t)c * pv.n_pad : nullptr;
@@ -474,6 +539,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
         order32[n - 1 - k] = row;
       } else {
       hirow[row] = (uint16_t)hi;
+      if (gidx_c) gidx_c[n - 1 - k] = (uint8_t)min(hi - k, 255);   // rows of my group in front of me in processing order
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
@@ -522,6 +588,11 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   }
   if (tid == 0) { gflag[W] = 0ull; }
   for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
+  if (!WIDE && pv.tp_stride > 0) {
+    for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) gidx_c[k] = 0;
+    __syncthreads();   // gflag is complete (written by this workgroup: the same CU's L1)
+    if (tid < 64) k0_tie_program(gflag, n, W, pv.tprog + (int64_t)c * pv.tp_stride, (uint32_t)tid);
+  }
 
   // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
   // tie group of the OTHER column that spans several steps once, when that group closes.  A group's place in the
@@ -665,6 +736,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     const uint32_t rv = (uint32_t)(n - 1 - k) | (lo << 16);
     if (staged) { rec_s[row] = rv; hi_s[row] = (uint16_t)hi; }
     else { rec[2 * row] = rv; hirow[row] = (uint16_t)hi; }
+    if (pv.tp_stride > 0) pv.gidx[(int64_t)c * pv.n_ord + k] = (uint8_t)min(k - s, 255);
     if (k == s && e > s) {
       // tgroups is ascending in lo: groups that start after me (descending) come first
       const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
@@ -677,6 +749,10 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
       rec[2 * r] = rec_s[r];
       hirow[r] = hi_s[r];
     }
+  }
+  if (pv.tp_stride > 0) {
+    for (int k = n + (int)threadIdx.x; k < pv.n_ord; k += 64 * KX_WAVES) pv.gidx[(int64_t)c * pv.n_ord + k] = 0;
+    if (wave == 0) k0_tie_program(gf, n, W, pv.tprog + (int64_t)c * pv.tp_stride, (uint32_t)lane);
   }
 }
 
@@ -1518,19 +1594,16 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
 //      ranges.
 // Per 64 rows and two pairs: the hot step + ~35 + 8 per distance instructions (round 2 before: one 32-row segment
 // per call, an unpacked all-pairs chain, ~10 instructions per distance and pair).
-__device__ __forceinline__ SegCounts half_mixed64_corr(const unsigned long long F_in, const int nact_in, const uint32_t v0,
+__device__ __forceinline__ SegCounts half_mixed64_corr(const int dmax_in, const int nact_in, const uint32_t gi, const uint32_t v0,
                                                        const uint32_t v1, const uint32_t lane) {
-  const unsigned long long F = uniform_u64(F_in);
+  // dmax = the step's largest group - 1 (from the column's tie program), gi = rows of the lane's group in front of it
+  // (PrepView::gidx): both cut once per column by the pre-pass, not from the flag window here
+  const int dmax = __builtin_amdgcn_readfirstlane(dmax_in);
   const int nact = __builtin_amdgcn_readfirstlane(nact_in);
   const bool valid = (int)lane < nact;
   SegCounts c;
   c.tie2 = 0; c.cfill = 0;
   // ---- (2) pairs inside a group ---------------------------------------------------------------------------------
-  int dmax = 0;   // longest run of rows that continue a group = largest group - 1 (wave-uniform, from the flags)
-  {
-    unsigned long long z = ~F & ((nact >= 64) ? ~0ull : ((1ull << nact) - 1ull));
-    while (z != 0ull) { z &= z >> 1; ++dmax; }
-  }
   uint32_t spur_tie = 0;   // row layout: pair 0's counts in bits 0..15, pair 1's in bits 16..31 (spur | tie << 8)
   if (dmax > 0) {
     const uint32_t X0 = 0x00007FFFu + (v0 & 0xFFFF0000u) - (v0 & 0xFFFFu);
@@ -1553,9 +1626,8 @@ __device__ __forceinline__ SegCounts half_mixed64_corr(const unsigned long long 
       W0 = (W0 >> 1) | ((s0 + Y0) & M16);
       W1 = (W1 >> 1) | ((s1 + Y1) & M16);
     }
-    // rows of my group before me: distance to the last group start at or before me
-    const unsigned long long upto = F & ((2ull << lane) - 1ull);
-    const uint32_t idx = valid ? (lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull))) : 0u;
+    // rows of my group before me
+    const uint32_t idx = valid ? gi : 0u;
     // in a vector of k distances, its i-th distance (1-based) sits at bit 15 - (k - i)
     const uint32_t i1 = min(idx, 16u), i2 = idx - i1;
     const uint32_t m = ((1u << i1) - 1u) << (16 - n1);
@@ -1853,6 +1925,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // reloads it (order[] is zero padded for the run-ahead: PrepView::n_ord).
   uint32_t r0 = gload_u16(ord, lane), r1 = gload_u16(ord, 64u + lane), r2 = gload_u16(ord, 128u + lane);
   uint32_t rk_pre[NP];   // the rec values of the step that starts at pos, gathered during the previous step
+  uint2 rv_pre = make_uint2(0u, 0u);   // (two pairs per wave: the 8-byte gather as it arrives; a pair takes its column only where
+                                       //  the values are USED, so that no wait for the gather sits right behind its issue)
   bool rk_ok = false;
 #pragma unroll
   for (int k = 0; k < NP; ++k) rk_pre[k] = 0u;
@@ -1901,20 +1975,29 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   ICIKT_ST_MARK(6, 0)
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
+  // half-wave kernels: the streamed column's tie program and group offsets (PrepView::tprog / gidx)
+  const uint32_t* tprog_col = half_mode ? pv.tprog + (int64_t)scol * pv.tp_stride : nullptr;
+  const uint8_t* gidx_col = half_mode ? pv.gidx + (int64_t)scol * pv.n_ord : nullptr;
+  uint32_t tp_pre = 0u;
+  int tp_idx = 0;
+  bool tp_ok = false;
   // the ring moves on by a 64-row step: next step's rows are in r1 already -> gather its rec values now
   // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at the top of
   //  the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
   auto advance64 = [&]() {
     r0 = r1; r1 = r2;
-    if (NP == 2) {
-      const uint2 rv = gload_rec2(rec_blk, r0);
-#pragma unroll
-      for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
-    } else {
-      rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
-    }
+    if (NP == 2) rv_pre = gload_rec2(rec_blk, r0);
+    else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
     r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
     rk_ok = true;
+  };
+  auto take_rk = [&](uint32_t (&rk)[NP]) {   // the prefetched values of the step that starts now
+    if (NP == 2) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv_pre.y : rv_pre.x;
+    } else {
+      rk[0] = rk_pre[0];
+    }
   };
   // ---- hot step: 64 rows, each its own tie group of the streamed column, nothing open ---------------------------
   // one-pair kernels on columns of at most 32 768 rows count the in-step pairs of two hot steps together
@@ -2004,8 +2087,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       do {
         uint32_t rk[NP];
         if (rk_ok) {
-#pragma unroll
-          for (int k = 0; k < NP; ++k) rk[k] = rk_pre[k];
+          take_rk(rk);
         } else if (NP == 2) {
           const uint2 rv = gload_rec2(rec_blk, r0);
 #pragma unroll
@@ -2040,8 +2122,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const bool hi_now_ok = hi_ok;
     uint32_t rk[NP];
     if (rk_ok) {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) rk[k] = rk_pre[k];
+      take_rk(rk);
     } else if (NP == 2) {  // after a short step: gather now, its latency runs behind the window logic
       const uint2 rv = gload_rec2(rec_blk, row);
 #pragma unroll
@@ -2054,6 +2135,32 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     unsigned long long F;
     int kind = 0;          // 0: hot step or the general step (decided below), 1: MIXED, 2: GROUP (fast tie steps)
     bool closes = true;    // GROUP: the step holds the group's last row
+    int dmax = 0;          // MIXED (half-wave kernels): the step's largest group - 1
+    uint32_t gi = 0;       // MIXED (half-wave kernels): rows of the lane's group in front of it
+    if constexpr (half_mode) {
+      // The step comes from the streamed column's TIE PROGRAM (k0_tie_program: cut and classified once per column by
+      // the pre-pass, the list starts where the singleton loop above ends): one dword per step, fetched one step
+      // ahead by a vector load (a scalar load would make every wait for LDS data in the step a full drain).
+      if (!tp_ok) {
+        uint32_t off = 0u;
+        asm volatile("" : "+v"(off));
+        tp_pre = gload_u32(tprog_col, off);
+        tp_ok = true;
+      }
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_pre);
+      {
+        uint32_t off = (uint32_t)(++tp_idx);
+        asm volatile("" : "+v"(off));
+        tp_pre = gload_u32(tprog_col, off);
+      }
+      nact = (int)tprog_rows(e);
+      kind = (int)tprog_kind(e);
+      closes = tprog_closes(e);
+      dmax = (int)tprog_dmax(e);
+      Fn = (kind == 2) ? closes : true;
+      F = (kind == 0) ? ~0ull : 0ull;     // (only `all_fast` below looks at it)
+      if (kind == 1) gi = (uint32_t)gidx_col[(uint32_t)pos + lane];
+    } else
     if (pos + 64 <= hot_until) {
       nact = 64; Fn = true; F = ~0ull;
     } else {
@@ -2144,13 +2251,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const bool wrap = lane + (uint32_t)nact >= 64u;
       r0 = wrap ? a1 : a0;
       r1 = wrap ? a2 : a1;
-      if (NP == 2) {
-        const uint2 rv = gload_rec2(rec_blk, r0);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rk_pre[k] = comp[k] ? rv.y : rv.x;
-      } else {
-        rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
-      }
+      if (NP == 2) rv_pre = gload_rec2(rec_blk, r0);
+      else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
       r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
       rk_ok = true;
     }
@@ -2208,7 +2310,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
           for (int k = 0; k < NP; ++k) rkm[k] = ((int)lane_t < nact) ? rk[k] : ((uint32_t)W << 6);
           hot_step(rkm);
-          c = half_mixed64_corr(F, nact, rkm[0], rkm[NP - 1], lane_t);
+          c = half_mixed64_corr(dmax, nact, gi, rkm[0], rkm[NP - 1], lane_t);
         }
         else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {

@@ -280,7 +280,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
-  c->tgroups.release(); c->tprog.release(); c->gidx.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
+  c->tgroups.release(); c->tprog.release(); c->tmask.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -390,7 +390,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     HIPCHK(c, c->rec.reserve(2));
     HIPCHK(c, c->tgroups.reserve(1));
     HIPCHK(c, c->tprog.reserve(1));
-    HIPCHK(c, c->gidx.reserve(1));
+    HIPCHK(c, c->tmask.reserve(1));
   } else {
     HIPCHK(c, c->order.reserve(S * pv.n_ord));
     HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
@@ -399,7 +399,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     // the tie program serves the half-wave kernels only (n <= 18 336); longer columns classify their steps in the pair kernel
     pv.tp_stride = (icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX) ? pv.n_pad + 2 : 0;
     HIPCHK(c, c->tprog.reserve(std::max<size_t>(1, S * (size_t)pv.tp_stride)));
-    HIPCHK(c, c->gidx.reserve(std::max<size_t>(1, pv.tp_stride ? S * (size_t)pv.n_ord : 0)));
+    HIPCHK(c, c->tmask.reserve(std::max<size_t>(1, pv.tp_stride ? S * (size_t)pv.n_ord : 0)));
   }
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
@@ -410,7 +410,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;
   pv.tprog = c->tprog.p;
-  pv.gidx = c->gidx.p;
+  pv.tmask = c->tmask.p;
   if (pv.wide) {
     pv.order32 = c->wide32.p;
     pv.q32 = pv.order32 + S * (size_t)pv.n_pad;

@@ -27,12 +27,14 @@ struct ColStats {
 };
 constexpr int COL_ODD_TIE = 1;
 
-// tie-program entry: rows of the step | kind << 7 | closes << 9 | dmax << 10
+// tie-program entry: rows of the step | kind << 7 | closes << 9 | n0 << 10 (MIXED: rows of its first sub-step) |
+// dmax << 16 (MIXED: rows of its largest group - 1: how far apart two rows of one group can be)
 constexpr uint32_t TPROG_KIND_HOT = 0u, TPROG_KIND_MIXED = 1u, TPROG_KIND_GROUP = 2u;
 __host__ __device__ inline uint32_t tprog_rows(uint32_t e) { return e & 127u; }
 __host__ __device__ inline uint32_t tprog_kind(uint32_t e) { return (e >> 7) & 3u; }
 __host__ __device__ inline bool tprog_closes(uint32_t e) { return ((e >> 9) & 1u) != 0u; }
-__host__ __device__ inline uint32_t tprog_dmax(uint32_t e) { return (e >> 10) & 63u; }
+__host__ __device__ inline uint32_t tprog_n0(uint32_t e) { return (e >> 10) & 63u; }
+__host__ __device__ inline uint32_t tprog_dmax(uint32_t e) { return (e >> 16) & 63u; }
 
 // setup_missing_matrix (R/utils.R:1-23) on the device: which cells of the data matrix are excluded (become NA,
 // R/kendalltau.R:119-121) before the pre-pass.  The pre-pass applies it while it reads the matrix, so the masked copy
@@ -93,11 +95,12 @@ struct PrepView {
   int tg_stride;                 // n_pad / 2 + 1
   // The tie program of a column as the STREAMED side of a half-wave kernel (n <= 18 336): the steps the pair kernel
   // takes from where the column's tie groups begin, cut and classified ONCE per column by the pre-pass instead of by
-  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  gidx: per processing position the rows of
-  // its tie group in front of it (capped at 255).  Both are functions of gflag: rebuilt, not exchanged, between ranks.
+  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  tmask: per processing position of a row of
+  // a MIXED step, which flags of the pair kernel's in-step compare vectors belong to pairs INSIDE the row's tie group
+  // (x: vector 1, y: vector 2).  Both are functions of gflag: rebuilt, not exchanged, between ranks.
   uint32_t* tprog;               // [S][tp_stride]; tp_stride = n_pad + 2 (a step takes at least one row; 0 ends the list)
   int tp_stride;
-  uint8_t* gidx;                 // [S][n_ord]
+  uint2* tmask;                  // [S][n_ord]
   // sort scratch (per column of the current chunk)
   unsigned long long* sort_keys;  // [chunk][npow2]
   uint32_t* sort_idx;             // [chunk][npow2]

@@ -47,7 +47,7 @@ struct icikt_ctx {
   DevBuf<uint32_t> wide32;                 // wide columns: order32 | q32 | lo32 | hi32, S x n_pad each
   DevBuf<unsigned long long> k0_bits;      // wide columns: K0's phase-3 bitsets, per column of a sort chunk
   DevBuf<uint32_t> rec, tgroups, tprog;
-  DevBuf<uint8_t> gidx;
+  DevBuf<uint2> tmask;
   DevBuf<unsigned long long> meta, sort_keys;
   DevBuf<uint32_t> sort_idx;
   int sort_chunk = 0;

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "icikt_device.h"
 
@@ -226,21 +227,36 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
 #undef ICIKT_CE
 }
 
-// ---- the tie program of a column (PrepView::tprog) ----------------------------------------------------------------
-// From where a column's tie groups begin, the pair kernel walks it in steps cut at group boundaries: 64 singleton
-// rows (HOT), up to 64 rows of COMPLETE groups of at most 32 rows (MIXED), or up to 64 rows of ONE longer group (GROUP;
-// `closes`: the step holds the group's last row).  The cut depends on the streamed column alone, so it is made here,
-// once per column, by one wave (scalar code: every lane computes the same values, lane 0 stores), instead of by every
-// pair that streams the column -- S - 1 times, on the scalar unit of the pair kernel, with the flag words fetched from
-// memory inside its step loop.  gf: the column's group-start flags in PROCESSING order, W words + a zero guard word.
-// The program starts at pos0 = 64 floor(hot_until / 64), where the pair kernel's singleton loop ends, and runs to n.
+// ---- the tie program of a column (PrepView::tprog, tmask) ---------------------------------------------------------
+// From where a column's tie groups begin, the half-wave pair kernels walk it in steps cut at group boundaries:
+//   HOT    64 singleton rows;
+//   MIXED  two SUB-STEPS of up to 32 rows each, every one made of COMPLETE groups of at most 32 rows: no group
+//          straddles the two, so rows of one group only ever meet inside a sub-step, in registers;
+//   GROUP  up to 64 rows of ONE longer group (`closes`: the step holds the group's last row).
+// The cut depends on the streamed column alone, so it is made here, once per column, by one wave (the step sequence is
+// scalar code: every lane computes the same values, lane 0 stores) instead of by every pair that streams the column --
+// S - 1 times, on the scalar unit of the pair kernel, with the flag words fetched from memory inside its step loop.
+// For the rows of a MIXED step the wave also writes, one lane per row, WHICH FLAGS of the pair kernel's in-step compare
+// vectors (half_step_flags: bit layout below) belong to pairs inside the row's own tie group: the pair kernel masks them
+// out of the discordance count and counts the joint ties among them, whatever the sizes of the groups.
+// gf: the column's group-start flags in PROCESSING order, W words + a zero guard word (in LDS).  The program starts at
+// pos0 = 64 floor(hot_until / 64), where the pair kernel's singleton loop ends, and runs to n.
+//
+// Flag layout of half_step_flags (lane = (pair h, l = 0..31), DPP row = l >> 4, p = l & 15; sub-step s of the lane's two
+// rows in byte s ("b" slots) and byte 2 + s ("a" slots) of both vectors):
+//   vector 1   a bit i = in-row distance 2i + 1, b bit i = in-row distance 2i + 2 (i <= 6); b bit 7 = rows crossed at
+//              rotation 0.  In-row distance d: the lane is the LATER row, its partner sits d lanes in front.
+//   vector 2   a bit 4 + i = rotation 2i + 1, b bit 4 + i = rotation 2i + 2 (i <= 2); rotation 7 = bit 15 (s = 0) / 31.
+//   rotation r of an UPPER-row lane: the lane is the later row, its partner the lower row's lane (p - r) mod 16, i.e.
+//   D = (p >= r ? 16 + r : r) lanes in front; of a LOWER-row lane: the lane is the EARLIER row, its partner the upper
+//   row's lane (p - r - 1) mod 16, D = (p - r - 1 >= 0 ? 15 - r : 31 - r) lanes behind.
+// Two rows D lanes apart belong to one group iff D <= idx of the later one (rows of its group in front of it) iff
+// D <= fwd of the earlier one (rows of its group behind it).
 constexpr int TPROG_KS = 32;   // == k1_ks(true): MIXED steps take groups of up to this many rows
-__device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W, uint32_t* prog, uint32_t lane) {
-  // (agent-scope loads: in the pre-pass the flags were stored a moment ago by other waves of this workgroup)
-  auto ld = [gf](int w) { return __hip_atomic_load(&gf[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+__device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W, uint32_t* prog, uint2* tmask, uint32_t lane) {
   int first_cont = n;   // first position that continues a group
   for (int w = (int)lane; w < W; w += 64) {
-    unsigned long long z = ~ld(w);
+    unsigned long long z = ~gf[w];
     if (w == W - 1 && (n & 63)) z &= (1ull << (n & 63)) - 1ull;
     if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
   }
@@ -250,19 +266,20 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W
   int ne = 0;
   while (pos < n) {
     const int wc = pos >> 6, fb = pos & 63;
-    const unsigned long long w0 = ld(min(wc, W)), w1 = ld(min(wc + 1, W));
+    const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
     unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
     const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
     const int remaining = n - pos;
     if (remaining < 64) F &= (1ull << remaining) - 1ull;
     const int avail = (remaining <= 64) ? remaining : 64;
-    const bool endbit = fnbit || remaining == 64;            // row 64 of the window starts a group / is the end
-    uint32_t nact, kind, closes = 1u, dmax = 0u;
+    const bool endbit = fnbit || remaining == 64;            // offset 64 starts a group / is the end of the data
+    uint32_t nact, kind, closes = 1u, n0 = 0u, dmax = 0u;
     if (avail == 64 && F == ~0ull && endbit) {
       nact = 64u; kind = TPROG_KIND_HOT;
     } else {
-      const unsigned long long Fz = (avail < 64) ? (F | (~0ull << avail)) : F;   // the end of the data ends the last group
-      const unsigned long long Fr = Fz & ~1ull;
+      // group boundaries of the window: the starts, and the end of the data (one marker: no boundary beyond it)
+      const unsigned long long Fe = (avail < 64) ? (F | (1ull << avail)) : F;
+      const unsigned long long Fr = Fe & ~1ull;
       const int next = (Fr != 0ull) ? (int)__builtin_ctzll(Fr) : (endbit ? 64 : 65);   // end of the group at pos
       if ((F & 1ull) == 0ull || next > TPROG_KS) {
         kind = TPROG_KIND_GROUP;
@@ -271,19 +288,52 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W
         closes = (next <= glim) ? 1u : 0u;
       } else {
         kind = TPROG_KIND_MIXED;
-        unsigned long long r = ~Fz;                           // rows that continue a group
-        r &= r >> 1; r &= r >> 2; r &= r >> 4; r &= r >> 8; r &= r >> 16;   // bit i: rows i .. i + 31 continue: > 32 rows
-        int s0 = 64;                                          // start of the first group the step must not take
-        if (r != 0ull) s0 = 63 - (int)__builtin_clzll(Fz & ((1ull << __builtin_ctzll(r)) - 1ull));
-        if (avail == 64 && !endbit) s0 = min(s0, 63 - (int)__builtin_clzll(Fz));   // cut by the window
-        const int upper = min(min(remaining, 64), s0);
-        const int na = (upper >= 64) ? 64 : (63 - (int)__builtin_clzll(Fz & ((2ull << upper) - 1ull) & ~1ull));
-        nact = (uint32_t)na;
-        unsigned long long z = ~F & ((na >= 64) ? ~0ull : ((1ull << na) - 1ull));
-        while (z != 0ull) { z &= z >> 1; ++dmax; }            // largest group of the step - 1
+        // sub-step 0: up to the last boundary within 32 rows (there is one: the first group has at most 32 rows)
+        const int b0 = 63 - (int)__builtin_clzll(Fe & 0x1FFFFFFFEull);
+        // sub-step 1: from b0 up to the last boundary within the next 32 rows; none: the next group is longer (or
+        // the data end at b0) and the step ends at b0.  The boundary at offset 64 (b0 == 32 only) is `endbit`.
+        unsigned long long rest = (Fe >> b0) & 0x1FFFFFFFEull;
+        if (b0 == 32 && endbit) rest |= 1ull << 32;
+        const int b1 = (rest != 0ull) ? (63 - (int)__builtin_clzll(rest)) : 0;
+        n0 = (uint32_t)b0;
+        nact = (uint32_t)(b0 + b1);
+        {
+          unsigned long long z = ~F & ((nact >= 64u) ? ~0ull : ((1ull << nact) - 1ull));   // rows that continue a group
+          while (z != 0ull) { z &= z >> 1; ++dmax; }
+        }
+        // ---- the step's rows, one lane each: sub-step s = lane >> 5, l = lane & 31 --------------------------------
+        const uint32_t sb = lane >> 5, l = lane & 31u;
+        const bool valid = l < (sb ? (uint32_t)b1 : (uint32_t)b0);
+        if (valid) {
+          const uint32_t o = sb ? (uint32_t)b0 + l : l;                                   // offset of the row in the window (< 64)
+          const unsigned long long upto = Fe & ((o < 63u) ? ((2ull << o) - 1ull) : ~0ull);
+          const uint32_t idx = o - (63u - (uint32_t)__builtin_clzll(upto));               // bit 0 is set: the step starts a group
+          const unsigned long long above = (o < 63u) ? (Fe >> (o + 1u)) : 0ull;
+          const uint32_t nxt = (above != 0ull) ? (o + 1u + (uint32_t)__builtin_ctzll(above)) : 64u;   // (offset 64: endbit)
+          const uint32_t fwd = nxt - 1u - o;
+          const uint32_t p = l & 15u;
+          const bool upper = (l & 16u) != 0u;
+          const uint32_t c = min(min(idx, p), 15u);                                       // in-row partners inside my group
+          uint32_t a1 = (1u << ((c + 1u) >> 1)) - 1u, b1m = (1u << (c >> 1)) - 1u;         // vector 1: a / b slots
+          uint32_t a2 = 0u, b2 = 0u, r7 = 0u;
+#pragma unroll
+          for (uint32_t r = 0; r < 8; ++r) {
+            const uint32_t D = upper ? ((p >= r) ? 16u + r : r) : ((p >= r + 1u) ? 15u - r : 31u - r);
+            const bool same = upper ? (D <= idx) : (D <= fwd);
+            if (!same) continue;
+            if (r == 0u) b1m |= 0x80u;
+            else if (r == 7u) r7 = 1u;
+            else if (r & 1u) a2 |= 1u << (4u + ((r - 1u) >> 1));
+            else b2 |= 1u << (4u + ((r - 2u) >> 1));
+          }
+          uint2 m;
+          m.x = (b1m << (8u * sb)) | (a1 << (8u * (2u + sb)));
+          m.y = (b2 << (8u * sb)) | (a2 << (8u * (2u + sb))) | (r7 ? (sb ? 0x80000000u : 0x00008000u) : 0u);
+          tmask[(uint32_t)pos + o] = m;
+        }
       }
     }
-    if (lane == 0u) prog[ne] = nact | (kind << 7) | (closes << 9) | (dmax << 10);
+    if (lane == 0u) prog[ne] = nact | (kind << 7) | (closes << 9) | (n0 << 10) | (dmax << 16);
     ++ne;
     pos += (int)nact;
   }
@@ -324,7 +374,6 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
   uint16_t* hirow = WIDE ? nullptr : pv.hirow + (int64_t)c * pv.n_pad;
   uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
-  uint8_t* gidx_c = (!WIDE && pv.tp_stride > 0) ? pv.gidx + (int64_t)c * pv.n_ord : nullptr;
   uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* lo32 = WIDE ? pv.lo32 + (int64_t)c * pv.n_pad : nullptr;
@@ -539,7 +588,6 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
         order32[n - 1 - k] = row;
       } else {
       hirow[row] = (uint16_t)hi;
-      if (gidx_c) gidx_c[n - 1 - k] = (uint8_t)min(hi - k, 255);   // rows of my group in front of me in processing order
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
@@ -589,9 +637,18 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   if (tid == 0) { gflag[W] = 0ull; }
   for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
   if (!WIDE && pv.tp_stride > 0) {
-    for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) gidx_c[k] = 0;
-    __syncthreads();   // gflag is complete (written by this workgroup: the same CU's L1)
-    if (tid < 64) k0_tie_program(gflag, n, W, pv.tprog + (int64_t)c * pv.tp_stride, (uint32_t)tid);
+    // the tie program of the column: its flag words, still in registers of the lanes that wrote them, go to LDS (the
+    // fill-group bitset there has just been copied out) and one wave cuts the steps from that copy
+    __syncthreads();
+    for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+      const int kp = base + tid;
+      const bool flag = (kp < n) && is_start(n - kp);          // the same bit as above: position n-1-kp ends a group
+      const unsigned long long b = __ballot(flag);
+      if (lane == 0 && (kp >> 6) < W) sh_bits_lds[kp >> 6] = b;
+    }
+    if (tid == 0) sh_bits_lds[W] = 0ull;
+    __syncthreads();
+    if (tid < 64) k0_tie_program(sh_bits_lds, n, W, pv.tprog + (int64_t)c * pv.tp_stride, pv.tmask + (int64_t)c * pv.n_ord, (uint32_t)tid);
   }
 
   // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
@@ -663,7 +720,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   extern __shared__ __attribute__((aligned(16))) unsigned char kx_stage[];
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(kx_stage);
   uint16_t* hi_s = reinterpret_cast<uint16_t*>(kx_stage + (size_t)pv.n_pad * 4);
-  __shared__ int prevs[1032];   // highest group start in the words before w (-1: none)
+  __shared__ __attribute__((aligned(8))) int prevs[1032];   // highest group start in the words before w (-1: none)
   __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
   const int wave = (int)(threadIdx.x >> 6);
@@ -736,7 +793,6 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     const uint32_t rv = (uint32_t)(n - 1 - k) | (lo << 16);
     if (staged) { rec_s[row] = rv; hi_s[row] = (uint16_t)hi; }
     else { rec[2 * row] = rv; hirow[row] = (uint16_t)hi; }
-    if (pv.tp_stride > 0) pv.gidx[(int64_t)c * pv.n_ord + k] = (uint8_t)min(k - s, 255);
     if (k == s && e > s) {
       // tgroups is ascending in lo: groups that start after me (descending) come first
       const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
@@ -750,9 +806,12 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
       hirow[r] = hi_s[r];
     }
   }
-  if (pv.tp_stride > 0) {
-    for (int k = n + (int)threadIdx.x; k < pv.n_ord; k += 64 * KX_WAVES) pv.gidx[(int64_t)c * pv.n_ord + k] = 0;
-    if (wave == 0) k0_tie_program(gf, n, W, pv.tprog + (int64_t)c * pv.tp_stride, (uint32_t)lane);
+  if (pv.tp_stride > 0) {   // (half-wave kernels only: W <= 287 words)
+    __syncthreads();
+    unsigned long long* gfl = reinterpret_cast<unsigned long long*>(prevs);   // the scan arrays are free now: 1032 ints = 516 words
+    for (int w = (int)threadIdx.x; w <= W; w += 64 * KX_WAVES) gfl[w] = gf[w];
+    __syncthreads();
+    if (wave == 0) k0_tie_program(gfl, n, W, pv.tprog + (int64_t)c * pv.tp_stride, pv.tmask + (int64_t)c * pv.n_ord, (uint32_t)lane);
   }
 }
 
@@ -1026,6 +1085,79 @@ __device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, 
                : "=&v"(v2), "=&v"(t1), "=&v"(t2)
                : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
   return bcnt_acc(v2, bcnt_acc(v1, 0u));
+}
+
+// The same chain, returning the flag vectors themselves (layout: k0_tie_program) instead of their popcount, for steps
+// whose rows form tie groups of the streamed column (MIXED): `src` is what a row offers to the rows behind it inside
+// its DPP row, `own` what a row adds; between the rows `offer` is both.  (src, own, offer) = (A, B, upper ? B : A)
+// gives [q_earlier < lo_later] per pair, (B, A, upper ? A : B) the other direction, [q_later < lo_earlier].
+__device__ __forceinline__ void half_step_flags(uint32_t src, uint32_t own, uint32_t offer, uint32_t partner_addr,
+                                                uint32_t& v1, uint32_t& v2) {
+  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)offer);
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
+  uint32_t t1, t2;
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PSHR2(3, 4) ICIKT_PSHR2(5, 6) ICIKT_PSHR2(7, 8) ICIKT_PSHR2(9, 10) ICIKT_PSHR2(11, 12)
+               ICIKT_PSHR2(13, 14)
+               "v_add_u32_dpp %1, %3, %4 row_shr:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_e32 %2, %7, %8\n\t" ICIKT_PACC
+               : "=&v"(v1), "=&v"(t1), "=&v"(t2)
+               : "v"(src), "v"(own), "s"(M8), "s"(SEL), "v"(xa), "v"(offer));
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PROR2(3, 4) ICIKT_PROR2(5, 6)
+               "v_add_u32_dpp %1, %3, %4 row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+               "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %7, %0\n\t"
+               : "=&v"(v2), "=&v"(t1), "=&v"(t2)
+               : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
+}
+
+// The flags of the distances a small tie group can span, in the same bit positions: two rows of one group lie at most
+// DMAX lanes apart, so of the other direction's chain (which only serves pairs inside a group) the in-row distances
+// 1 .. DMAX and the rotations 1 .. DMAX (an upper-row lane whose partner sits in the last lanes of the lower row)
+// are all there is.  DMAX = 2: 11 instructions, 4: 23, against 58 for the whole chain.
+template <int DMAX>
+__device__ __forceinline__ void half_step_flags_near(uint32_t src, uint32_t own, uint32_t offer, uint32_t partner_addr,
+                                                     uint32_t& v1, uint32_t& v2) {
+  static_assert(DMAX == 2 || DMAX == 4, "half_step_flags_near variants");
+  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)offer);
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u;
+  uint32_t t1, t2, u1, u2;
+  // vector 1: distances (1, 2) -> bit 0 of the a / b bytes, (3, 4) -> bit 1
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 7, %0\n\t"
+               : "=&v"(v1), "=&v"(t1), "=&v"(t2)
+               : "v"(src), "v"(own), "s"(M8), "s"(SEL));
+  // vector 2: rotations (1, 2) -> bit 4, (3, 4) -> bit 5
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 3, %0\n\t"
+               : "=&v"(v2), "=&v"(t1), "=&v"(t2)
+               : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
+  if (DMAX == 4) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %1, %3, %4 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_u32_dpp %2, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 6, %0\n\t"
+                 : "=&v"(u1), "=&v"(t1), "=&v"(t2)
+                 : "v"(src), "v"(own), "s"(M8), "s"(SEL));
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %1, %3, %4 row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %2, %3, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 2, %0\n\t"
+                 : "=&v"(u2), "=&v"(t1), "=&v"(t2)
+                 : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
+    v1 |= u1;
+    v2 |= u2;
+  }
 }
 
 // ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
@@ -1578,80 +1710,15 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
   return c;
 }
 
-// MIXED step of a half-wave kernel: up to 64 rows of COMPLETE groups of at most k1_ks(true) rows, BOTH pairs.
-// Splitting "rows before my group" into "rows before me" minus "rows of my group before me" separates the work:
-//  (1) rows before me with q < lo_me: what the hot step counts -- prefix query + the packed in-step chain on two
-//      32-row sub-steps per pair -- and it does not look at the groups at all (the sub-steps need not end where
-//      groups end).  The caller therefore runs the HOT STEP ITSELF on the step's rows; lanes past them carry
-//      q = 64 W (a position in the guard word of `seen`, above every real one) and lo = 0: they never count, are
-//      never counted, their query is 0, and what they insert is a bit no query ever reaches.
-//  (2) pairs inside a group (this function), in the row layout (lane = row of the streamed column, both pairs'
-//      values in the lane): d = 1 .. largest group - 1 whole-wave shifts of X = (0x3FFF - q) | (0x4000 + lo) << 16
-//      added to the lane's own X with its halves swapped give, in bits 15 and 31, [q_prev < lo_me] and
-//      [q_me < lo_prev]; one bit vector per pair collects them (one bit per distance).  A lane's group reaches idx
-//      rows back, so the vector masked to distances <= idx holds the lane's spurious counts (first flag) and, where
-//      neither flag is set, its joint ties: lo_prev == lo_me, because tie groups of the gathered column are disjoint
-//      ranges.
-// Per 64 rows and two pairs: the hot step + ~35 + 8 per distance instructions (round 2 before: one 32-row segment
-// per call, an unpacked all-pairs chain, ~10 instructions per distance and pair).
-__device__ __forceinline__ SegCounts half_mixed64_corr(const int dmax_in, const int nact_in, const uint32_t gi, const uint32_t v0,
-                                                       const uint32_t v1, const uint32_t lane) {
-  // dmax = the step's largest group - 1 (from the column's tie program), gi = rows of the lane's group in front of it
-  // (PrepView::gidx): both cut once per column by the pre-pass, not from the flag window here
-  const int dmax = __builtin_amdgcn_readfirstlane(dmax_in);
-  const int nact = __builtin_amdgcn_readfirstlane(nact_in);
-  const bool valid = (int)lane < nact;
-  SegCounts c;
-  c.tie2 = 0; c.cfill = 0;
-  // ---- (2) pairs inside a group ---------------------------------------------------------------------------------
-  uint32_t spur_tie = 0;   // row layout: pair 0's counts in bits 0..15, pair 1's in bits 16..31 (spur | tie << 8)
-  if (dmax > 0) {
-    const uint32_t X0 = 0x00007FFFu + (v0 & 0xFFFF0000u) - (v0 & 0xFFFFu);
-    const uint32_t X1 = 0x00007FFFu + (v1 & 0xFFFF0000u) - (v1 & 0xFFFFu);
-    const uint32_t Y0 = __builtin_amdgcn_alignbit(X0, X0, 16), Y1 = __builtin_amdgcn_alignbit(X1, X1, 16);
-    const uint32_t M16 = 0x80008000u;
-    // one vector holds 16 distances (a 17th shift would move the upper flags into the lower half): distances
-    // 1 .. 16 in V0 / V1, 17 .. 31 in W0 / W1
-    uint32_t s0 = X0, s1 = X1, V0 = 0, V1 = 0, W0 = 0, W1 = 0;
-    const int n1 = min(dmax, 16), n2 = dmax - n1;
-    for (int d = 0; d < n1; ++d) {
-      s0 = dpp_wave_shr1(0u, s0);     // lane l now holds row l - (d + 1); no source: 0, no flag
-      s1 = dpp_wave_shr1(0u, s1);
-      V0 = (V0 >> 1) | ((s0 + Y0) & M16);
-      V1 = (V1 >> 1) | ((s1 + Y1) & M16);
-    }
-    for (int d = 0; d < n2; ++d) {
-      s0 = dpp_wave_shr1(0u, s0);
-      s1 = dpp_wave_shr1(0u, s1);
-      W0 = (W0 >> 1) | ((s0 + Y0) & M16);
-      W1 = (W1 >> 1) | ((s1 + Y1) & M16);
-    }
-    // rows of my group before me
-    const uint32_t idx = valid ? gi : 0u;
-    // in a vector of k distances, its i-th distance (1-based) sits at bit 15 - (k - i)
-    const uint32_t i1 = min(idx, 16u), i2 = idx - i1;
-    const uint32_t m = ((1u << i1) - 1u) << (16 - n1);
-    uint32_t sp0 = (uint32_t)__builtin_popcount(V0 & m), sp1 = (uint32_t)__builtin_popcount(V1 & m);
-    uint32_t t0 = (uint32_t)__builtin_popcount(~(V0 | (V0 >> 16)) & m);
-    uint32_t t1 = (uint32_t)__builtin_popcount(~(V1 | (V1 >> 16)) & m);
-    if (n2 > 0) {
-      const uint32_t m2 = ((1u << i2) - 1u) << (16 - n2);
-      sp0 += (uint32_t)__builtin_popcount(W0 & m2); sp1 += (uint32_t)__builtin_popcount(W1 & m2);
-      t0 += (uint32_t)__builtin_popcount(~(W0 | (W0 >> 16)) & m2);
-      t1 += (uint32_t)__builtin_popcount(~(W1 | (W1 >> 16)) & m2);
-    }
-    spur_tie = sp0 | (t0 << 8) | (sp1 << 16) | (t1 << 24);
-  }
-  // row layout -> the lane's pair: lanes < 32 take pair 0's counts of rows l and l + 32, lanes >= 32 pair 1's
-  const auto st2 = __builtin_amdgcn_permlane32_swap(spur_tie, spur_tie, false, false);
-  const uint32_t a = (lane < 32u) ? (st2[0] & 0xFFFFu) : (st2[0] >> 16);
-  const uint32_t b = (lane < 32u) ? (st2[1] & 0xFFFFu) : (st2[1] >> 16);
-  c.dis = 0;
-  c.neg = (a & 0xFFu) + (b & 0xFFu);
-  c.tie = (a >> 8) + (b >> 8);
-  return c;
-}
-
+// MIXED step of a half-wave kernel: two sub-steps of up to 32 rows of COMPLETE groups each (no group straddles them:
+// k0_tie_program), BOTH pairs.  It is the hot step on those rows -- lanes past a sub-step's rows carry q = 64 W (a
+// position in the guard word of `seen`, above every real one) and lo = 0: they never count, are never counted, query 0
+// and insert a bit no query reaches -- with two changes to the in-step pairs: the flags of pairs INSIDE a tie group
+// (PrepView::tmask, cut once per column by the pre-pass) do not count as discordant, and a second chain in the other
+// direction tells which of those pairs are joint ties: rows of one group of the streamed column with neither
+// q_a < lo_j nor q_j < lo_a share a tie group of the gathered column (its groups are disjoint position ranges).
+// Cost: the hot step + one more chain + ~15 instructions, whatever the sizes of the groups (round 2: a shift loop of
+// 14 instructions per row of the step's largest group).
 // GROUP step.  `single`: the group starts and ends in this step (wave-uniform).  `rowmode` (per lane = per pair):
 // joint ties are counted row by row from cell popcounts; otherwise (the gathered column has few tie groups, which
 // may be thousands of rows long) the rows only collect in pend and the caller counts them from the column's tie
@@ -1977,10 +2044,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   int fw_word = -1;
   // half-wave kernels: the streamed column's tie program and group offsets (PrepView::tprog / gidx)
   const uint32_t* tprog_col = half_mode ? pv.tprog + (int64_t)scol * pv.tp_stride : nullptr;
-  const uint8_t* gidx_col = half_mode ? pv.gidx + (int64_t)scol * pv.n_ord : nullptr;
-  uint32_t tp_pre = 0u;
+  const uint2* tmask_col = half_mode ? pv.tmask + (int64_t)scol * pv.n_ord : nullptr;
+  uint32_t tp_a = 0u, tp_b = 0u;   // entries of this step and the next, fetched two steps ahead (vector loads: see below)
   int tp_idx = 0;
   bool tp_ok = false;
+  int pre_n0 = 32;                 // row layout of the prefetched gather: sub-step 1 starts n0 rows in (32: lane = row)
   // the ring moves on by a 64-row step: next step's rows are in r1 already -> gather its rec values now
   // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at the top of
   //  the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
@@ -1990,6 +2058,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
     r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
     rk_ok = true;
+  };
+  // MIXED steps of a half-wave kernel lay their rows out in two sub-steps: lanes 0..31 take the step's rows 0..31,
+  // lanes 32..63 the rows n0 .. n0 + 31 (n0 = rows of the first sub-step; n0 == 32: lane = row)
+  auto layout_rows = [&](uint32_t rows, int n0) -> uint32_t {
+    if (n0 == 32) return rows;
+    uint32_t lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const uint32_t o = (lane_t < 32u) ? lane_t : (uint32_t)n0 + lane_t - 32u;   // < 64: inside the ring's first register
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o << 2), (int)rows);
   };
   auto take_rk = [&](uint32_t (&rk)[NP]) {   // the prefetched values of the step that starts now
     if (NP == 2) {
@@ -2003,7 +2080,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // one-pair kernels on columns of at most 32 768 rows count the in-step pairs of two hot steps together
   // (wave_allpairs_packed2): inside the hot loop the step itself skips them
   bool defer_allpairs = false;
-  auto hot_step = [&](const uint32_t (&rk)[NP]) {
+  uint32_t mix_sg1 = 0u, mix_sg2 = 0u;   // MIXED: the lane's same-group flag masks (both sub-steps); 0 in a plain hot step
+  int mix_dmax = 0;                      // MIXED: rows of the step's largest group - 1 (wave-uniform)
+  auto hot_step = [&](const uint32_t (&rk)[NP], auto mixed_tag) {
+    constexpr bool MIXED = decltype(mixed_tag)::value;
     if constexpr (half_mode) {
       // lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One 8-byte gather per row;
       // permlane32_swap turns the two 64-row registers (pair 0, pair 1) into the two sub-steps' operands
@@ -2037,7 +2117,24 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         unsigned long long wv[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
-        if (sub == 0) inpairs = half_step_count(sw[0], sw[1], lane, partner_addr);
+        if (sub == 0) {
+          if constexpr (!MIXED) {
+            inpairs = half_step_count(sw[0], sw[1], lane, partner_addr);
+          } else {
+            const uint32_t Q = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
+            const uint32_t LO = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);   // lo likewise
+            // (guard lanes: q = 64 W <= 0x47C0 and lo = 0 keep every field inside 15 bits)
+            const uint32_t A = 0x7FFF7FFFu - Q, B = LO;
+            uint32_t f1, f2, g1, g2;
+            half_step_flags(A, B, (lane & 16u) ? B : A, partner_addr, f1, f2);      // [q_earlier < lo_later]
+            // [q_later < lo_earlier]: only pairs inside a group need it, and those lie at most mix_dmax lanes apart
+            if (mix_dmax <= 2) half_step_flags_near<2>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            else if (mix_dmax <= 4) half_step_flags_near<4>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            else half_step_flags(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            inpairs = bcnt_acc(f2 & ~mix_sg2, bcnt_acc(f1 & ~mix_sg1, 0u));         // pairs of different groups only
+            seg_tie = bcnt_acc(mix_sg2 & ~(f2 | g2), bcnt_acc(mix_sg1 & ~(f1 | g1), seg_tie));   // joint ties inside the groups
+          }
+        }
         // (the loaded words are consumed only behind the all-pairs block: an empty asm pins that order, or the
         //  scheduler hoists the popcounts -- and the wait for the loads -- in front of it)
         uint32_t pre_lo_k = pre_lo;
@@ -2097,7 +2194,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
         pos += 64;
         advance64();
-        hot_step(rk);
+        hot_step(rk, std::false_type{});
         if (pack2) {
           if (have_prev) {
             uint32_t ka = rk_prev, kb = rk[0];
@@ -2123,6 +2220,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     uint32_t rk[NP];
     if (rk_ok) {
       take_rk(rk);
+    } else if (half_mode) {   // gathered below, once the step's row layout is known
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk[k] = 0u;
     } else if (NP == 2) {  // after a short step: gather now, its latency runs behind the window logic
       const uint2 rv = gload_rec2(rec_blk, row);
 #pragma unroll
@@ -2135,31 +2235,49 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     unsigned long long F;
     int kind = 0;          // 0: hot step or the general step (decided below), 1: MIXED, 2: GROUP (fast tie steps)
     bool closes = true;    // GROUP: the step holds the group's last row
-    int dmax = 0;          // MIXED (half-wave kernels): the step's largest group - 1
-    uint32_t gi = 0;       // MIXED (half-wave kernels): rows of the lane's group in front of it
+    int n0 = 32;           // MIXED (half-wave kernels): rows of the first sub-step (the second one starts at lane 32)
+    uint32_t e_next = 0u, e_cur = 0u;  // half-wave kernels: this step's and the next step's program entries
+    uint2 tmx = make_uint2(0u, 0u);   // MIXED (half-wave kernels): the row's same-group flag masks
     if constexpr (half_mode) {
       // The step comes from the streamed column's TIE PROGRAM (k0_tie_program: cut and classified once per column by
-      // the pre-pass, the list starts where the singleton loop above ends): one dword per step, fetched one step
-      // ahead by a vector load (a scalar load would make every wait for LDS data in the step a full drain).
+      // the pre-pass, the list starts where the singleton loop above ends): one dword per step, fetched TWO steps
+      // ahead by vector loads (a scalar load would make every wait for LDS data in the step a full drain) -- the next
+      // step's entry is needed now, to lay out and gather its rows during this step.
       if (!tp_ok) {
         uint32_t off = 0u;
         asm volatile("" : "+v"(off));
-        tp_pre = gload_u32(tprog_col, off);
+        tp_a = gload_u32(tprog_col, off);
+        tp_b = gload_u32(tprog_col, off + 1u);
+        tp_idx = 1;
         tp_ok = true;
       }
-      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_pre);
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_a);
+      e_cur = e;
+      e_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_b);
+      tp_a = tp_b;
       {
         uint32_t off = (uint32_t)(++tp_idx);
         asm volatile("" : "+v"(off));
-        tp_pre = gload_u32(tprog_col, off);
+        tp_b = gload_u32(tprog_col, off);
       }
       nact = (int)tprog_rows(e);
       kind = (int)tprog_kind(e);
       closes = tprog_closes(e);
-      dmax = (int)tprog_dmax(e);
+      n0 = (kind == 1) ? (int)tprog_n0(e) : 32;
       Fn = (kind == 2) ? closes : true;
       F = (kind == 0) ? ~0ull : 0ull;     // (only `all_fast` below looks at it)
-      if (kind == 1) gi = (uint32_t)gidx_col[(uint32_t)pos + lane];
+      if (pre_n0 != n0 || !rk_ok) {       // the first program step only: the singleton loop gathered for lane = row
+        const uint2 rv = gload_rec2(rec_blk, layout_rows(row, n0));
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rk[k] = comp[(NP == 2) ? k : 0] ? rv.y : rv.x;
+      }
+      if (kind == 1) {   // which flags of the in-step compare belong to pairs inside a tie group (consumed behind the chains)
+        uint32_t lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const uint32_t o = (lane_t < 32u) ? lane_t : (uint32_t)n0 + lane_t - 32u;
+        const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
+        tmx = vrow ? tmask_col[(uint32_t)pos + o] : make_uint2(0u, 0u);
+      }
     } else
     if (pos + 64 <= hot_until) {
       nact = 64; Fn = true; F = ~0ull;
@@ -2238,8 +2356,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
     pos = pos_next;
-    if (nact == 64) {  // the ring stays aligned
+    const int n0_next = (half_mode && tprog_kind(e_next) == TPROG_KIND_MIXED) ? (int)tprog_n0(e_next) : 32;
+    if (nact == 64 && n0_next == 32) {  // the ring stays aligned
       advance64();
+      pre_n0 = 32;
+    } else if (nact == 64) {
+      r0 = r1; r1 = r2;
+      rv_pre = gload_rec2(rec_blk, layout_rows(r0, n0_next));
+      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+      rk_ok = true;
+      pre_n0 = n0_next;
     } else {
       // a shorter step: the next step's rows are in the ring already, nact lanes further on -> rotate the ring
       // (three cross-lane moves) instead of reloading it, and gather the rec values of the next step right away:
@@ -2251,10 +2377,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const bool wrap = lane + (uint32_t)nact >= 64u;
       r0 = wrap ? a1 : a0;
       r1 = wrap ? a2 : a1;
-      if (NP == 2) rv_pre = gload_rec2(rec_blk, r0);
+      if (NP == 2) rv_pre = gload_rec2(rec_blk, layout_rows(r0, n0_next));
       else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
       r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
       rk_ok = true;
+      pre_n0 = n0_next;
     }
     if (fast_ties) {
       // a GROUP step needs the last position of every row's tie group in the gathered column -> gathered one step
@@ -2273,7 +2400,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     uint32_t q[NP], lo[NP];
 
     if (all_fast) {
-      hot_step(rk);
+      hot_step(rk, std::false_type{});
       ICIKT_ST_MARK(1, 64)
       continue;
     }
@@ -2306,11 +2433,20 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         if constexpr (half_mode) {
           // the hot step on the step's rows (lanes past them: a position in the guard word, lo = 0), then the pairs
           // inside the groups
+          const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
           uint32_t rkm[NP];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) rkm[k] = ((int)lane_t < nact) ? rk[k] : ((uint32_t)W << 6);
-          hot_step(rkm);
-          c = half_mixed64_corr(dmax, nact, gi, rkm[0], rkm[NP - 1], lane_t);
+          for (int k = 0; k < NP; ++k) rkm[k] = vrow ? rk[k] : ((uint32_t)W << 6);
+          // row layout -> (pair, row of the sub-step): a lane's two rows are those of lanes l and l + 32
+          {
+            const auto m1 = __builtin_amdgcn_permlane32_swap(tmx.x, tmx.x, false, false);
+            const auto m2 = __builtin_amdgcn_permlane32_swap(tmx.y, tmx.y, false, false);
+            mix_sg1 = m1[0] | m1[1];
+            mix_sg2 = m2[0] | m2[1];
+          }
+          mix_dmax = (int)tprog_dmax(e_cur);
+          hot_step(rkm, std::true_type{});
+          c.dis = 0; c.neg = 0; c.tie = 0; c.tie2 = 0; c.cfill = 0;   // (counted inside the step)
         }
         else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {

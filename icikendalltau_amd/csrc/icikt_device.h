@@ -27,14 +27,12 @@ struct ColStats {
 };
 constexpr int COL_ODD_TIE = 1;
 
-// tie-program entry: rows of the step | kind << 7 | closes << 9 | n0 << 10 (MIXED: rows of its first sub-step) |
-// dmax << 16 (MIXED: rows of its largest group - 1: how far apart two rows of one group can be)
+// tie-program entry: rows of the step | kind << 7 | closes << 9 | n0 << 10 (MIXED: rows of its first sub-step)
 constexpr uint32_t TPROG_KIND_HOT = 0u, TPROG_KIND_MIXED = 1u, TPROG_KIND_GROUP = 2u;
 __host__ __device__ inline uint32_t tprog_rows(uint32_t e) { return e & 127u; }
 __host__ __device__ inline uint32_t tprog_kind(uint32_t e) { return (e >> 7) & 3u; }
 __host__ __device__ inline bool tprog_closes(uint32_t e) { return ((e >> 9) & 1u) != 0u; }
 __host__ __device__ inline uint32_t tprog_n0(uint32_t e) { return (e >> 10) & 63u; }
-__host__ __device__ inline uint32_t tprog_dmax(uint32_t e) { return (e >> 16) & 63u; }
 
 // setup_missing_matrix (R/utils.R:1-23) on the device: which cells of the data matrix are excluded (become NA,
 // R/kendalltau.R:119-121) before the pre-pass.  The pre-pass applies it while it reads the matrix, so the masked copy

@@ -253,91 +253,124 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
 // Two rows D lanes apart belong to one group iff D <= idx of the later one (rows of its group in front of it) iff
 // D <= fwd of the earlier one (rows of its group behind it).
 constexpr int TPROG_KS = 32;   // == k1_ks(true): MIXED steps take groups of up to this many rows
-__device__ inline void k0_tie_program(const unsigned long long* gf, int n, int W, uint32_t* prog, uint2* tmask, uint32_t lane) {
-  int first_cont = n;   // first position that continues a group
-  for (int w = (int)lane; w < W; w += 64) {
-    unsigned long long z = ~gf[w];
-    if (w == W - 1 && (n & 63)) z &= (1ull << (n & 63)) - 1ull;
-    if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
-  }
-  first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
-  const int hot_until = (first_cont < n) ? first_cont - 1 : n;
-  int pos = (hot_until >> 6) << 6;
-  int ne = 0;
-  while (pos < n) {
-    const int wc = pos >> 6, fb = pos & 63;
-    const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
-    unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
-    const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
-    const int remaining = n - pos;
-    if (remaining < 64) F &= (1ull << remaining) - 1ull;
-    const int avail = (remaining <= 64) ? remaining : 64;
-    const bool endbit = fnbit || remaining == 64;            // offset 64 starts a group / is the end of the data
-    uint32_t nact, kind, closes = 1u, n0 = 0u, dmax = 0u;
-    if (avail == 64 && F == ~0ull && endbit) {
-      nact = 64u; kind = TPROG_KIND_HOT;
-    } else {
-      // group boundaries of the window: the starts, and the end of the data (one marker: no boundary beyond it)
-      const unsigned long long Fe = (avail < 64) ? (F | (1ull << avail)) : F;
-      const unsigned long long Fr = Fe & ~1ull;
-      const int next = (Fr != 0ull) ? (int)__builtin_ctzll(Fr) : (endbit ? 64 : 65);   // end of the group at pos
-      if ((F & 1ull) == 0ull || next > TPROG_KS) {
-        kind = TPROG_KIND_GROUP;
-        const int glim = min(remaining, 64);
-        nact = (uint32_t)min(next, glim);
-        closes = (next <= glim) ? 1u : 0u;
-      } else {
-        kind = TPROG_KIND_MIXED;
-        // sub-step 0: up to the last boundary within 32 rows (there is one: the first group has at most 32 rows)
-        const int b0 = 63 - (int)__builtin_clzll(Fe & 0x1FFFFFFFEull);
-        // sub-step 1: from b0 up to the last boundary within the next 32 rows; none: the next group is longer (or
-        // the data end at b0) and the step ends at b0.  The boundary at offset 64 (b0 == 32 only) is `endbit`.
-        unsigned long long rest = (Fe >> b0) & 0x1FFFFFFFEull;
-        if (b0 == 32 && endbit) rest |= 1ull << 32;
-        const int b1 = (rest != 0ull) ? (63 - (int)__builtin_clzll(rest)) : 0;
-        n0 = (uint32_t)b0;
-        nact = (uint32_t)(b0 + b1);
-        {
-          unsigned long long z = ~F & ((nact >= 64u) ? ~0ull : ((1ull << nact) - 1ull));   // rows that continue a group
-          while (z != 0ull) { z &= z >> 1; ++dmax; }
-        }
-        // ---- the step's rows, one lane each: sub-step s = lane >> 5, l = lane & 31 --------------------------------
-        const uint32_t sb = lane >> 5, l = lane & 31u;
-        const bool valid = l < (sb ? (uint32_t)b1 : (uint32_t)b0);
-        if (valid) {
-          const uint32_t o = sb ? (uint32_t)b0 + l : l;                                   // offset of the row in the window (< 64)
-          const unsigned long long upto = Fe & ((o < 63u) ? ((2ull << o) - 1ull) : ~0ull);
-          const uint32_t idx = o - (63u - (uint32_t)__builtin_clzll(upto));               // bit 0 is set: the step starts a group
-          const unsigned long long above = (o < 63u) ? (Fe >> (o + 1u)) : 0ull;
-          const uint32_t nxt = (above != 0ull) ? (o + 1u + (uint32_t)__builtin_ctzll(above)) : 64u;   // (offset 64: endbit)
-          const uint32_t fwd = nxt - 1u - o;
-          const uint32_t p = l & 15u;
-          const bool upper = (l & 16u) != 0u;
-          const uint32_t c = min(min(idx, p), 15u);                                       // in-row partners inside my group
-          uint32_t a1 = (1u << ((c + 1u) >> 1)) - 1u, b1m = (1u << (c >> 1)) - 1u;         // vector 1: a / b slots
-          uint32_t a2 = 0u, b2 = 0u, r7 = 0u;
-#pragma unroll
-          for (uint32_t r = 0; r < 8; ++r) {
-            const uint32_t D = upper ? ((p >= r) ? 16u + r : r) : ((p >= r + 1u) ? 15u - r : 31u - r);
-            const bool same = upper ? (D <= idx) : (D <= fwd);
-            if (!same) continue;
-            if (r == 0u) b1m |= 0x80u;
-            else if (r == 7u) r7 = 1u;
-            else if (r & 1u) a2 |= 1u << (4u + ((r - 1u) >> 1));
-            else b2 |= 1u << (4u + ((r - 2u) >> 1));
-          }
-          uint2 m;
-          m.x = (b1m << (8u * sb)) | (a1 << (8u * (2u + sb)));
-          m.y = (b2 << (8u * sb)) | (a2 << (8u * (2u + sb))) | (r7 ? (sb ? 0x80000000u : 0x00008000u) : 0u);
-          tmask[(uint32_t)pos + o] = m;
-        }
-      }
+// The cross-row part of a row's masks depends on its lane and on ONE number, lim = idx of an upper-row lane / fwd of a
+// lower-row lane (<= 31): a table [32][64] in LDS, filled once per workgroup, replaces eight compares per row and step.
+//   bit 7: vector 1, rotation 0; bits 4..6: vector 2, rotations 2 4 6 (b slots); bits 12..14: rotations 1 3 5 (a slots);
+//   bit 16: rotation 7
+__device__ inline void k0_cross_table(uint32_t* T, int tid, int nthreads) {
+  for (int i = tid; i < 32 * 64; i += nthreads) {
+    const uint32_t lim = (uint32_t)i >> 6, l = (uint32_t)i & 31u, p = l & 15u;
+    const bool upper = (l & 16u) != 0u;
+    uint32_t t = 0u;
+    for (uint32_t r = 0; r < 8; ++r) {
+      const uint32_t D = upper ? ((p >= r) ? 16u + r : r) : ((p >= r + 1u) ? 15u - r : 31u - r);
+      if (D > lim) continue;
+      if (r == 0u) t |= 0x80u;
+      else if (r == 7u) t |= 0x10000u;
+      else if (r & 1u) t |= 0x1000u << ((r - 1u) >> 1);
+      else t |= 0x10u << ((r - 2u) >> 1);
     }
-    if (lane == 0u) prog[ne] = nact | (kind << 7) | (closes << 9) | (n0 << 10) | (dmax << 16);
-    ++ne;
-    pos += (int)nact;
+    T[i] = t;
   }
-  if (lane == 0u) prog[ne] = 0u;
+}
+
+// One step's entry, as if a step STARTED at position pos (every position is evaluated, in parallel; the steps the walk
+// really takes are then picked out by following the chain).  16 bits: the layout of PrepView::tprog entries.
+__device__ __forceinline__ uint32_t k0_step_at(const unsigned long long* gf, int n, int W, int pos) {
+  const int wc = pos >> 6, fb = pos & 63;
+  const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
+  unsigned long long F = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+  const bool fnbit = ((w1 >> fb) & 1ull) != 0ull;          // position pos + 64 starts a group
+  const int remaining = n - pos;
+  if (remaining < 64) F &= (1ull << remaining) - 1ull;
+  const int avail = (remaining <= 64) ? remaining : 64;
+  const bool endbit = fnbit || remaining == 64;            // offset 64 starts a group / is the end of the data
+  if (avail == 64 && F == ~0ull && endbit) return 64u | (TPROG_KIND_HOT << 7) | (1u << 9);
+  // group boundaries of the window: the starts, and the end of the data (one marker: no boundary beyond it)
+  const unsigned long long Fe = (avail < 64) ? (F | (1ull << avail)) : F;
+  const unsigned long long Fr = Fe & ~1ull;
+  const int next = (Fr != 0ull) ? (int)__builtin_ctzll(Fr) : (endbit ? 64 : 65);   // end of the group at pos
+  if ((F & 1ull) == 0ull || next > TPROG_KS) {
+    const int glim = min(remaining, 64);
+    return (uint32_t)min(next, glim) | (TPROG_KIND_GROUP << 7) | ((next <= glim) ? (1u << 9) : 0u);
+  }
+  // MIXED.  Sub-step 0: up to the last boundary within 32 rows (there is one: the first group has at most 32 rows);
+  // sub-step 1: from b0 up to the last boundary within the next 32 rows -- none: the next group is longer (or the
+  // data end at b0) and the step ends at b0.  The boundary at offset 64 (b0 == 32 only) is `endbit`.
+  const int b0 = 63 - (int)__builtin_clzll(Fe & 0x1FFFFFFFEull);
+  unsigned long long rest = (Fe >> b0) & 0x1FFFFFFFEull;
+  if (b0 == 32 && endbit) rest |= 1ull << 32;
+  const int b1 = (rest != 0ull) ? (63 - (int)__builtin_clzll(rest)) : 0;
+  return (uint32_t)(b0 + b1) | (TPROG_KIND_MIXED << 7) | (1u << 9) | ((uint32_t)b0 << 10);
+}
+
+// the same-group flag masks of the rows of the MIXED step that starts at pos (entry e): one lane per row
+__device__ __forceinline__ void k0_step_masks(const unsigned long long* gf, const uint32_t* crossT, int n, int W, int pos,
+                                              uint32_t e, uint2* tmask, uint32_t lane) {
+  const uint32_t b0 = tprog_n0(e), b1 = tprog_rows(e) - b0;
+  const uint32_t sb = lane >> 5, l = lane & 31u;
+  if (l >= (sb ? b1 : b0)) return;
+  const int wc = pos >> 6, fb = pos & 63;
+  const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
+  unsigned long long Fe = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
+  const int remaining = n - pos;
+  if (remaining < 64) Fe = (Fe & ((1ull << remaining) - 1ull)) | (1ull << remaining);
+  const uint32_t o = sb ? b0 + l : l;                                             // offset of the row in the window (< 64)
+  const unsigned long long upto = Fe & ((o < 63u) ? ((2ull << o) - 1ull) : ~0ull);
+  const uint32_t idx = o - (63u - (uint32_t)__builtin_clzll(upto));               // bit 0 is set: the step starts a group
+  const unsigned long long above = (o < 63u) ? (Fe >> (o + 1u)) : 0ull;
+  const uint32_t nxt = (above != 0ull) ? (o + 1u + (uint32_t)__builtin_ctzll(above)) : 64u;   // (offset 64: the step ends there)
+  const uint32_t fwd = nxt - 1u - o;
+  const uint32_t p = l & 15u;
+  const uint32_t c = min(min(idx, p), 15u);                                       // in-row partners inside my group
+  const uint32_t a1 = (1u << ((c + 1u) >> 1)) - 1u, b1m = (1u << (c >> 1)) - 1u;   // vector 1: a / b slots
+  const uint32_t t = crossT[min((l & 16u) ? idx : fwd, 31u) * 64u + lane];
+  const uint32_t sh = 8u * sb;
+  uint2 m;
+  m.x = ((b1m | (t & 0x80u)) << sh) | (a1 << (16u + sh));
+  m.y = ((t & 0x70u) << sh) | (((t >> 8) & 0x70u) << (16u + sh)) | ((t & 0x10000u) ? (0x8000u << (16u * sb)) : 0u);
+  tmask[(uint32_t)pos + o] = m;
+}
+
+// The whole workgroup builds the program: (A) every position's would-be step, in parallel, into E (u16 per position, LDS);
+// (B) one wave follows the chain from pos0 -- one LDS read per step instead of a hundred dependent scalar operations --
+// writes the entries and lists the MIXED steps; (C) the waves share out the MIXED steps and write their rows' masks.
+// scratch: E (n u16) | list of MIXED step positions (u16) | crossT (32 x 64 u32); `cnt`: one shared int.
+__device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
+                                      int n, int W, uint32_t* prog, uint2* tmask, int tid, int nthreads) {
+  const uint32_t lane = (uint32_t)tid & 63u;
+  const int wave = tid >> 6, nwaves = nthreads >> 6;
+  k0_cross_table(crossT, tid, nthreads);
+  for (int p = tid; p < n; p += nthreads) E[p] = (uint16_t)k0_step_at(gf, n, W, p);
+  __syncthreads();
+  if (wave == 0) {
+    int first_cont = n;   // first position that continues a group
+    for (int w = (int)lane; w < W; w += 64) {
+      unsigned long long z = ~gf[w];
+      if (w == W - 1 && (n & 63)) z &= (1ull << (n & 63)) - 1ull;
+      if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
+    }
+    first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
+    const int hot_until = (first_cont < n) ? first_cont - 1 : n;
+    int pos = (hot_until >> 6) << 6, ne = 0, nm = 0;
+    while (pos < n) {
+      const uint32_t e = (uint32_t)E[pos];
+      if (lane == 0u) {
+        prog[ne] = e;
+        if (tprog_kind(e) == TPROG_KIND_MIXED) mlist[nm] = (uint16_t)pos;
+      }
+      nm += (tprog_kind(e) == TPROG_KIND_MIXED) ? 1 : 0;
+      ++ne;
+      pos += (int)tprog_rows(e);
+    }
+    if (lane == 0u) { prog[ne] = 0u; *cnt = nm; }
+  }
+  __syncthreads();
+  const int nm = *cnt;
+  for (int i = wave; i < nm; i += nwaves) {
+    const int pos = (int)mlist[i];
+    k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos], tmask, lane);
+  }
 }
 
 // WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
@@ -648,7 +681,13 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     }
     if (tid == 0) sh_bits_lds[W] = 0ull;
     __syncthreads();
-    if (tid < 64) k0_tie_program(sh_bits_lds, n, W, pv.tprog + (int64_t)c * pv.tp_stride, pv.tmask + (int64_t)c * pv.n_ord, (uint32_t)tid);
+    // scratch in the sort tile / rec staging area (48 KB, copied out above): E 18 432 u16 | crossT 2 048 u32 | list 1 536 u16
+    uint16_t* E = reinterpret_cast<uint16_t*>(sh_sort);
+    uint32_t* crossT = reinterpret_cast<uint32_t*>(E + 18432);
+    uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
+    k0_tie_program(sh_bits_lds, E, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+                   pv.tmask + (int64_t)c * pv.n_ord, tid, K0_THREADS);
+    __syncthreads();   // (sh_i is used by the reductions below)
   }
 
   // list of the tie groups (size >= 2) in ascending order, lo | hi << 16: K1 counts the joint ties of a
@@ -723,6 +762,10 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   __shared__ __attribute__((aligned(8))) int prevs[1032];   // highest group start in the words before w (-1: none)
   __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
+  __shared__ uint32_t kx_cross[32 * 64];   // k0_tie_program's scratch: cross table, would-be steps, MIXED step list
+  __shared__ uint16_t kx_E[18432];
+  __shared__ uint16_t kx_list[1536];
+  __shared__ int kx_cnt;
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   const int c = col_begin + (int)blockIdx.x;
@@ -811,7 +854,8 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     unsigned long long* gfl = reinterpret_cast<unsigned long long*>(prevs);   // the scan arrays are free now: 1032 ints = 516 words
     for (int w = (int)threadIdx.x; w <= W; w += 64 * KX_WAVES) gfl[w] = gf[w];
     __syncthreads();
-    if (wave == 0) k0_tie_program(gfl, n, W, pv.tprog + (int64_t)c * pv.tp_stride, pv.tmask + (int64_t)c * pv.n_ord, (uint32_t)lane);
+    k0_tie_program(gfl, kx_E, kx_list, kx_cross, &kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+                   pv.tmask + (int64_t)c * pv.n_ord, (int)threadIdx.x, 64 * KX_WAVES);
   }
 }
 
@@ -1115,49 +1159,6 @@ __device__ __forceinline__ void half_step_flags(uint32_t src, uint32_t own, uint
                "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %7, %0\n\t"
                : "=&v"(v2), "=&v"(t1), "=&v"(t2)
                : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
-}
-
-// The flags of the distances a small tie group can span, in the same bit positions: two rows of one group lie at most
-// DMAX lanes apart, so of the other direction's chain (which only serves pairs inside a group) the in-row distances
-// 1 .. DMAX and the rotations 1 .. DMAX (an upper-row lane whose partner sits in the last lanes of the lower row)
-// are all there is.  DMAX = 2: 11 instructions, 4: 23, against 58 for the whole chain.
-template <int DMAX>
-__device__ __forceinline__ void half_step_flags_near(uint32_t src, uint32_t own, uint32_t offer, uint32_t partner_addr,
-                                                     uint32_t& v1, uint32_t& v2) {
-  static_assert(DMAX == 2 || DMAX == 4, "half_step_flags_near variants");
-  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)offer);
-  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u;
-  uint32_t t1, t2, u1, u2;
-  // vector 1: distances (1, 2) -> bit 0 of the a / b bytes, (3, 4) -> bit 1
-  asm volatile("s_nop 1\n\t"
-               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 7, %0\n\t"
-               : "=&v"(v1), "=&v"(t1), "=&v"(t2)
-               : "v"(src), "v"(own), "s"(M8), "s"(SEL));
-  // vector 2: rotations (1, 2) -> bit 4, (3, 4) -> bit 5
-  asm volatile("s_nop 1\n\t"
-               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
-               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 3, %0\n\t"
-               : "=&v"(v2), "=&v"(t1), "=&v"(t2)
-               : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
-  if (DMAX == 4) {
-    asm volatile("s_nop 1\n\t"
-                 "v_add_u32_dpp %1, %3, %4 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "v_add_u32_dpp %2, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 6, %0\n\t"
-                 : "=&v"(u1), "=&v"(t1), "=&v"(t2)
-                 : "v"(src), "v"(own), "s"(M8), "s"(SEL));
-    asm volatile("s_nop 1\n\t"
-                 "v_add_u32_dpp %1, %3, %4 row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_u32_dpp %2, %3, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\tv_lshrrev_b32_e32 %0, 2, %0\n\t"
-                 : "=&v"(u2), "=&v"(t1), "=&v"(t2)
-                 : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
-    v1 |= u1;
-    v2 |= u2;
-  }
 }
 
 // ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
@@ -2081,7 +2082,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // (wave_allpairs_packed2): inside the hot loop the step itself skips them
   bool defer_allpairs = false;
   uint32_t mix_sg1 = 0u, mix_sg2 = 0u;   // MIXED: the lane's same-group flag masks (both sub-steps); 0 in a plain hot step
-  int mix_dmax = 0;                      // MIXED: rows of the step's largest group - 1 (wave-uniform)
   auto hot_step = [&](const uint32_t (&rk)[NP], auto mixed_tag) {
     constexpr bool MIXED = decltype(mixed_tag)::value;
     if constexpr (half_mode) {
@@ -2127,10 +2127,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             const uint32_t A = 0x7FFF7FFFu - Q, B = LO;
             uint32_t f1, f2, g1, g2;
             half_step_flags(A, B, (lane & 16u) ? B : A, partner_addr, f1, f2);      // [q_earlier < lo_later]
-            // [q_later < lo_earlier]: only pairs inside a group need it, and those lie at most mix_dmax lanes apart
-            if (mix_dmax <= 2) half_step_flags_near<2>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
-            else if (mix_dmax <= 4) half_step_flags_near<4>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
-            else half_step_flags(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            half_step_flags(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);      // [q_later < lo_earlier]
             inpairs = bcnt_acc(f2 & ~mix_sg2, bcnt_acc(f1 & ~mix_sg1, 0u));         // pairs of different groups only
             seg_tie = bcnt_acc(mix_sg2 & ~(f2 | g2), bcnt_acc(mix_sg1 & ~(f1 | g1), seg_tie));   // joint ties inside the groups
           }
@@ -2236,7 +2233,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     int kind = 0;          // 0: hot step or the general step (decided below), 1: MIXED, 2: GROUP (fast tie steps)
     bool closes = true;    // GROUP: the step holds the group's last row
     int n0 = 32;           // MIXED (half-wave kernels): rows of the first sub-step (the second one starts at lane 32)
-    uint32_t e_next = 0u, e_cur = 0u;  // half-wave kernels: this step's and the next step's program entries
+    uint32_t e_next = 0u;  // half-wave kernels: the next step's program entry
     uint2 tmx = make_uint2(0u, 0u);   // MIXED (half-wave kernels): the row's same-group flag masks
     if constexpr (half_mode) {
       // The step comes from the streamed column's TIE PROGRAM (k0_tie_program: cut and classified once per column by
@@ -2252,7 +2249,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         tp_ok = true;
       }
       const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_a);
-      e_cur = e;
       e_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_b);
       tp_a = tp_b;
       {
@@ -2444,7 +2440,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             mix_sg1 = m1[0] | m1[1];
             mix_sg2 = m2[0] | m2[1];
           }
-          mix_dmax = (int)tprog_dmax(e_cur);
           hot_step(rkm, std::true_type{});
           c.dis = 0; c.neg = 0; c.tie = 0; c.tie2 = 0; c.cfill = 0;   // (counted inside the step)
         }

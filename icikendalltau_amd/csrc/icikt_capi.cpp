@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -152,7 +153,32 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
 // block of the interleaved rec table, so that ONE 8-byte gather per row serves both pairs; pairs without such
 // a partner run alone.  Tasks are ordered by gathered block, then streamed column (cache locality of the
 // block's rec table).
+// the host copies of a combn range (the device arrays were filled by a kernel)
+void ensure_host_pairs(icikt_ctx* c) {
+  if (c->h_pairs_valid) return;
+  const int64_t n_samp = c->combn_S, begin = c->combn_begin, end = c->combn_end;
+  c->h_pi.resize((size_t)(end - begin));
+  c->h_pj.resize((size_t)(end - begin));
+  // walk combn order: row i holds pairs (i, i+1..S-1), starting at offset i*S - i(i+1)/2
+  int64_t i = 0, row_start = 0;
+  while (i < n_samp - 1 && row_start + (n_samp - 1 - i) <= begin) {
+    row_start += n_samp - 1 - i;
+    ++i;
+  }
+  int64_t j = i + 1 + (begin - row_start);
+  for (int64_t p = begin; p < end; ++p) {
+    c->h_pi[(size_t)(p - begin)] = (int32_t)i;
+    c->h_pj[(size_t)(p - begin)] = (int32_t)j;
+    if (++j >= n_samp) {
+      ++i;
+      j = i + 1;
+    }
+  }
+  c->h_pairs_valid = true;
+}
+
 void build_units(icikt_ctx* c, int np) {
+  ensure_host_pairs(c);
   auto& u = c->h_units;
   u.clear();
   const int64_t P = c->n_pairs;
@@ -232,6 +258,49 @@ int upload_units(icikt_ctx* c) {
   return icikt::host::upload_sync(c, c->d_unit_start.p, c->h_units.data(), c->h_units.size() * sizeof(int32_t));
 }
 
+// One launch of the pair kernel over tasks [first, first + count) of the uploaded task list, on c->stream.
+int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
+  if (count <= 0) return ICIKT_SUCCESS;
+  // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
+  // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
+  // wave owns a slot of it: the grid is what the chip holds at once and the waves fetch tasks, in order, from
+  // one counter per XCD group (k1_pairs: why the order matters for the L2).
+  int per_cu = 0;
+  HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
+  if (per_cu < 1) per_cu = 1;
+  const int want = (count + pl.wpb - 1) / pl.wpb;
+  int blocks = want;
+  if (pl.pend_global) {
+    const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
+    const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
+    blocks = (int)std::min<int64_t>(want, mult * resident);
+    // test hook: a grid far smaller than the task list makes every persistent wave run many tasks in a row
+    // (slot reuse, the per-XCD task counters, the in-order fetch) whatever the chip would hold
+    if (c->plan_ov.grid_cap > 0) blocks = std::min(blocks, c->plan_ov.grid_cap);
+  }
+  blocks = std::max(blocks, 1);
+  if (c->plan_ov.verbose)
+    fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d (from %d)\n",
+            pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
+            blocks, count, first);
+  if (pl.pend_global) {
+    const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * pl.stride;
+    if (pend_elems > c->d_pend_bits.cap) {
+      HIPCHK(c, c->d_pend_bits.reserve(pend_elems));
+      HIPCHK(c, c->d_pend_pre.reserve(pend_elems));
+      // slots start (and are left by every task) all zero
+      HIPCHK(c, hipMemsetAsync(c->d_pend_bits.p, 0, c->d_pend_bits.cap * sizeof(unsigned long long), c->stream));
+      HIPCHK(c, hipMemsetAsync(c->d_pend_pre.p, 0, c->d_pend_pre.cap * sizeof(uint32_t), c->stream));
+    }
+    HIPCHK(c, c->d_task_ctr.reserve(8));
+    HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
+  }
+  HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
+                             pl.pend_global, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
+                             c->d_pend_pre.p, c->d_task_ctr.p, pl.opts, c->stream));
+  return ICIKT_SUCCESS;
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +334,16 @@ int icikt_ctx_create(int device, icikt_ctx** out) {
     icikt_ctx_destroy(c);
     return ICIKT_E_HIP;
   }
+  {
+    // the pre-pass of a chunk must not queue behind the pair kernel of the chunks before it for longer than that
+    // kernel's workgroups take to retire: the highest priority the device offers
+    int lo_prio = 0, hi_prio = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) { (void)hipGetLastError(); hi_prio = 0; }
+    if (hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, hi_prio) != hipSuccess) {
+      icikt_ctx_destroy(c);
+      return ICIKT_E_HIP;
+    }
+  }
   for (auto& e : c->ev_copy)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
       icikt_ctx_destroy(c);
@@ -293,6 +372,10 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   for (auto& e : c->ev_copy)
     if (e) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->pinned_tasks) (void)hipHostFree(c->pinned_tasks);
+  for (auto& e : c->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
+  if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -423,17 +506,18 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   return ICIKT_SUCCESS;
 }
 
-int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end) {
+int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end, hipStream_t stream) {
   const PrepView& pv = c->pv;
+  if (!stream) stream = c->stream;
   c->raw_valid = false;
   if (col_end > col_begin)
     HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
-                             (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), c->stream));
+                             (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), stream));
   if (pv.n > 0) {
     const int64_t chunk = std::max(1, c->sort_chunk);
     for (int64_t c0 = col_begin; c0 < col_end; c0 += chunk) {
       const int nc = (int)std::min<int64_t>(chunk, col_end - c0);
-      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->k0_mask, c->k0_keep, c->stream));
+      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->k0_mask, c->k0_keep, stream));
     }
   }
   return ICIKT_SUCCESS;
@@ -545,6 +629,8 @@ int icikt_set_pairs(icikt_ctx* c, const int32_t* pi, const int32_t* pj, int64_t 
   c->pairs_nsamp = (int64_t)mx + 1;
   c->raw_valid = false;
   c->wpb = 0;  // units are (re)built at run time for the plan of the prepared matrix
+  c->combn_S = -1;
+  c->h_pairs_valid = true;
   return upload_pairs(c);
 }
 
@@ -556,32 +642,20 @@ int icikt_set_pairs_combn(icikt_ctx* c, int64_t n_samp, int64_t begin, int64_t e
   if (end - begin >= ((int64_t)1 << 31) - 1) return fail(c, ICIKT_E_INVALID, "set_pairs_combn: too many pairs");
   int rc = use_device(c);
   if (rc) return rc;
-  try {
-    c->h_pi.resize((size_t)(end - begin));
-    c->h_pj.resize((size_t)(end - begin));
-  } catch (const std::bad_alloc&) {
-    return fail(c, ICIKT_E_NOMEM, "set_pairs_combn: host allocation failed");
-  }
-  // walk combn order: row i holds pairs (i, i+1..S-1), starting at offset i*S - i(i+1)/2
-  int64_t i = 0, row_start = 0;
-  while (i < n_samp - 1 && row_start + (n_samp - 1 - i) <= begin) {
-    row_start += n_samp - 1 - i;
-    ++i;
-  }
-  int64_t j = i + 1 + (begin - row_start);
-  for (int64_t p = begin; p < end; ++p) {
-    c->h_pi[(size_t)(p - begin)] = (int32_t)i;
-    c->h_pj[(size_t)(p - begin)] = (int32_t)j;
-    if (++j >= n_samp) {
-      ++i;
-      j = i + 1;
-    }
-  }
+  // the pair arrays of a combn range are arithmetic: a kernel fills the device copies (no host loop, no upload);
+  // the host copies are made only if a host-built task list needs them (ensure_host_pairs)
   c->n_pairs = end - begin;
   c->pairs_nsamp = n_samp;
   c->raw_valid = false;
   c->wpb = 0;
-  return upload_pairs(c);
+  c->combn_S = n_samp; c->combn_begin = begin; c->combn_end = end;
+  c->h_pairs_valid = false;
+  const int64_t P = c->n_pairs;
+  HIPCHK(c, c->d_pi.reserve((size_t)std::max<int64_t>(P, 1)));
+  HIPCHK(c, c->d_pj.reserve((size_t)std::max<int64_t>(P, 1)));
+  HIPCHK(c, c->d_raw.reserve((size_t)std::max<int64_t>(P, 1)));
+  HIPCHK(c, icikt::launch_fill_combn(c->d_pi.p, c->d_pj.p, n_samp, begin, P, c->stream));
+  return ICIKT_SUCCESS;
 }
 
 int64_t icikt_num_pairs(const icikt_ctx* c) { return c ? c->n_pairs : -1; }
@@ -629,62 +703,27 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
                                continuity ? 1 : 0, /*exact64=*/1, d_out4, d_counts, d_reasons, c->stream));
     return timer_end(c, ICIKT_K_EPILOGUE, flags);
   }
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
-  if (c->wpb != pl.np) {
-    build_units(c, pl.np);
-    c->units_dirty = true;
-  }
-  if (c->units_dirty) {
-    rc = upload_units(c);
-    if (rc) return rc;
-    c->units_dirty = false;
-  }
   // The pair kernel's counts (dis, joint ties, both-missing rows) do not depend on perspective, alternative or
   // continuity: with ICIKT_FLAG_REUSE_COUNTS a second run over the same prepared matrix and pair list (the other
   // perspective of BASELINE config 5, another alternative) is the epilogue alone.
   const bool reuse = (flags & ICIKT_FLAG_REUSE_COUNTS) && c->raw_valid;
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  if (c->pv.n > 0 && !reuse) {
+    if (c->wpb != pl.np) {
+      build_units(c, pl.np);
+      c->units_dirty = true;
+    }
+    if (c->units_dirty) {
+      rc = upload_units(c);
+      if (rc) return rc;
+      c->units_dirty = false;
+    }
+  }
   if (c->pv.n > 0 && !reuse) {
     rc = timer_begin(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
-    // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
-    // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
-    // wave owns a slot of it: the grid is what the chip holds at once and the waves fetch tasks, in order, from
-    // one counter per XCD group (k1_pairs: why the order matters for the L2).
-    int per_cu = 0;
-    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
-    if (per_cu < 1) per_cu = 1;
-    const int want = (c->n_units + pl.wpb - 1) / pl.wpb;
-    int blocks = want;
-    if (pl.pend_global) {
-      const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
-      const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
-      blocks = (int)std::min<int64_t>(want, mult * resident);
-      // test hook: a grid far smaller than the task list makes every persistent wave run many tasks in a row
-      // (slot reuse, the per-XCD task counters, the in-order fetch) whatever the chip would hold
-      if (c->plan_ov.grid_cap > 0) blocks = std::min(blocks, c->plan_ov.grid_cap);
-    }
-    blocks = std::max(blocks, 1);
-    if (c->plan_ov.verbose)
-      fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d\n",
-              pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
-              blocks, c->n_units);
-    if (pl.pend_global) {
-      const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * pl.stride;
-      if (pend_elems > c->d_pend_bits.cap) {
-        HIPCHK(c, c->d_pend_bits.reserve(pend_elems));
-        HIPCHK(c, c->d_pend_pre.reserve(pend_elems));
-        // slots start (and are left by every task) all zero
-        HIPCHK(c, hipMemsetAsync(c->d_pend_bits.p, 0, c->d_pend_bits.cap * sizeof(unsigned long long), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_pend_pre.p, 0, c->d_pend_pre.cap * sizeof(uint32_t), c->stream));
-      }
-    }
-    if (pl.pend_global) {
-      HIPCHK(c, c->d_task_ctr.reserve(8));
-      HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
-    }
-    HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p, c->n_units, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
-                               pl.pend_global, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
-                               c->d_pend_pre.p, c->d_task_ctr.p, pl.opts, c->stream));
+    rc = launch_pair_tasks(c, pl, 0, c->n_units);
+    if (rc) return rc;
     rc = timer_end(c, ICIKT_K_PAIRS, flags);
     if (rc) return rc;
     c->raw_valid = true;
@@ -776,8 +815,9 @@ int ensure_bounce(icikt_ctx* c, size_t need) {
 //   mode 0            pageable copies through the runtime's own staging path: only for matrices below kLockMin
 //                     bytes, never selected for larger ones (icikt_host.h)
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister) {
+                       int64_t col_end, uint32_t flags, const void** deferred_unregister, bool pipelined) {
   if (deferred_unregister) *deferred_unregister = nullptr;
+  c->chunk_col_end.clear();
   const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
   HIPCHK(c, c->d_X.reserve(nel));
   int rc = timer_begin(c, ICIKT_K_PREPARE, flags);
@@ -787,6 +827,11 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     const size_t col_bytes = (size_t)n_feat * sizeof(double);
     // ~8 MB per chunk (an even number of columns: K0 ranges need not be even, but keeps chunks aligned)
     int64_t chunk = std::max<int64_t>(2, (int64_t)(((size_t)8 << 20) / std::max<size_t>(col_bytes, 1)) & ~(int64_t)1);
+    // pipelined: a chunk is also what one pre-pass launch and one pair-kernel launch cover.  A pre-pass launch takes
+    // the time of ONE column's sort up to a workgroup per CU, so chunks of fewer columns only lengthen the chain of
+    // pre-pass launches the last pair-kernel launch waits for (c4: ten chunks of 104 columns finished their pre-pass
+    // 1.4 ms after the last copy, four chunks of 256 right behind it)
+    if (pipelined) chunk = std::max<int64_t>(chunk, std::min<int64_t>(c->prop.multiProcessorCount, (n_samp / 4) & ~(int64_t)1));
     chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
     const double* src0 = X + col_begin * ld;
     const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
@@ -804,6 +849,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     // the copy stream must not overwrite d_X while earlier work on the compute stream still reads it
     hipError_t e = hipEventRecord(c->ev_copy[0], c->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0);
+    if (e == hipSuccess && pipelined) e = hipStreamWaitEvent(c->prep_stream, c->ev_copy[0], 0);
     int k = 0;
     for (int64_t c0 = col_begin; c0 < col_end && e == hipSuccess && rc == 0; c0 += chunk, ++k) {
       const int64_t nc = std::min<int64_t>(chunk, col_end - c0);
@@ -820,9 +866,23 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
                              hipMemcpyHostToDevice, c->copy_stream);
       }
       if (e == hipSuccess) e = hipEventRecord(ev, c->copy_stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
-      if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
+      if (pipelined) {
+        // the chunk's pre-pass on the pre-pass stream; an event of its own tells the pair kernel's stream when
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->prep_stream, ev, 0);
+        if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc, c->prep_stream);
+        if ((size_t)k >= c->ev_chunk.size()) {
+          hipEvent_t ne = nullptr;
+          if (e == hipSuccess) e = hipEventCreateWithFlags(&ne, hipEventDisableTiming);
+          if (e == hipSuccess) c->ev_chunk.push_back(ne);
+        }
+        if (e == hipSuccess && rc == 0) e = hipEventRecord(c->ev_chunk[(size_t)k], c->prep_stream);
+        if (e == hipSuccess && rc == 0) c->chunk_col_end.push_back(c0 + nc);
+      } else {
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+        if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
+      }
     }
+    if (pipelined && (e != hipSuccess || rc)) (void)hipStreamSynchronize(c->prep_stream);
     if (registered && deferred_unregister && e == hipSuccess && rc == 0) {
       // the caller goes on with host work while the copies run, and ends the registration itself
       // (finish_upload) once it has waited for them
@@ -851,6 +911,146 @@ void prebuild_units(icikt_ctx* c) {
     build_units(c, pl.np);
     c->units_dirty = true;
   }
+}
+
+// The host entries' H2D + pre-pass + pair kernel.  A matrix of several 8 MB chunks is PIPELINED: all copies and all
+// pre-pass launches are enqueued at once (copy stream -> pre-pass stream, an event per chunk); meanwhile the host
+// builds the task list, orders it by the chunk in which a task's LAST column arrives, and enqueues one pair-kernel
+// launch per chunk behind that chunk's pre-pass event.  The pairs among the columns that have arrived are counted
+// while the rest of the matrix still crosses PCIe: the available work grows with the square of the arrived columns,
+// so after the first millisecond of a c4-sized call the GPU never waits for the link again.
+int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags,
+                         const void** deferred_unregister) {
+  const size_t col_bytes = (size_t)n_feat * sizeof(double);
+  const size_t span = (n_samp > 0 && n_feat > 0) ? ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double) : 0;
+  const bool can = !c->pv.wide && n_feat > 0 && c->n_pairs > 0 && c->h2d_mode != 3;
+  const bool want = c->pipe_mode < 0 ? (span >= ((size_t)24 << 20)) : (c->pipe_mode == 1 && (size_t)n_samp * col_bytes > ((size_t)8 << 20));
+  if (!(can && want)) {
+    int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags, deferred_unregister, false);
+    if (rc) return rc;
+    c->prepared = true;
+    prebuild_units(c);   // host work under the copies; icikt_run_dev uploads the list
+    return ICIKT_SUCCESS;   // (the caller's icikt_run_dev runs the pair kernel)
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true);
+  if (rc) return rc;
+  c->prepared = true;
+  const double t_enq = ms_since();
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  const size_t nchunks = c->chunk_col_end.size();
+  const bool all_combn = c->combn_S == n_samp && c->combn_begin == 0 && c->combn_end == n_samp * (n_samp - 1) / 2;
+  double t_built = 0, t_up = 0;
+  if (all_combn) {
+    // All pairs of the upper triangle: a chunk's tasks are arithmetic.  They are written chunk by chunk straight into a
+    // pinned buffer, copied asynchronously and launched -- the first launch is enqueued a fraction of a millisecond into
+    // the call, no host copy of the pair list is ever made.  Order inside a chunk: gathered block, then streamed
+    // column (the order build_units gives: a block's rec table stays in cache); a task is the two pairs (2a, j),
+    // (2a + 1, j) that share their streamed column j, the pair (2a, 2a + 1) runs alone.
+    const int64_t S = n_samp;
+    auto pidx = [S](int64_t i, int64_t j) { return (int32_t)(i * (2 * S - i - 1) / 2 + (j - i - 1)); };
+    const size_t cap_tasks = (size_t)c->n_pairs + (size_t)S + 8;
+    HIPCHK(c, c->d_unit_start.reserve(cap_tasks * 2));
+    if (c->pinned_tasks_bytes < cap_tasks * 2 * sizeof(int32_t)) {
+      if (c->pinned_tasks) (void)hipHostFree(c->pinned_tasks);
+      c->pinned_tasks = nullptr; c->pinned_tasks_bytes = 0;
+      HIPCHK(c, hipHostMalloc(&c->pinned_tasks, cap_tasks * 2 * sizeof(int32_t), hipHostMallocDefault));
+      c->pinned_tasks_bytes = cap_tasks * 2 * sizeof(int32_t);
+    }
+    int32_t* u = static_cast<int32_t*>(c->pinned_tasks);
+    size_t nt = 0;
+    rc = timer_begin(c, ICIKT_K_PAIRS, flags);
+    int64_t cb = 0;
+    for (size_t q = 0; q < nchunks && rc == 0; ++q) {
+      const int64_t ce = c->chunk_col_end[q];
+      const size_t first = nt;
+      if (pl.np == 2) {
+        for (int64_t a2 = 0; a2 < ce; a2 += 2) {          // gathered block: columns a2, a2 + 1
+          const int64_t c1 = a2 + 1;
+          for (int64_t j = std::max(cb, a2 + 1); j < ce; ++j) {
+            if (j == c1) { u[2 * nt] = pidx(a2, c1); u[2 * nt + 1] = -1; }
+            else { u[2 * nt] = pidx(a2, j); u[2 * nt + 1] = pidx(c1, j); }
+            ++nt;
+          }
+        }
+      } else {
+        for (int64_t i = 0; i < ce; ++i)
+          for (int64_t j = std::max(cb, i + 1); j < ce; ++j) { u[2 * nt] = pidx(i, j); u[2 * nt + 1] = -1; ++nt; }
+      }
+      cb = ce;
+      const size_t cnt = nt - first;
+      if (cnt == 0) continue;
+      hipError_t e = hipMemcpyAsync(c->d_unit_start.p + 2 * first, u + 2 * first, cnt * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_chunk[q], 0);
+      if (e != hipSuccess) { rc = fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e)); break; }
+      rc = launch_pair_tasks(c, pl, (int)first, (int)cnt);
+    }
+    c->n_units = (int)nt;
+    c->wpb = 0;               // (h_units does not hold this list: a later device-resident run rebuilds it)
+    c->units_dirty = true;
+    t_built = t_up = ms_since();
+  } else {
+  build_units(c, pl.np);
+  // tasks by the chunk of their last column (a stable counting sort: inside a chunk the cache-friendly order stays)
+  const int T = c->n_units;
+  std::vector<int> first(nchunks + 1, 0);
+  {
+    std::vector<int32_t> col_chunk((size_t)n_samp, 0);
+    size_t k = 0;
+    for (int64_t col = 0; col < n_samp; ++col) {
+      while (k + 1 < nchunks && col >= c->chunk_col_end[k]) ++k;
+      col_chunk[(size_t)col] = (int32_t)k;
+    }
+    std::vector<int32_t> tchunk((size_t)T);
+    ensure_host_pairs(c);
+    const int32_t* pi = c->h_pi.data();
+    const int32_t* pj = c->h_pj.data();
+    for (int t = 0; t < T; ++t) {
+      const int32_t p0 = c->h_units[2 * (size_t)t], p1 = c->h_units[2 * (size_t)t + 1];
+      int32_t col = std::max(pi[p0], pj[p0]);
+      if (p1 >= 0) col = std::max(col, std::max(pi[p1], pj[p1]));
+      tchunk[(size_t)t] = col_chunk[(size_t)col];
+      first[(size_t)tchunk[(size_t)t] + 1] += 1;
+    }
+    for (size_t q = 0; q < nchunks; ++q) first[q + 1] += first[q];
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    std::vector<int32_t> sorted((size_t)T * 2);
+    for (int t = 0; t < T; ++t) {
+      const int d = fill[(size_t)tchunk[(size_t)t]]++;
+      sorted[2 * (size_t)d] = c->h_units[2 * (size_t)t];
+      sorted[2 * (size_t)d + 1] = c->h_units[2 * (size_t)t + 1];
+    }
+    c->h_units.swap(sorted);
+  }
+  t_built = ms_since();
+  rc = upload_units(c);
+  if (rc) { (void)hipStreamSynchronize(c->prep_stream); return rc; }
+  c->units_dirty = false;
+  t_up = ms_since();
+  rc = timer_begin(c, ICIKT_K_PAIRS, flags);
+  for (size_t q = 0; q < nchunks && rc == 0; ++q) {
+    const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_chunk[q], 0);
+    if (e != hipSuccess) { rc = fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e)); break; }
+    rc = launch_pair_tasks(c, pl, first[q], first[q + 1] - first[q]);
+  }
+  }
+  if (rc) { (void)hipStreamSynchronize(c->prep_stream); return rc; }
+  rc = timer_end(c, ICIKT_K_PAIRS, flags);
+  if (rc) return rc;
+  c->raw_valid = true;
+  if (c->plan_ov.verbose) {
+    const double t_launched = ms_since();
+    (void)hipStreamSynchronize(c->copy_stream);
+    const double t_copied = ms_since();
+    (void)hipStreamSynchronize(c->prep_stream);
+    const double t_prepped = ms_since();
+    (void)hipStreamSynchronize(c->stream);
+    fprintf(stderr, "[icikt] pipelined: %zu chunks; enqueued copies + pre-pass %.2f ms, tasks built %.2f, uploaded %.2f, pair launches "
+                    "enqueued %.2f, copies done %.2f, pre-pass done %.2f, pairs done %.2f ms\n", nchunks, t_enq, t_built, t_up,
+            t_launched, t_copied, t_prepped, ms_since());
+  }
+  return ICIKT_SUCCESS;
 }
 
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -952,8 +1152,9 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
   // crosses PCIe (it used to wait for the copies first and build the list afterwards, with the GPU idle: 1.2 ms of
   // 14.3 on c4), and ends the page-locking of the caller's matrix after the final synchronisation.
   const void* registered_src = nullptr;
-  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags, &registered_src);
+  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags, &registered_src);
   auto finish_upload = [&]() {
+    (void)hipStreamSynchronize(c->prep_stream);
     if (registered_src) {
       (void)hipStreamSynchronize(c->copy_stream);
       (void)hipHostUnregister(const_cast<void*>(registered_src));
@@ -961,7 +1162,6 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
     }
   };
   if (rc) { finish_upload(); return rc; }
-  c->prepared = true;
   const int64_t P = c->n_pairs;
   if (P == 0) {
     const hipError_t e0 = hipStreamSynchronize(c->stream);
@@ -969,13 +1169,13 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
     if (e0 != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pairs: ") + hipGetErrorString(e0));
     return ICIKT_SUCCESS;
   }
-  icikt::host::prebuild_units(c);   // host work under the copies; icikt_run_dev uploads the list
   auto body = [&]() -> int {
     HIPCHK(c, c->d_out4.reserve((size_t)P * 4));
     if (counts) HIPCHK(c, c->d_counts.reserve((size_t)P * ICIKT_CNT_FIELDS));
     if (reasons) HIPCHK(c, c->d_reasons.reserve((size_t)P));
-    int r = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, counts ? c->d_counts.p : nullptr,
-                          reasons ? c->d_reasons.p : nullptr);
+    // (pipelined: the pair kernel has been enqueued chunk by chunk already -- raw_valid -- and this is the epilogue alone)
+    int r = icikt_run_dev(c, perspective, alternative, continuity, flags | (c->raw_valid ? ICIKT_FLAG_REUSE_COUNTS : 0u),
+                          c->d_out4.p, counts ? c->d_counts.p : nullptr, reasons ? c->d_reasons.p : nullptr);
     if (r) return r;
     r = icikt::host::download(c, out4, c->d_out4.p, (size_t)P * 4 * sizeof(double));
     if (!r && counts) r = icikt::host::download(c, counts, c->d_counts.p, (size_t)P * ICIKT_CNT_FIELDS * sizeof(int64_t));
@@ -1064,10 +1264,11 @@ int icikt_matrix_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sa
   const void* registered_src = nullptr;
   c->k0_mask = &ms;
   c->k0_keep = keep_bytes ? c->d_keep.p : nullptr;
-  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags, &registered_src);
+  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags, &registered_src);
   c->k0_mask = nullptr;
   c->k0_keep = nullptr;
   auto finish_upload = [&]() {
+    (void)hipStreamSynchronize(c->prep_stream);
     if (registered_src) {
       (void)hipStreamSynchronize(c->copy_stream);
       (void)hipHostUnregister(const_cast<void*>(registered_src));
@@ -1075,11 +1276,10 @@ int icikt_matrix_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sa
     }
   };
   if (rc) { finish_upload(); return rc; }
-  c->prepared = true;
-  icikt::host::prebuild_units(c);
   unsigned long long red[8] = {};
   auto body = [&]() -> int {
-    int r = icikt_run_dev(c, perspective, alternative, continuity, flags, c->d_out4.p, nullptr, c->d_reasons.p);
+    int r = icikt_run_dev(c, perspective, alternative, continuity, flags | (c->raw_valid ? ICIKT_FLAG_REUSE_COUNTS : 0u),
+                          c->d_out4.p, nullptr, c->d_reasons.p);
     if (r) return r;
     HIPCHK(c, icikt::launch_out_stats(c->pv, c->d_out4.p, c->d_reasons.p, (int64_t)P, nullptr, c->d_red.p, c->stream));
     HIPCHK(c, icikt::launch_assemble(c->pv, c->d_out4.p, c->d_pi.p, c->d_pj.p, (int64_t)P, nullptr, c->d_red.p,
@@ -1241,7 +1441,7 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   if (!c) return ICIKT_E_INVALID;
   icikt_ctx::PlanOverride ov;
-  int h2d = -1;
+  int h2d = -1, pipe = -1;
   bool regfail = false;
   std::string sp = spec ? spec : "";
   size_t pos = 0;
@@ -1264,6 +1464,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());
     else if (key == "regfail") regfail = (val[0] == '1');
+    else if (key == "pipe") pipe = (val[0] == '1') ? 1 : 0;
     else if (key == "h2d") h2d = (val == "register") ? 1 : (val == "stage") ? 2 : -2;
     else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
     if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be register or stage");
@@ -1271,6 +1472,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   c->plan_ov = ov;
   c->h2d_mode = h2d;
   c->force_reg_fail = regfail;
+  c->pipe_mode = pipe;
   c->raw_valid = false;
   c->wpb = 0;  // tasks are rebuilt for the new plan
   return ICIKT_SUCCESS;

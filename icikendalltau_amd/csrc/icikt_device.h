@@ -172,6 +172,8 @@ hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32
                               int64_t* missing, hipStream_t s);
 hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,
                              int64_t npairs, double* dXp, hipStream_t s);
+// pi / pj of pairs [begin, begin + count) of combn(S, 2) order, computed on the device
+hipError_t launch_fill_combn(int32_t* pi, int32_t* pj, int64_t S, int64_t begin, int64_t count, hipStream_t s);
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t s);
 hipError_t read_step_stats(unsigned long long* out24, int reset);
 

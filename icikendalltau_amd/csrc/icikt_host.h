@@ -65,6 +65,12 @@ struct icikt_ctx {
   DevBuf<uint32_t> d_pend_pre;
   DevBuf<int> d_task_ctr;  // persistent pair kernel: one task counter per XCD group, zeroed before every launch
   std::vector<int32_t> h_pi, h_pj, h_units;
+  // a combn range [combn_begin, combn_end) of combn(combn_S, 2) set by icikt_set_pairs_combn: the device arrays are
+  // filled by a kernel at once, the host copies (h_pi / h_pj: only the host-built task lists read them) on demand
+  int64_t combn_S = -1, combn_begin = 0, combn_end = 0;
+  bool h_pairs_valid = false;
+  void* pinned_tasks = nullptr;   // pinned staging of the task list the pipelined host path generates chunk by chunk
+  size_t pinned_tasks_bytes = 0;
   bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
   // result buffers of the caller that were page-locked for a D2H copy (icikt::host::download): released by
   // finish_downloads() once the stream has been synchronised
@@ -76,6 +82,13 @@ struct icikt_ctx {
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
   hipStream_t copy_stream = nullptr;
+  // the pipelined host path (icikt_pairs_f64 / icikt_matrix_f64 on a matrix of several chunks): the pre-pass of chunk
+  // k runs on its own stream as soon as the chunk has arrived, and the pair kernel -- one launch per chunk, over the
+  // tasks whose LAST column lies in it -- follows on the context's stream while later chunks still cross PCIe
+  hipStream_t prep_stream = nullptr;
+  std::vector<hipEvent_t> ev_chunk;        // pre-pass of chunk k done
+  std::vector<int64_t> chunk_col_end;      // columns [.., chunk_col_end[k]) have arrived with chunk k (this call)
+  int pipe_mode = -1;                      // -1: the library's choice; 0 / 1: off / on whenever possible (debug plan)
   hipEvent_t ev_copy[4] = {};
   void* pinned = nullptr;   // pinned staging area (h2d mode "stage", and every transfer whose page-locking was refused)
   size_t pinned_bytes = 0;
@@ -131,13 +144,20 @@ int use_device(icikt_ctx* c);
 // sort_cols columns at a time) and set c->pv.  No kernel is launched.
 int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_cols, int64_t sort_cols);
 // K0 over columns [col_begin, col_end) of the device matrix dX (leading dimension ld) on c->stream.
-int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end);
+int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end, hipStream_t stream = nullptr);
 // Host matrix -> device (columns [col_begin, col_end) only) overlapped with K0 by column chunks; the device copy
 // keeps the full n_feat x n_samp layout (leading dimension n_feat) in c->d_X.  prepare_alloc() must have run.
 // deferred_unregister (optional): when the source was page-locked for the call, do not wait for the copies; the
 // caller synchronises c->copy_stream and calls hipHostUnregister(*deferred_unregister) itself.
+// pipelined: the pre-pass launches go to c->prep_stream, one event per chunk in c->ev_chunk / c->chunk_col_end; the
+// caller makes c->stream wait for them (per chunk, or for the last one).
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr);
+                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr, bool pipelined = false);
+// H2D + pre-pass + pair kernel of the host entries: pipelined by chunks when the matrix has several, else in sequence.
+// Leaves the pair kernel's counts in c->d_raw (raw_valid): the caller runs the epilogue (icikt_run_dev with
+// ICIKT_FLAG_REUSE_COUNTS).
+int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags,
+                         const void** deferred_unregister);
 // global_na values (NaN = NA, +-Inf = Inf, anything else compared with ==) -> the pre-pass's exclusion rule
 int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt::MaskSpec* ms);
 // Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).

@@ -3089,6 +3089,15 @@ k_out_stats(PrepView pv, const double* __restrict__ out4, const int32_t* __restr
   if (threadIdx.x >= 1 && threadIdx.x <= 5 && sh[threadIdx.x]) atomicAdd(&red[threadIdx.x], sh[threadIdx.x]);
 }
 
+// pair p of combn(S, 2): row i holds the pairs (i, i+1 .. S-1) and starts at offset i (2S - i - 1) / 2
+__device__ __forceinline__ void combn_pair(int64_t S, int64_t t, int64_t& i, int64_t& j) {
+  const double b = 2.0 * (double)S - 1.0;
+  i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+  i = max((int64_t)0, min(i, S - 2));
+  while (i > 0 && i * (2 * S - i - 1) / 2 > t) --i;
+  while ((i + 1) * (2 * S - i - 2) / 2 <= t) ++i;
+  j = i + 1 + (t - i * (2 * S - i - 1) / 2);
+}
 // out5: five S x S matrices, zero-filled by the caller; a thread per pair writes both triangles, then a thread per
 // sample the diagonal (the diagonal rows come AFTER the pairs in the reference: they win over a self pair of the list)
 __global__ void __launch_bounds__(256)
@@ -3102,13 +3111,7 @@ k_assemble(PrepView pv, const double* __restrict__ out4, const int32_t* __restri
     if (pi) {
       i = pi[t]; j = pj[t];
     } else {
-      // pair t of combn(S, 2): row i holds the pairs (i, i+1 .. S-1) and starts at offset i (2S - i - 1) / 2
-      const double b = 2.0 * (double)S - 1.0;
-      i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
-      i = max((int64_t)0, min(i, S - 2));
-      while (i > 0 && i * (2 * S - i - 1) / 2 > t) --i;
-      while ((i + 1) * (2 * S - i - 2) / 2 <= t) ++i;
-      j = i + 1 + (t - i * (2 * S - i - 1) / 2);
+      combn_pair(S, t, i, j);
     }
     const double raw = out4[4 * t + 0], pval = out4[4 * t + 1], tmax = out4[4 * t + 2], comp = out4[4 * t + 3];
     // max(numeric(0), na.rm = TRUE) is -Inf in R
@@ -3136,6 +3139,22 @@ k_assemble_diag(PrepView pv, const int64_t* __restrict__ n_good, const unsigned 
   out5[2 * SS + a] = 0.0;
   out5[3 * SS + a] = 1.0;
   out5[4 * SS + a] = g / (double)pv.n;                       // frac_complete = n_good / nrow
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_combn(int32_t* __restrict__ pi, int32_t* __restrict__ pj, int64_t S, int64_t begin, int64_t count) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  int64_t i, j;
+  combn_pair(S, begin + t, i, j);
+  pi[t] = (int32_t)i;
+  pj[t] = (int32_t)j;
+}
+hipError_t launch_fill_combn(int32_t* pi, int32_t* pj, int64_t S, int64_t begin, int64_t count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_fill_combn, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, pi, pj, S, begin, count);
+  return hipGetLastError();
 }
 
 hipError_t launch_out_stats(const PrepView& pv, const double* out4, const int32_t* reasons, int64_t n_pairs,

@@ -8,6 +8,9 @@ import pytest
 os.environ.setdefault("AMD_LOG_LEVEL", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("ICIKT_SEGV_BT"):   # development aid: native backtrace on SIGSEGV (tools/dbg/segv_bt.c)
+    import ctypes
+    ctypes.CDLL(os.environ["ICIKT_SEGV_BT"])
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

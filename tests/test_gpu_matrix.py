@@ -216,3 +216,41 @@ def test_transfers_when_page_locking_is_refused(plan_ctx):
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
     finally:
         m.close()
+
+
+def test_pipelined_host_path(plan_ctx):
+    """The host entries pipeline a matrix of several 8 MB chunks: the pre-pass of a chunk runs as it arrives and the pair
+    kernel is launched once per chunk, over the tasks whose last column lies in it (icikt::host::upload_prepare_pairs).
+    Same bytes out as the one-launch path: all pairs, an unsorted explicit list with both orientations and self pairs,
+    the matrix entry, with the staged and the bounced transfers, and on long columns (persistent pair kernel)."""
+    rng = np.random.default_rng(12)
+    n, S = 9000, 300                                     # three chunks of 116 columns
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    X[rng.random((n, S)) < 0.05] = np.nan
+    X[:, 7] = np.round(X[:, 7] * 50)
+    iu, ju = np.triu_indices(S, k=0)
+    sel = rng.permutation(len(iu))[:5000]
+    qi = np.where(rng.random(len(sel)) < 0.5, iu[sel], ju[sel]).astype(np.int32)
+    qj = np.where(qi == iu[sel], ju[sel], iu[sel]).astype(np.int32)
+    plan_ctx.debug_set_plan({"pipe": 0})
+    ref_all = plan_ctx.pairs(X, perspective="global")
+    ref_lst = plan_ctx.pairs(X, qi, qj, "local")
+    ref_mat = plan_ctx.matrix(X, (float("nan"),))
+    for plan in ({"pipe": 1}, {"pipe": 1, "h2d": "stage"}, {"pipe": 1, "regfail": 1}, {"pipe": 1, "np": 1}):
+        plan_ctx.debug_set_plan(plan)
+        got = plan_ctx.pairs(X, perspective="global")
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref_all, got)), plan
+        got = plan_ctx.pairs(X, qi, qj, "local")
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref_lst, got)), plan
+        got = plan_ctx.matrix(X, (float("nan"),))
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref_mat, got)), plan
+    # long columns: the persistent kernel (pend in global memory) launched once per chunk
+    n2, S2 = 40000, 60                                   # 19 MB in chunks of 26 columns
+    X2 = np.asfortranarray(rng.standard_normal((n2, S2)))
+    X2[rng.random((n2, S2)) < 0.03] = np.nan
+    X2[:, 3] = np.round(X2[:, 3] * 20)
+    plan_ctx.debug_set_plan({"pipe": 0})
+    ref = plan_ctx.pairs(X2, perspective="global")
+    plan_ctx.debug_set_plan({"pipe": 1})
+    got = plan_ctx.pairs(X2, perspective="global")
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))

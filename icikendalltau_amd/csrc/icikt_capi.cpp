@@ -138,7 +138,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * (8 + 8 + 2) + icikt::k1_half_pre(pl.half_items));  // seen, pend, ppre + prefix slots
+  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items));  // seen + prefix slots (no pend)
   else  // one pair per wave: seen [, pend], the two-level counts [, ppre]
     pl.perpair_bytes = (int)((size_t)pl.stride * (pl.pend_global ? 8 : (8 + 8 + 2)) + icikt::K1_TL_BYTES);
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
@@ -476,7 +476,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     HIPCHK(c, c->tmask.reserve(1));
   } else {
     HIPCHK(c, c->order.reserve(S * pv.n_ord));
-    HIPCHK(c, c->hirow.reserve(S * pv.n_pad));
+    HIPCHK(c, c->hirow.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // interleaved like rec: [S/2 blocks][n_pad rows][2 columns]
     HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
     HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
     // the tie program serves the half-wave kernels only (n <= 18 336); longer columns classify their steps in the pair kernel

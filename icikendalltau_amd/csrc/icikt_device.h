@@ -74,7 +74,8 @@ struct PrepView {
   uint16_t* order;   // [S][n_ord]  row at processing position k (descending value)
   uint32_t* rec;     // [S/2][n_pad][2]  per row: q | lo << 16  (ascending stable position, group start),
                      // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
-  uint16_t* hirow;   // [S][n_pad]  per row: last ascending position of its tie group
+  uint16_t* hirow;   // [S/2][n_pad][2]  per row: last ascending position of its tie group, the columns 2a and 2a+1
+                     // interleaved like rec (a half-wave GROUP step reads both pairs' ends with one 4-byte gather per row)
   // per column, stride Wp
   // per column one record of mstride = 3 * Wp + 9 words (one array: one collective moves it between ranks):
   //   [Wp] mask      missing rows

@@ -405,7 +405,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   unsigned long long* gflag = pv.col_gflag(c);
   uint16_t* order = WIDE ? nullptr : pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
-  uint16_t* hirow = WIDE ? nullptr : pv.hirow + (int64_t)c * pv.n_pad;
+  uint16_t* hirow = WIDE ? nullptr : pv.hirow + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);            // [block][row][2]: stride 2
   uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
   uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
@@ -620,7 +620,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
         hi32[row] = (uint32_t)hi; q32[row] = (uint32_t)k; lo32[row] = (uint32_t)lo;
         order32[n - 1 - k] = row;
       } else {
-      hirow[row] = (uint16_t)hi;
+      hirow[2 * row] = (uint16_t)hi;
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   const unsigned long long* gf = pv.col_gflag(c);
   const uint16_t* ord = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
-  uint16_t* hirow = pv.hirow + (int64_t)c * pv.n_pad;
+  uint16_t* hirow = pv.hirow + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
   uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
 
   // starts of groups of size >= 2: a start whose successor position exists and is not a start
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     const uint32_t lo = (uint32_t)(n - 1 - e), hi = (uint32_t)(n - 1 - s);
     const uint32_t rv = (uint32_t)(n - 1 - k) | (lo << 16);
     if (staged) { rec_s[row] = rv; hi_s[row] = (uint16_t)hi; }
-    else { rec[2 * row] = rv; hirow[row] = (uint16_t)hi; }
+    else { rec[2 * row] = rv; hirow[2 * row] = (uint16_t)hi; }
     if (k == s && e > s) {
       // tgroups is ascending in lo: groups that start after me (descending) come first
       const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     __syncthreads();
     for (int r = (int)threadIdx.x; r < n; r += 64 * KX_WAVES) {
       rec[2 * r] = rec_s[r];
-      hirow[r] = hi_s[r];
+      hirow[2 * r] = hi_s[r];
     }
   }
   if (pv.tp_stride > 0) {   // (half-wave kernels only: W <= 287 words)
@@ -1548,7 +1548,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
       }
     } else if (olane) {
       // joint ties with the group's rows of earlier steps
-      ph = (uint32_t)hiG[row] + 1u;
+      ph = (uint32_t)hiG[2u * row] + 1u;
       ebefore = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
       S.tie += ebefore;
     } else if (valid) {
@@ -1846,7 +1846,7 @@ __device__ unsigned long long g_step_stats[24];
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, bool PG, int HI>
-__global__ void __launch_bounds__(512, (HI > 8 ? 3 : HI > 5 ? 4 : 6))  // 6 waves per SIMD (<= 80 VGPRs); HI > 5 / > 8: the LDS state allows 4 / 3
+__global__ void __launch_bounds__(512, 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
          int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
@@ -1930,18 +1930,21 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   uint32_t cb[NP], gg[NP];
   bool g_oddtie = false;       // the (first) gathered column has a tie group that starts at an odd position
   const uint32_t* rec_blk;
+  const uint32_t* hi_blk;   // the block's tie-group ends: hi of column 2a | hi of column 2a + 1 << 16 per row
   {
     const int g0 = __builtin_amdgcn_readfirstlane(pi[pidx[0]]);
     rec_blk = pv.rec + ((int64_t)(g0 >> 1) * pv.n_pad) * 2;
+    hi_blk = reinterpret_cast<const uint32_t*>(pv.hirow + ((int64_t)(g0 >> 1) * pv.n_pad) * 2);
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int gcol = __builtin_amdgcn_readfirstlane(pi[pidx[k]]);
     comp[k] = (uint32_t)(gcol & 1);
-    hiG[k] = pv.hirow + (int64_t)gcol * pv.n_pad;
+    hiG[k] = pv.hirow + ((int64_t)(gcol >> 1) * pv.n_pad) * 2 + (gcol & 1);   // interleaved like rec: index 2 * row
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
-    ntgB[k] = (!(opts & 2) && ntg_raw <= tg_max) ? ntg_raw : -1;
+    // (half-wave kernels count a closing group's joint ties with at most four listed groups per lane)
+    ntgB[k] = (!(opts & 2) && ntg_raw <= (half_mode ? min(tg_max, 128) : tg_max)) ? ntg_raw : -1;
     if (k == 0) g_oddtie = (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
@@ -1967,12 +1970,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
       for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
     } else {
-      // half-wave kernels: seen | pend | prefix slots of seen (32 lanes x 16 B) | ppre
-      Pg[k].bits = S[k].L.seen + Wp4;
-      S[k].L.spre = reinterpret_cast<uint16_t*>(Pg[k].bits + Wp4);
-      Pg[k].pre16 = S[k].L.spre + k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2;
-      Pg[k].pre = nullptr;
-      for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; Pg[k].pre16[w] = 0; }
+      // half-wave kernels: seen | prefix slots of seen (32 lanes x 16 B).  No `pend`: the rows of a tie group of the
+      // streamed column are queried first and inserted when the group closes (GROUP steps below)
+      S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
+      Pg[k].bits = nullptr; Pg[k].pre16 = nullptr; Pg[k].pre = nullptr;
+      for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
@@ -2039,6 +2041,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // (their counts and subtrahends go into dis_half / dis_half_neg: the same per-lane convention, two registers fewer)
   uint32_t seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
   bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
+  bool grp_open = false;   // half-wave kernels: likewise; grp_start = first position of the open group
+  int grp_start = 0, grp_entries = 0;   // grp_entries: steps of the open group so far
+  uint32_t sv_k0 = 0, sv_k1 = 0, sv_h = 0;   // the open group's first step: its rows' values, still in registers when the second step closes it
   int pos = 0;
   ICIKT_ST_MARK(6, 0)
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
@@ -2348,6 +2353,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       }
     }
     const int pos_next = pos + nact;
+    const int pos_step = pos;
     const int kpos = pos + (int)lane;
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
@@ -2379,19 +2385,17 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       rk_ok = true;
       pre_n0 = n0_next;
     }
-    if (fast_ties) {
+    if (fast_ties && !half_mode) {
       // a GROUP step needs the last position of every row's tie group in the gathered column -> gathered one step
-      // ahead, beside the rec values (half-wave kernels: rows 0..31 for both halves)
+      // ahead, beside the rec values
       hi_ok = kind == 2;   // after a GROUP step the next one is most likely a GROUP step too (MIXED steps need no ends)
-      if (hi_ok) {
-        // (lane_t: the per-lane choices of a tie step are made HERE, from a copy of the lane number the optimiser
-        //  cannot see through -- hoisted out of the loop they occupy registers across the hot loop and spill)
-        uint32_t lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        const uint32_t rowN = half_mode ? (uint32_t)__builtin_amdgcn_permlane32_swap(r0, r0, false, false)[0] : r0;
-        const uint16_t* hb = (half_mode && lane_t >= 32u) ? hiG[NP - 1] : hiG[0];
-        hi_pre = gload_u16(hb, rowN);
-      }
+      if (hi_ok) hi_pre = gload_u16(hiG[0], 2u * r0);
+    }
+    if constexpr (half_mode) {
+      // the next step is a GROUP step and a pair counts its joint ties row by row: the ends of the rows' tie groups
+      // in the gathered column, one step ahead (lane (h, l): rows l and l + 32 of the next step, column of pair h)
+      hi_ok = tprog_kind(e_next) == TPROG_KIND_GROUP && ((ntgB[0] < 0) || (ntgB[NP - 1] < 0));
+      if (hi_ok) hi_pre = gload_u32(hi_blk, r0);   // (lane = row: both columns of the block in one entry)
     }
     uint32_t q[NP], lo[NP];
 
@@ -2401,82 +2405,188 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       continue;
     }
 
-    if constexpr (fast_ties) {
-      // ---- fast tie step: both pairs of a half-wave kernel advance together, each on its 32 lanes -------------
-      constexpr int SW = half_mode ? 32 : 64;
-      uint32_t rkS = rk[0], rowS = row;
-      SegState st;
-      const uint16_t* hbase = hiG[0];
+    if constexpr (half_mode) {
+      // ---- tie step of a half-wave kernel: both pairs advance together, each on its 32 lanes ---------------------
       uint32_t lane_t = lane;
-      asm volatile("" : "+v"(lane_t));   // see above: keeps the per-lane choices below inside the tie step
-      if (half_mode) {
-        if (kind != 1) {
-          rkS = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[0];  // [pair 0 | pair 1] of rows 0..31
-          rowS = __builtin_amdgcn_permlane32_swap(row, row, false, false)[0];           // rows 0..31 in both halves
+      asm volatile("" : "+v"(lane_t));   // keeps the per-lane choices below inside the tie step (see layout_rows)
+      if (kind == 1) {
+        // MIXED: the hot step on the step's rows (lanes past them: a position in the guard word, lo = 0), then the
+        // pairs inside the groups
+        const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
+        uint32_t rkm[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) rkm[k] = vrow ? rk[k] : ((uint32_t)W << 6);
+        // row layout -> (pair, row of the sub-step): a lane's two rows are those of lanes l and l + 32
+        {
+          const auto m1 = __builtin_amdgcn_permlane32_swap(tmx.x, tmx.x, false, false);
+          const auto m2 = __builtin_amdgcn_permlane32_swap(tmx.y, tmx.y, false, false);
+          mix_sg1 = m1[0] | m1[1];
+          mix_sg2 = m2[0] | m2[1];
         }
-        const bool hi = lane_t >= 32u;
-        st.seen = (lds_u64p)(hi ? S[NP - 1].L.seen : S[0].L.seen);
-        st.spre = (lds_u16p)(hi ? S[NP - 1].L.spre : S[0].L.spre);
-        st.pend = (lds_u64p)(hi ? Pg[NP - 1].bits : Pg[0].bits);
-        hbase = hi ? hiG[NP - 1] : hiG[0];
+        hot_step(rkm, std::true_type{});
+        ICIKT_ST_MARK(2, nact)
       } else {
-        st.seen = (lds_u64p)S[0].L.seen;
-        st.spre = (lds_u16p)S[0].L.spre;
-        st.pend = (lds_u64p)Pg[0].bits;
+        // GROUP: up to 64 rows of ONE tie group of the streamed column (a piece of it, or all of it).  Rows of one
+        // group are never discordant with each other, so a group needs no all-pairs count at all -- and no second
+        // bitset: `seen` does not change while the group's rows are QUERIED (phase A, step by step as the program
+        // delivers them), and when the group closes its rows are INSERTED together (phase B: from registers when the
+        // group is one step, else by streaming its positions a second time) and the prefix is rebuilt once.  The
+        // group's joint ties, sum over the gathered column's tie groups g of C(rows of the group in g, 2), come from
+        // range counts of `seen` before and after the insertion:
+        //   list mode (the gathered column has <= 128 tie groups): per listed group, count after - count before;
+        //   row mode: per ROW of the group the rows in its cell [lo, hi], after - before - 1 (every pair twice: tie2);
+        //             "before" is taken in phase A, "after" in a third pass over the group's rows (phase C).
+        // A range count is two prefix queries, whatever the width of the range.
+        constexpr int H = (HI > 0 ? HI : 1);
+        const bool hi_half = lane_t >= 32u;
+        const uint32_t l32 = lane_t & 31u;
+        unsigned long long* seenH = hi_half ? S[NP - 1].L.seen : S[0].L.seen;
+        uint16_t* spreH = hi_half ? S[NP - 1].L.spre : S[0].L.spre;
+        const uint32_t* tgH = hi_half ? tgB[NP - 1] : tgB[0];
+        const int ntgH = hi_half ? ntgB[NP - 1] : ntgB[0];
+        const bool compH = (hi_half ? comp[NP - 1] : comp[0]) != 0u;   // the lane's pair reads column 2a + 1 of the block
+        const bool rowmode = ntgH < 0;                              // per lane = per pair
+        const bool any_row = (ntgB[0] < 0) || (ntgB[NP - 1] < 0);   // wave-uniform
+        const int kmax = (max(ntgB[0], ntgB[NP - 1]) + 31) >> 5;    // listed groups per lane (<= 4: tg_max <= 128)
+        const uint32_t GUARD = (uint32_t)W << 6;                    // q = 64 W, lo = 0: queries 0, inserts into the guard word
+        auto Q = [&](uint32_t p) -> uint32_t { return prefix_query_half<H>(seenH, spreH, p); };
+        auto range = [&](uint32_t r) -> uint32_t { return Q((r >> 16) + 1u) - Q(r & 0xFFFFu); };   // r = lo | hi << 16
+        // rows of the lane's pair in the cell [lo, hi] of a row (k = q | lo << 16), the row itself excluded
+        auto cell_others = [&](uint32_t k, uint32_t h) -> uint32_t { return Q(h + 1u) - Q(k >> 16) - 1u; };
+        // lane (h, l): rows l and l + 32 of a 64-row chunk, for pair h (a, b: the values of pair 0 / pair 1 by row)
+        auto two_rows = [&](uint32_t a, uint32_t b, int cnt, uint32_t& x0, uint32_t& x1, bool& v0, bool& v1) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+          v0 = (int)l32 < cnt; v1 = (int)l32 + 32 < cnt;
+          x0 = sw[0]; x1 = sw[1];
+        };
+        auto two_his = [&](uint32_t hv, uint32_t& x0, uint32_t& x1) {   // hv: the block's hi entry by row
+          const auto sw = __builtin_amdgcn_permlane32_swap(hv, hv, false, false);
+          x0 = compH ? (sw[0] >> 16) : (sw[0] & 0xFFFFu);
+          x1 = compH ? (sw[1] >> 16) : (sw[1] & 0xFFFFu);
+        };
+        if (!grp_open) { grp_start = pos_step; grp_entries = 0; }
+        uint32_t k0, k1;
+        bool v0, v1;
+        two_rows(rk[0], rk[NP - 1], nact, k0, k1, v0, v1);
+        if (!v0) k0 = GUARD;
+        if (!v1) k1 = GUARD;
+        uint32_t h0 = 0u, h1 = 0u;
+        if (any_row) two_his(hi_now_ok ? hi_now : gload_u32(hi_blk, row), h0, h1);
+        // phase A: rows of strictly higher groups below each row's tie group
+        const uint32_t c0 = Q(k0 >> 16), c1 = Q(k1 >> 16);
+        dis_half += c0 + c1;
+        if (any_row) {
+          const uint32_t b0 = (rowmode && v0) ? Q(h0 + 1u) - c0 : 0u;
+          const uint32_t b1 = (rowmode && v1) ? Q(h1 + 1u) - c1 : 0u;
+          seg_tie2 -= b0 + b1;
+        }
+        if (closes) {
+          // the group's rows: this step's alone (kept = 0), this and the previous step's, which are still in
+          // registers (kept = 1), or more: those are streamed again from the group's first position
+          const int kept = grp_entries;
+          const int grp_end = pos;                                  // (pos has moved on to the next step)
+          // list mode: rows of earlier groups inside each listed tie group of the gathered column
+          uint32_t bef[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < kmax) {
+              const int g = (int)l32 + 32 * i;
+              if (g < ntgH) bef[i] = range(tgH[g]);
+            }
+          }
+          wave_lds_fence();
+          // phase B: the group's rows enter `seen`
+          if (kept <= 1) {
+            if (kept == 1) {
+              seen_insert(seenH, sv_k0 & 0xFFFFu);
+              seen_insert(seenH, sv_k1 & 0xFFFFu);
+            }
+            seen_insert(seenH, k0 & 0xFFFFu);
+            seen_insert(seenH, k1 & 0xFFFFu);
+          } else {
+            uint32_t rw = gload_u16(ord, (uint32_t)grp_start + lane);
+            uint2 rv = gload_rec2(rec_blk, rw);
+            uint32_t rw_n = gload_u16(ord, (uint32_t)grp_start + 64u + lane);
+            for (int p = grp_start; p < grp_end; p += 64) {
+              const uint2 rv_n = gload_rec2(rec_blk, rw_n);
+              rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
+              uint32_t a0, a1;
+              bool w0, w1;
+              two_rows(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, grp_end - p, a0, a1, w0, w1);
+              seen_insert(seenH, w0 ? (a0 & 0xFFFFu) : GUARD);
+              seen_insert(seenH, w1 ? (a1 & 0xFFFFu) : GUARD);
+              rv = rv_n;
+            }
+          }
+          wave_lds_fence();
+          rebuild_prefix_half<H>(seenH, spreH, l32);
+          wave_lds_fence();
+          // list mode: C(rows of the group in the listed tie group, 2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < kmax) {
+              const int g = (int)l32 + 32 * i;
+              if (g < ntgH) {
+                const uint32_t c = range(tgH[g]) - bef[i];
+                seg_tie += c * (c - 1u) / 2u;
+              }
+            }
+          }
+          // phase C (row mode): rows of the group in each row's cell, the row itself excluded
+          if (any_row) {
+            if (kept <= 1) {
+              uint32_t e = ((rowmode && v0) ? cell_others(k0, h0) : 0u) + ((rowmode && v1) ? cell_others(k1, h1) : 0u);
+              if (kept == 1 && rowmode) e += cell_others(sv_k0, sv_h & 0xFFFFu) + cell_others(sv_k1, sv_h >> 16);
+              seg_tie2 += e;
+            } else {
+              // (the gathers of the next chunk are in flight while this one is counted)
+              uint32_t rw = gload_u16(ord, (uint32_t)grp_start + lane);
+              uint2 rv = gload_rec2(rec_blk, rw);
+              uint32_t hv = gload_u32(hi_blk, rw);
+              uint32_t rw_n = gload_u16(ord, (uint32_t)grp_start + 64u + lane);
+              for (int p = grp_start; p < grp_end; p += 64) {
+                const uint2 rv_n = gload_rec2(rec_blk, rw_n);
+                const uint32_t hv_n = gload_u32(hi_blk, rw_n);
+                rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
+                uint32_t a0, a1, g0, g1;
+                bool w0, w1;
+                two_rows(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, grp_end - p, a0, a1, w0, w1);
+                two_his(hv, g0, g1);
+                seg_tie2 += ((rowmode && w0) ? cell_others(a0, g0) : 0u) + ((rowmode && w1) ? cell_others(a1, g1) : 0u);
+                rv = rv_n; hv = hv_n;
+              }
+            }
+          }
+          grp_open = false;
+        } else {
+          if (grp_entries == 0) { sv_k0 = k0; sv_k1 = k1; sv_h = h0 | (h1 << 16); }   // (a step that does not close has 64 rows)
+          ++grp_entries;
+          grp_open = true;
+        }
+        ICIKT_ST_MARK(3, nact)
       }
+    } else if constexpr (fast_ties) {
+      // ---- fast tie step of a one-pair kernel with pend in LDS ------------------------------------------------------
+      constexpr int SW = 64;
+      const uint32_t rkS = rk[0], rowS = row;
+      SegState st;
+      st.seen = (lds_u64p)S[0].L.seen;
+      st.spre = (lds_u16p)S[0].L.spre;
+      st.pend = (lds_u64p)Pg[0].bits;
       SegCounts c;
       if (kind == 1) {
-        if constexpr (half_mode) {
-          // the hot step on the step's rows (lanes past them: a position in the guard word, lo = 0), then the pairs
-          // inside the groups
-          const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
-          uint32_t rkm[NP];
-#pragma unroll
-          for (int k = 0; k < NP; ++k) rkm[k] = vrow ? rk[k] : ((uint32_t)W << 6);
-          // row layout -> (pair, row of the sub-step): a lane's two rows are those of lanes l and l + 32
-          {
-            const auto m1 = __builtin_amdgcn_permlane32_swap(tmx.x, tmx.x, false, false);
-            const auto m2 = __builtin_amdgcn_permlane32_swap(tmx.y, tmx.y, false, false);
-            mix_sg1 = m1[0] | m1[1];
-            mix_sg2 = m2[0] | m2[1];
-          }
-          hot_step(rkm, std::true_type{});
-          c.dis = 0; c.neg = 0; c.tie = 0; c.tie2 = 0; c.cfill = 0;   // (counted inside the step)
-        }
-        else c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
+        c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
       } else {
         // last position of the row's tie group in the gathered column
-        const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hbase, rowS);
-        const bool rowmode = ((half_mode && lane_t >= 32u) ? ntgB[NP - 1] : ntgB[0]) < 0;
-        // a half-wave kernel takes up to 64 rows of the group: two 32-row pieces through ONE call site
-        const int npieces = (half_mode && nact > 32) ? 2 : 1;
-        const bool single = closes && !seg_open && npieces == 1;   // the group starts and ends in this step
-        uint32_t rk2 = 0, hi2 = 0;
-        if (npieces == 2) {   // rows 32 .. nact - 1: their values and tie-group ends
-          rk2 = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false)[1];
-          hi2 = gload_u16(hbase, __builtin_amdgcn_permlane32_swap(row, row, false, false)[1]);
-        }
-        for (int pc = 0; pc < npieces; ++pc) {
-          const bool lastp = pc == npieces - 1;
-          const int np_rows = (npieces == 2) ? (pc ? nact - 32 : 32) : nact;
-          c = seg_group_step<SW, HI>(st, np_rows, single, closes && lastp, rowmode, pc ? rk2 : rkS, pc ? hi2 : hiA,
-                                     seg_cfill, IT, magic, lane);
-          if (!lastp) {
-            dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
-            seg_cfill = c.cfill;
-          }
-        }
+        const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hiG[0], 2u * rowS);
+        const bool rowmode = ntgB[0] < 0;
+        const bool single = closes && !seg_open;   // the group starts and ends in this step
+        c = seg_group_step<SW, HI>(st, nact, single, closes, rowmode, rkS, hiA, seg_cfill, IT, magic, lane);
         seg_cfill = c.cfill;
         seg_open = !closes;
         if (closes) {
-          bool any_list = false;
-#pragma unroll
-          for (int k = 0; k < NP; ++k) {   // list mode: joint ties of the closed group from the column's tie-group list
-            if (ntgB[k] >= 0) {
-              any_list = true;
-              if (ntgB[k] > 0) S[k].tie += close_group_ties_lds(Pg[k], tgB[k], ntgB[k], Wp, items, lane);
-            }
-          }
+          const bool any_list = ntgB[0] >= 0;
+          if (ntgB[0] > 0) S[0].tie += close_group_ties_lds(Pg[0], tgB[0], ntgB[0], Wp, items, lane);
           if (!single || any_list) seg_group_close<SW, HI>(st, IT, lane);
         }
       }
@@ -2511,6 +2621,44 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
   for (int k = 0; k < NP; ++k) corr[k] = 0ull;
   if (closed_form) {
+    if constexpr (half_mode) {
+      // Half-wave kernels: every row that is not in `seen` by now belongs to this last group, so the group has
+      // (size of g) - (rows of g in seen) rows in a tie group g of the gathered column: T from one range count per
+      // listed group, and the group's rows only gather and add their lo.
+      uint32_t lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      const bool hi_half = lane_t >= 32u;
+      const uint32_t l32 = lane_t & 31u;
+      constexpr int H = (HI > 0 ? HI : 1);
+      unsigned long long* seenH = hi_half ? S[NP - 1].L.seen : S[0].L.seen;
+      uint16_t* spreH = hi_half ? S[NP - 1].L.spre : S[0].L.spre;
+      const uint32_t* tgH = hi_half ? tgB[NP - 1] : tgB[0];
+      const int ntgH = hi_half ? ntgB[NP - 1] : ntgB[0];
+      uint32_t tl = 0;
+      for (int g = (int)l32; g < ntgH; g += 32) {
+        const uint32_t r = tgH[g];
+        const uint32_t in_seen = prefix_query_half<H>(seenH, spreH, (r >> 16) + 1u) - prefix_query_half<H>(seenH, spreH, r & 0xFFFFu);
+        const uint32_t c = (r >> 16) - (r & 0xFFFFu) + 1u - in_seen;
+        tl += c * (c - 1u) / 2u;
+      }
+      seg_tie += tl;
+      uint32_t row_next = r0;
+      for (int p = last_start; p < n; p += 64) {
+        const int kpos = p + (int)lane;
+        const uint2 rv = gload_rec2(rec_blk, row_next);
+        row_next = gload_u16(ord, (uint32_t)(kpos + 64));
+        if (kpos < n) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) S[k].dis += (comp[k] ? rv.y : rv.x) >> 16;
+        }
+      }
+      const unsigned long long m = (unsigned long long)(n - last_start);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const bool mine = (lane >= 32u) == (k == NP - 1);
+        corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(mine ? tl : 0u);
+      }
+    } else {
     // The group's bitset: pend in LDS where the kernel has one.  With pend in global memory (long columns) the
     // tail uses `seen` instead -- nothing queries it any more -- so that the rows missing in the streamed column
     // cost LDS atomics, not one global atomic each (measured on the full c5 matrix, whose 1 GB of prepared state
@@ -2555,6 +2703,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       S[k].tie += tl;
       const unsigned long long m = (unsigned long long)(n - last_start);
       corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
+    }
     }
     ICIKT_ST_MARK(5, n - last_start)
   }

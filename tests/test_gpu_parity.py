@@ -499,7 +499,7 @@ def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
             return torch.as_tensor(_D(), device="cuda")
 
         alloc = S + (S & 1)
-        derived = {i: view(i, alloc if i == 1 else S) for i in (1, 2, 4)}
+        derived = {i: view(i, alloc if i in (1, 2) else S) for i in (1, 2, 4)}   # rec and hirow interleave column pairs
         want = {i: t.clone() for i, t in derived.items()}
         # tgroups beyond a column's ntg entries and the pad rows of rec / hirow are unspecified: compare what K1 reads
         for t in derived.values():
@@ -511,13 +511,13 @@ def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
         n_pad = arrays[2][1] // 2
         rec_w = want[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
         rec_g = derived[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
-        hi_w = want[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
-        hi_g = derived[2].cpu().numpy().view(np.uint16).reshape(S, n_pad)
+        hi_w = want[2].cpu().numpy().view(np.uint16).reshape(-1, n_pad, 2)
+        hi_g = derived[2].cpu().numpy().view(np.uint16).reshape(-1, n_pad, 2)
         tg_w = want[4].cpu().numpy().view(np.uint32).reshape(S, -1)
         tg_g = derived[4].cpu().numpy().view(np.uint32).reshape(S, -1)
         for c in range(S):
             assert np.array_equal(rec_g[c >> 1, :n, c & 1], rec_w[c >> 1, :n, c & 1]), (n, c)
-            assert np.array_equal(hi_g[c, :n], hi_w[c, :n]), (n, c)
+            assert np.array_equal(hi_g[c >> 1, :n, c & 1], hi_w[c >> 1, :n, c & 1]), (n, c)
             assert np.array_equal(tg_g[c, :ntg[c]], tg_w[c, :ntg[c]]), (n, c)
 
 

@@ -1283,21 +1283,16 @@ __device__ __forceinline__ TwoLevel tl_view(unsigned long long* seen, uint16_t* 
   return t;
 }
 constexpr int TL_BYTES = K1_TL_BYTES;  // loc + lb + hist + locg
-// words per owner: the W = Wp - 1 words that can hold bits (the guard word never does) over 64 lanes, rounded up
-// to even (two words are read at a time); <= 16 for every n <= 65 535
-__device__ __forceinline__ int tl_items(int Wp) { return ((((Wp - 1) + 63) >> 6) + 1) & ~1; }
-__device__ __forceinline__ uint32_t tl_magic(int IT) {  // 65536 / IT + 1 for the even IT <= 16
-  switch (IT >> 1) {
-    case 1: return 32769u; case 2: return 16385u; case 3: return 10923u; case 4: return 8193u;
-    case 5: return 6554u;  case 6: return 5462u;  case 7: return 4682u;  default: return 4097u;
-  }
-}
-
-// word -> (owner, index inside the owner); magic = 65536 / IT + 1 is exact for every w < 1100, IT <= 16
-// (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
-__device__ __forceinline__ void tl_split(uint32_t w, int IT, uint32_t magic, uint32_t& o, uint32_t& j) {
-  o = __umul24(w, magic) >> 16;
-  j = w - __umul24(o, (uint32_t)IT);
+// Words per owner: ALWAYS 16 (round 3).  Owner o owns words [16 o, 16 o + 16) whatever the column length, so a word
+// splits into (owner, index) by two bit operations and loc / locg / lb are indexed by w, w >> 2 and w >> 4 directly;
+// the owners past the column's last word simply own nothing (n = 50 000: 49 of 64 are used).  Rounds 2 used
+// ceil(W / 64) words per owner (balanced, but a multiply-shift-multiply-subtract per split, twice per row, and address
+// arithmetic on top: ~20 of the hot step's ~134 vector instructions).
+__device__ __forceinline__ int tl_items(int) { return 16; }
+__device__ __forceinline__ uint32_t tl_magic(int) { return 0u; }
+__device__ __forceinline__ void tl_split(uint32_t w, int, uint32_t, uint32_t& o, uint32_t& j) {
+  o = w >> 4;
+  j = w & 15u;
 }
 
 // The counters inside an owner are kept on two levels (round 2b): its <= 16 words are four groups of four, locg[o]
@@ -1331,22 +1326,27 @@ __device__ __forceinline__ void tl_update(const TwoLevel& T, bool ins, uint32_t 
 }
 
 // Recompute loc, locg and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
+// NW: words of seen (and of the pend array) that exist (even: k1_lds_stride); owners past them own nothing.
 template <bool PG>
-__device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge_from, int IT, uint32_t lane) {
+__device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge_from, int NW, uint32_t lane) {
+  constexpr int IT = 16;
   const uint32_t base = lane * (uint32_t)IT;
   ulonglong2* b2 = reinterpret_cast<ulonglong2*>(T.seen + base);
   uint32_t* l32 = reinterpret_cast<uint32_t*>(T.loc + lane * 16u);
   uint32_t run = 0, grun = 0;          // bits in the owner's words so far; of them, in the groups before this one
   unsigned long long gpack = 0ull;     // locg[lane]: four u16
   for (int i = 0; i < (IT >> 1); ++i) {
-    ulonglong2 v = b2[i];
-    if (merge_from) {
-      const int w = (int)base + 2 * i;
-      v.x |= p_ld<PG>(*merge_from, w);
-      v.y |= p_ld<PG>(*merge_from, w + 1);
-      b2[i] = v;
-      p_st<PG>(*merge_from, w, 0ull);
-      p_st<PG>(*merge_from, w + 1, 0ull);
+    const int w = (int)base + 2 * i;
+    ulonglong2 v = make_ulonglong2(0ull, 0ull);
+    if (w < NW) {
+      v = b2[i];
+      if (merge_from) {
+        v.x |= p_ld<PG>(*merge_from, w);
+        v.y |= p_ld<PG>(*merge_from, w + 1);
+        b2[i] = v;
+        p_st<PG>(*merge_from, w, 0ull);
+        p_st<PG>(*merge_from, w + 1, 0ull);
+      }
     }
     if ((i & 1) == 0) {  // words 2i, 2i+1 open group i / 2
       grun = run;
@@ -1358,8 +1358,6 @@ __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge
     run += (uint32_t)__popcll(v.y);
     l32[i] = c0 | (c1 << 16);
   }
-  for (int i = (IT >> 1); i < 8; ++i)   // groups past the owner's words: everything is below them
-    if ((i & 1) == 0) gpack |= (unsigned long long)run << (16 * (i >> 1));
   reinterpret_cast<unsigned long long*>(T.locg)[lane] = gpack;
   T.lb[lane] = wave_incl_scan(run) - run;
 }
@@ -1495,7 +1493,7 @@ __device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw,
   const int IT = tl_items(Wp);
   const uint32_t magic = tl_magic(IT);
   auto merge_pend_into_seen = [&]() {
-    if (LONGR) tl_rebuild<PG>(tl_view(S.L.seen, S.L.spre), &Pg, IT, lane);
+    if (LONGR) tl_rebuild<PG>(tl_view(S.L.seen, S.L.spre), &Pg, k1_lds_stride(Wp, 0), lane);
     else rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
   };
   const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
@@ -1794,15 +1792,15 @@ __device__ __forceinline__ SegCounts seg_group_step(const SegState st, const int
 
 // a group closes: its rows, collected in pend, become visible in seen
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int IT_in, const uint32_t lane) {
-  const int IT = __builtin_amdgcn_readfirstlane(IT_in);
+__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int NW_in, const uint32_t lane) {
+  const int NW = __builtin_amdgcn_readfirstlane(NW_in);   // words of seen / pend that exist
   unsigned long long* seen = (unsigned long long*)st.seen;
   unsigned long long* pend = (unsigned long long*)st.pend;
   uint16_t* spre = (uint16_t*)st.spre;
   if (SEG == 64) {
     PendG P;
     P.bits = pend; P.pre = nullptr; P.pre16 = nullptr;
-    tl_rebuild<false>(tl_view(seen, spre), &P, IT, lane);
+    tl_rebuild<false>(tl_view(seen, spre), &P, NW, lane);
   } else {
     const uint32_t sl = lane & 31u;
     constexpr int H = (HI > 0 ? HI : 1);
@@ -2587,7 +2585,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         if (closes) {
           const bool any_list = ntgB[0] >= 0;
           if (ntgB[0] > 0) S[0].tie += close_group_ties_lds(Pg[0], tgB[0], ntgB[0], Wp, items, lane);
-          if (!single || any_list) seg_group_close<SW, HI>(st, IT, lane);
+          if (!single || any_list) seg_group_close<SW, HI>(st, Wp4, lane);
         }
       }
       dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;

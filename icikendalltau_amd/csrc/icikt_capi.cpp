@@ -118,7 +118,21 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable);
   // a plan without a kernel variant falls back to one pair per wave
   if (ov.pend >= 0) pl.pend_global = ov.pend != 0;
-  if (ov.np == 1 || (ov.np == 2 && half_ok)) np = ov.np;
+  // Long columns with pend in global memory: TWO pairs per wave again, one after the other on the whole wave.  They
+  // share the streamed column and the rec block, so one 8-byte gather per row serves both: the pair kernel of such
+  // columns is bound by the L2's request rate (64 requests per wave and gather; the block never sits in an L1), not by
+  // instruction issue (round 3: a quarter fewer vector instructions changed nothing at n = 50 000).
+  // Measured (tools/n_sweep.py, 512 columns): n = 20 000 1.33e7 -> 1.73e7 pairs/s, 30 000 8.2e6 -> 1.04e7, 36 000 6.9e6 ->
+  // 8.5e6, 50 000 4.92e6 -> 5.36e6; at 65 535 the two pairs' LDS state leaves 4-6 waves per CU and one pair per wave wins
+  // (3.72e6 vs 3.14e6): taken while eight waves of two pairs fit a CU.
+  {
+    const size_t two = 2 * ((size_t)icikt::k1_lds_stride(pv.Wp, 0) * 8 + icikt::K1_TL_BYTES);
+    if (!half_ok && ov.pend != 0 && n_pairs > (int64_t)4 * n_cu && 8 * two <= lds_cap) {
+      np = 2;
+      pl.pend_global = true;
+    }
+  }
+  if (ov.np == 1 || (ov.np == 2 && (half_ok || pl.pend_global))) np = ov.np;
   int wpb = 4;
   if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
@@ -131,7 +145,13 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
   // LDS arrays of such a kernel are padded to 32 * half_items words
   pl.half_items = icikt::k1_half_items(pv.Wp);
-  if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) {
+  const bool seq2 = np == 2 && pl.pend_global;   // two pairs per wave, each on the whole wave (k1_pairs<2, true, 0>)
+  if (seq2) {
+    pl.opts &= ~1;
+    pl.half_items = 0;
+    // (four waves per workgroup: 2 x 8.4 KB of LDS per wave at n = 50 000 -> two workgroups per CU; three workgroups of
+    //  three waves hold one wave more and run slower, 5.12e6 vs 5.36e6)
+  } else if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) {
     pl.opts &= ~1;
     pl.half_items = 0;
     np = 1;

@@ -113,8 +113,8 @@ struct PrepView {
   unsigned long long* k0_bits;    // [chunk][2][Wp + 1]  K0's group-start and fill bitsets (LDS holds them up to 65 535 rows)
 };
 
-// one pair per wave: bytes of the counts of `seen` (loc 64 x 16 x u16, lb 64 x u32, hist 64 x u32, locg 64 x 4 x u16)
-constexpr int K1_TL_BYTES = 2048 + 256 + 256 + 512;
+// one pair per wave: bytes of the counts of `seen` (loc 64 x 16 x u8, lb 64 x u32, hist 64 x u32, locg 64 x 4 x u16)
+constexpr int K1_TL_BYTES = 1024 + 256 + 256 + 512 + 64;   // (+ 64: the closed-form tail reuses the area as a u16 prefix over Wp <= 1 025 words)
 
 // half-wave kernels: bytes of a pair's prefix slots (32 lanes x one aligned slot of 8 u16 -- 16 u16 above 8 words per
 // lane)
@@ -134,11 +134,12 @@ __host__ __device__ inline int k1_half_items(int Wp) {
 // Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan.  The
 // arrays are padded so that the hot steps' prefix rebuilds run without predicates:
 //  * half-wave kernels: 32 lanes x half_items words;
-//  * one pair per wave: 64 lanes x (words per lane rounded up to even; two words are read at a time).
+//  * one pair per wave: the Wp words, rounded up to a multiple of 8 (two words are read at a time, and the u16 array
+//    `ppre` of that length must end on a 16-byte boundary; an owner of the two-level counts has 16 words whatever the
+//    length, and the owners past the last word own nothing).
 __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
   if (half_items > 0) return 32 * half_items;
-  const int items = (Wp + 63) >> 6;
-  return 64 * ((items + 1) & ~1);
+  return (Wp + 7) & ~7;
 }
 
 // ms: cells to exclude while reading dX (nullptr: NaN = missing, nothing else); keep: optional [n_samp][n] bytes,

@@ -1268,7 +1268,7 @@ __device__ __forceinline__ uint32_t wave_allpairs_packed2(uint32_t rka, uint32_t
 // of the streamed column closes) everything is recomputed once from the words (tl_rebuild).
 struct TwoLevel {
   unsigned long long* seen;
-  uint16_t* loc;    // [64][4][4]: per owner and group of four words, bits in the group's words below word jj
+  uint8_t* loc;     // [64][4][4]: per owner and group of four words, bits in the group's words below word jj (<= 192: a byte)
   uint32_t* lb;     // [64]
   uint32_t* hist;   // [64], all zero between steps
   uint16_t* locg;   // [64][4]: per owner, bits in its groups below group g
@@ -1276,8 +1276,8 @@ struct TwoLevel {
 __device__ __forceinline__ TwoLevel tl_view(unsigned long long* seen, uint16_t* spre) {
   TwoLevel t;
   t.seen = seen;
-  t.loc = spre;
-  t.lb = reinterpret_cast<uint32_t*>(spre + 1024);
+  t.loc = reinterpret_cast<uint8_t*>(spre);
+  t.lb = reinterpret_cast<uint32_t*>(spre + 512);
   t.hist = t.lb + 64;
   t.locg = reinterpret_cast<uint16_t*>(t.hist + 64);
   return t;
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ uint32_t tl_query(const TwoLevel& T, uint32_t pos, in
   uint32_t o, j;
   tl_split(w, IT, magic, o, j);
   const uint32_t below_group = (IT > 4) ? (uint32_t)T.locg[o * 4u + (j >> 2)] : 0u;   // one group: nothing below it
-  return T.lb[o] + below_group + (uint32_t)T.loc[o * 16u + j] + (uint32_t)__popcll(T.seen[w] & low_mask64(pos & 63u));
+  return T.lb[o] + below_group + (uint32_t)T.loc[w] + (uint32_t)__popcll(T.seen[w] & low_mask64(pos & 63u));
 }
 
 // Rows with ins == true have just been OR-ed into seen at position q (by these lanes): bring lb and loc up to date.
@@ -1316,13 +1316,22 @@ __device__ __forceinline__ void tl_update(const TwoLevel& T, bool ins, uint32_t 
   if (ins) {
     atomicAdd(&T.hist[o], 1u);
     const unsigned long long ABOVE = 0x0001000100010000ull;
-    atomicAdd(reinterpret_cast<unsigned long long*>(T.loc) + o * 4u + (j >> 2), ABOVE << (16u * (j & 3u)));
+    // "+1 in the bytes above byte f" of the group's four counters: one 32-bit add (what leaves the top: nothing to count)
+    atomicAdd(reinterpret_cast<uint32_t*>(T.loc) + o * 4u + (j >> 2), 0x01010100u << (8u * (j & 3u)));
     if (IT > 4) atomicAdd(reinterpret_cast<unsigned long long*>(T.locg) + o, ABOVE << (16u * (j >> 2)));
   }
   wave_lds_fence();
   const uint32_t h = atomicExch(&T.hist[lane], 0u);
   const uint32_t below = wave_incl_scan(h) - h;
   if (below != 0u) atomicAdd(&T.lb[lane], below);
+}
+
+// the per-row part of tl_update alone (the histogram is collected by the caller: two pairs per wave issue theirs together)
+__device__ __forceinline__ void tl_update_rows(const TwoLevel& T, uint32_t q) {
+  const uint32_t w = (q & 0xFFFFu) >> 6, o = w >> 4, j = w & 15u;
+  atomicAdd(&T.hist[o], 1u);
+  atomicAdd(reinterpret_cast<uint32_t*>(T.loc) + (w >> 2), 0x01010100u << (8u * (j & 3u)));
+  atomicAdd(reinterpret_cast<unsigned long long*>(T.locg) + o, 0x0001000100010000ull << (16u * (j >> 2)));
 }
 
 // Recompute loc, locg and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
@@ -1332,7 +1341,7 @@ __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge
   constexpr int IT = 16;
   const uint32_t base = lane * (uint32_t)IT;
   ulonglong2* b2 = reinterpret_cast<ulonglong2*>(T.seen + base);
-  uint32_t* l32 = reinterpret_cast<uint32_t*>(T.loc + lane * 16u);
+  uint16_t* l16 = reinterpret_cast<uint16_t*>(T.loc + lane * 16u);
   uint32_t run = 0, grun = 0;          // bits in the owner's words so far; of them, in the groups before this one
   unsigned long long gpack = 0ull;     // locg[lane]: four u16
   for (int i = 0; i < (IT >> 1); ++i) {
@@ -1356,7 +1365,7 @@ __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge
     run += (uint32_t)__popcll(v.x);
     const uint32_t c1 = run - grun;
     run += (uint32_t)__popcll(v.y);
-    l32[i] = c0 | (c1 << 16);
+    l16[i] = (uint16_t)(c0 | (c1 << 8));
   }
   reinterpret_cast<unsigned long long*>(T.locg)[lane] = gpack;
   T.lb[lane] = wave_incl_scan(run) - run;
@@ -1844,7 +1853,8 @@ __device__ unsigned long long g_step_stats[24];
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, bool PG, int HI>
-__global__ void __launch_bounds__(512, 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9
+__global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
+                                                                     // Two long-column pairs per wave: the LDS state allows 2-3 waves per SIMD, 3 leave 168 VGPRs
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
          int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
@@ -1871,7 +1881,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const int items = (Wp + 63) >> 6;
   const int IT = tl_items(Wp);                              // one pair per wave: words of seen owned by a lane
   const uint32_t magic = tl_magic(IT);
-  static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG), "k1_pairs variants");
+  static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG) || (NP == 2 && HI == 0 && PG), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
   constexpr bool fast_ties = !PG;                           // MIXED / GROUP steps instead of the general step
@@ -1926,7 +1936,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   PairState S[NP];
   PendG Pg[NP];
   uint32_t cb[NP], gg[NP];
-  bool g_oddtie = false;       // the (first) gathered column has a tie group that starts at an odd position
+  bool g_oddtie = false;       // a gathered column has a tie group that starts at an odd position
   const uint32_t* rec_blk;
   const uint32_t* hi_blk;   // the block's tie-group ends: hi of column 2a | hi of column 2a + 1 << 16 per row
   {
@@ -1943,7 +1953,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
     // (half-wave kernels count a closing group's joint ties with at most four listed groups per lane)
     ntgB[k] = (!(opts & 2) && ntg_raw <= (half_mode ? min(tg_max, 128) : tg_max)) ? ntg_raw : -1;
-    if (k == 0) g_oddtie = (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
+    g_oddtie = g_oddtie || (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
 
@@ -2156,14 +2166,42 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         wave_lds_fence();
       }
     } else {
-      // one pair on the whole wave: gather, count, insert into `seen`, update its counts
-      const uint32_t q0 = rk[0] & 0xFFFFu, lo0 = rk[0] >> 16;
-      const TwoLevel T = tl_view(S[0].L.seen, S[0].L.spre);
-      S[0].dis += tl_query(T, lo0, IT, magic);
-      if (!defer_allpairs) S[0].dis += wave_allpairs(q0, lo0, lane);
+      // one pair on the whole wave: gather, count, insert into `seen`, update its counts.  <2, true, 0>: TWO pairs, one
+      // after the other, each on the whole wave -- they share the streamed column and the rec block, so ONE 8-byte
+      // gather per row serves both (long columns are bound by the L2's request rate: 64 requests per wave and gather,
+      // the 400 KB block of a 50 000-row column never sits in a CU's L1), and their LDS phases are issued together:
+      // the queries of both, then the insertions of both, then the count updates of both
+      TwoLevel T[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        T[k] = tl_view(S[k].L.seen, S[k].L.spre);
+        S[k].dis += tl_query(T[k], rk[k] >> 16, IT, magic);
+      }
+      if (!defer_allpairs) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) S[k].dis += wave_allpairs(rk[k] & 0xFFFFu, rk[k] >> 16, lane);
+      }
       wave_lds_fence();
-      seen_insert(S[0].L.seen, q0);
-      tl_update(T, true, q0, IT, magic, lane);
+      if constexpr (NP == 1) {
+        seen_insert(S[0].L.seen, rk[0] & 0xFFFFu);
+        tl_update(T[0], true, rk[0] & 0xFFFFu, IT, magic, lane);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t qk = rk[k] & 0xFFFFu;
+          seen_insert(S[k].L.seen, qk);
+          tl_update_rows(T[k], qk);
+        }
+        wave_lds_fence();
+        uint32_t hh[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) hh[k] = atomicExch(&T[k].hist[lane], 0u);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t below = wave_incl_scan(hh[k]) - hh[k];
+          if (below != 0u) atomicAdd(&T[k].lb[lane], below);
+        }
+      }
       wave_lds_fence();
     }
   };
@@ -2176,10 +2214,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // the first position of the row's own tie group, i.e. a tie group of >= 2 rows that starts at an odd position.
       // Columns without one (K0 notes it: COL_ODD_TIE; continuous data never have one, the fill group starts at 0)
       // take the packed chain at any length; the others keep the two-instruction compare above 32 768 rows.
-      const bool halved = (NP == 1) && (n > 32768) && !g_oddtie;
-      const bool pack2 = (NP == 1) && ((n <= 32768) || halved);
+      const bool halved = (HI == 0) && (n > 32768) && !g_oddtie;
+      const bool pack2 = (HI == 0) && ((n <= 32768) || halved);
       bool have_prev = false;      // wave-uniform
-      uint32_t rk_prev = 0;
+      uint32_t rk_prev[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rk_prev[k] = 0u;
       defer_allpairs = pack2;
       do {
         uint32_t rk[NP];
@@ -2196,20 +2236,29 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         advance64();
         hot_step(rk, std::false_type{});
         if (pack2) {
-          if (have_prev) {
-            uint32_t ka = rk_prev, kb = rk[0];
-            if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
-              ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
-              kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+          if constexpr (HI == 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              if (have_prev) {
+                uint32_t ka = rk_prev[k], kb = rk[k];
+                if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
+                  ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
+                  kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+                }
+                S[k].dis += wave_allpairs_packed2(ka, kb, lane);
+              }
+              else rk_prev[k] = rk[k];
             }
-            S[0].dis += wave_allpairs_packed2(ka, kb, lane);
           }
-          else rk_prev = rk[0];
           have_prev = !have_prev;
         }
         ICIKT_ST_MARK(0, 64)
       } while (pos + 64 <= hot_until);
-      if (pack2 && have_prev) S[0].dis += wave_allpairs(rk_prev & 0xFFFFu, rk_prev >> 16, lane);   // an odd step out
+      if (pack2 && have_prev) {   // an odd step out
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if (HI == 0) S[k].dis += wave_allpairs(rk_prev[k] & 0xFFFFu, rk_prev[k] >> 16, lane);
+      }
       defer_allpairs = false;
       hi_ok = false;
       continue;
@@ -3367,6 +3416,7 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       default: break;
     }
   }
+  if (np == 2 && pend_global && half_items == 0) return &k1_pairs<2, true, 0>;
   if (np != 1) return nullptr;
   return pend_global ? &k1_pairs<1, true, 0> : &k1_pairs<1, false, 0>;
 }

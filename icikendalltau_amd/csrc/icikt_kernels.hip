@@ -1222,16 +1222,24 @@ __device__ __forceinline__ uint32_t wave_round_packed(uint32_t xa, uint32_t offe
                : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
   return v;
 }
-__device__ __forceinline__ uint32_t wave_allpairs_packed2(uint32_t rka, uint32_t rkb, uint32_t lane) {
+// (in two parts: the operands with the partners' offers -- three ds_bpermute, which queue with the wave's other LDS
+//  operations -- and the sums, which need registers only and can run while LDS atomics are in flight)
+struct Packed2 { uint32_t A, B, off1, off2, xa1, xa2, xa3; };
+__device__ __forceinline__ Packed2 wave_allpairs_packed2_prep(uint32_t rka, uint32_t rkb, uint32_t lane) {
+  Packed2 p;
   const uint32_t Q = __builtin_amdgcn_perm(rkb, rka, 0x05040100u);    // q of step t | q of step t + 1 << 16
   const uint32_t LO = __builtin_amdgcn_perm(rkb, rka, 0x07060302u);   // lo likewise
-  const uint32_t A = 0x7FFF7FFFu - Q, B = LO;
+  p.A = 0x7FFF7FFFu - Q; p.B = LO;
+  p.off1 = (lane & 16u) ? p.B : p.A;   // round 1: rows 1, 3 are the later ones
+  p.off2 = (lane & 32u) ? p.B : p.A;   // rounds 2, 3: rows 2, 3
+  p.xa1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 1u), (int)p.off1);
+  p.xa2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 2u), (int)p.off2);
+  p.xa3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 3u), (int)p.off2);
+  return p;
+}
+__device__ __forceinline__ uint32_t wave_allpairs_packed2_count(const Packed2& p) {
+  const uint32_t A = p.A, B = p.B, off1 = p.off1, off2 = p.off2, xa1 = p.xa1, xa2 = p.xa2, xa3 = p.xa3;
   const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
-  const uint32_t off1 = (lane & 16u) ? B : A;   // round 1: rows 1, 3 are the later ones
-  const uint32_t off2 = (lane & 32u) ? B : A;   // rounds 2, 3: rows 2, 3
-  const uint32_t xa1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 1u), (int)off1);
-  const uint32_t xa2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 2u), (int)off2);
-  const uint32_t xa3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)wave_cross_idx(lane, 3u), (int)off2);
   uint32_t v1, t1, t2;
   // the 15 in-row distances: seven gathers of two sums, the last sum alone (its flags, bits 15 and 31, unpermuted)
   asm volatile("s_nop 1\n\t"
@@ -1248,6 +1256,9 @@ __device__ __forceinline__ uint32_t wave_allpairs_packed2(uint32_t rka, uint32_t
   const uint32_t r2 = wave_round_packed(xa2, off2, M8, SEL);
   const uint32_t r3 = wave_round_packed(xa3, off2, M8, SEL);
   return bcnt_acc(r3, bcnt_acc(r2, bcnt_acc(r1, bcnt_acc(v1, 0u))));
+}
+__device__ __forceinline__ uint32_t wave_allpairs_packed2(uint32_t rka, uint32_t rkb, uint32_t lane) {
+  return wave_allpairs_packed2_count(wave_allpairs_packed2_prep(rka, rkb, lane));
 }
 
 // ---- two-level prefix for one pair per wave (long columns): O(1) work per step -------------------------------
@@ -2216,11 +2227,87 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // take the packed chain at any length; the others keep the two-instruction compare above 32 768 rows.
       const bool halved = (HI == 0) && (n > 32768) && !g_oddtie;
       const bool pack2 = (HI == 0) && ((n <= 32768) || halved);
-      bool have_prev = false;      // wave-uniform
       uint32_t rk_prev[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) rk_prev[k] = 0u;
-      defer_allpairs = pack2;
+      if (HI == 0 && pack2) {
+        // One pair per wave (or two, one after the other) with the packed two-step chain.  A step's LDS work is two
+        // dependent round trips -- the query's reads, then the histogram exchange behind the insertions' atomics -- and at
+        // 2 .. 4 waves per SIMD nothing else covers them, so the chain (registers only, ~105 instructions for two steps of
+        // a pair) is placed BEHIND the issue of the atomics and the exchange and IN FRONT of the wait for them; its three
+        // ds_bpermute are issued with the query's reads.  Two pairs take turns: pair 0 counts its steps (2m, 2m + 1)
+        // during step 2m + 1, pair 1 counts (2m + 1, 2m + 2) during step 2m + 2 -- its step 0 alone, unpacked -- so that
+        // every step has one chain to run.
+        int ph[NP];   // per pair, wave-uniform: 0 = this step is counted alone, 1 = kept for the next step, 2 = counted with the kept one
+#pragma unroll
+        for (int k = 0; k < NP; ++k) ph[k] = (k == 0) ? 1 : 0;
+        do {
+          uint32_t rk[NP];
+          if (rk_ok) {
+            take_rk(rk);
+          } else if (NP == 2) {
+            const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+          } else {
+            rk[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
+          }
+          pos += 64;
+          advance64();
+          TwoLevel T[NP];
+          uint32_t cnt[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            T[k] = tl_view(S[k].L.seen, S[k].L.spre);
+            cnt[k] = tl_query(T[k], rk[k] >> 16, IT, magic);
+          }
+          Packed2 pk[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            if (ph[k] == 2) {
+              uint32_t ka = rk_prev[k], kb = rk[k];
+              if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
+                ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
+                kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+              }
+              pk[k] = wave_allpairs_packed2_prep(ka, kb, lane);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            S[k].dis += cnt[k];
+            if (ph[k] == 0) S[k].dis += wave_allpairs(rk[k] & 0xFFFFu, rk[k] >> 16, lane);
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            seen_insert(S[k].L.seen, rk[k] & 0xFFFFu);
+            tl_update_rows(T[k], rk[k] & 0xFFFFu);
+          }
+          wave_lds_fence();
+          uint32_t hh[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) hh[k] = atomicExch(&T[k].hist[lane], 0u);
+#pragma unroll
+          for (int k = 0; k < NP; ++k)
+            if (ph[k] == 2) S[k].dis += wave_allpairs_packed2_count(pk[k]);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const uint32_t below = wave_incl_scan(hh[k]) - hh[k];
+            if (below != 0u) atomicAdd(&T[k].lb[lane], below);
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            if (ph[k] == 1) { rk_prev[k] = rk[k]; ph[k] = 2; }
+            else ph[k] = 1;
+          }
+          ICIKT_ST_MARK(0, 64)
+        } while (pos + 64 <= hot_until);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)   // a kept step that met no partner
+          if (ph[k] == 2) S[k].dis += wave_allpairs(rk_prev[k] & 0xFFFFu, rk_prev[k] >> 16, lane);
+      } else {
       do {
         uint32_t rk[NP];
         if (rk_ok) {
@@ -2235,29 +2322,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         pos += 64;
         advance64();
         hot_step(rk, std::false_type{});
-        if (pack2) {
-          if constexpr (HI == 0) {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-              if (have_prev) {
-                uint32_t ka = rk_prev[k], kb = rk[k];
-                if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
-                  ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
-                  kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
-                }
-                S[k].dis += wave_allpairs_packed2(ka, kb, lane);
-              }
-              else rk_prev[k] = rk[k];
-            }
-          }
-          have_prev = !have_prev;
-        }
         ICIKT_ST_MARK(0, 64)
       } while (pos + 64 <= hot_until);
-      if (pack2 && have_prev) {   // an odd step out
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if (HI == 0) S[k].dis += wave_allpairs(rk_prev[k] & 0xFFFFu, rk_prev[k] >> 16, lane);
       }
       defer_allpairs = false;
       hi_ok = false;

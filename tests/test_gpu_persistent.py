@@ -74,6 +74,24 @@ def test_persistent_waves_run_many_tasks(plan_ctx, n):
     assert np.array_equal(capped[0], one[0]) and np.array_equal(capped[1], one[1])
 
 
+@pytest.mark.parametrize("n", [18400, 33000, 50000])
+def test_two_pairs_per_wave_long_columns(plan_ctx, n):
+    """k1_pairs<2, true, 0>: two pairs of a long column per wave, one after the other on the whole wave, sharing the
+    streamed column and one 8-byte gather per row; the packed two-step chains of the two pairs take turns (pair 1 counts
+    its first singleton step alone).  Tied, left-censored, scattered-missing and half-missing columns -- every general
+    step of the pair kernel with two pairs in flight -- on a capped grid (every wave runs several tasks: both pairs'
+    global pend slots are reused) and on the library's own grid; all pairs, both perspectives, counts bit-exact; an odd
+    column count leaves tasks with a single pair."""
+    X = _tied_matrix(n, 19, seed=n + 7)
+    plan_ctx.debug_set_plan({"np": 2, "pend": "g", "gridcap": 4})
+    _all_pairs_vs_oracle(plan_ctx, X)
+    plan_ctx.debug_set_plan({"np": 2, "pend": "g"})
+    two = plan_ctx.pairs(X, perspective="global")
+    plan_ctx.debug_set_plan({"np": 1, "pend": "g"})
+    one = plan_ctx.pairs(X, perspective="global")
+    assert np.array_equal(two[0], one[0], equal_nan=True) and np.array_equal(two[1], one[1])
+
+
 def test_persistent_grid_natural_plan(hip_ctx):
     """36 000 x 128 = 8 128 tasks against the ~5 000 waves the chip holds at that length: the library's own plan
     makes waves take a second task.  Oracle on 300 sampled pairs, count identities on all."""

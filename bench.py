@@ -139,6 +139,7 @@ PMC_PASSES = (  # one rocprofv3 --pmc run each: 8 SQ slots (+ GRBM, its own bloc
             "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]),
     ("fetch", ["FETCH_SIZE"]),
     ("write", ["WRITE_SIZE"]),
+    ("l2", ["TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]),
 )
 
 
@@ -184,7 +185,7 @@ def _pmc_pass(config: str, counters, outdir: str, timeout_s: int):
     return {c: sum(v) / len(v) for c, v in agg.items()}, info   # one row per dispatch and counter: the mean per dispatch
 
 
-K1_KERNEL_OF = {"c3": "k1_pairsILi2ELb0ELi5", "c4": "k1_pairsILi2ELb0ELi5", "c5": "k1_pairsILi1ELb1ELi0"}   # plan_k1's choice
+K1_KERNEL_OF = {"c3": "k1_pairsILi2ELb0ELi5", "c4": "k1_pairsILi2ELb0ELi5", "c5": "k1_pairsILi2ELb1ELi0"}   # plan_k1's choice
 
 
 def static_valu_mix(config: str):
@@ -308,7 +309,21 @@ def build_roofline(pmc, pmc_source, pmc_note, k1_avg_s, P_local, n):
         roof["traffic_uncorrected"] = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         roof["hbm_measured_GBs"] = traffic / k1_avg_s / 1e9
         roof["hbm_measured_frac"] = roof["hbm_measured_GBs"] / HBM_PEAK_GBS
-    roof["pmc"] = {k: pmc[k] for k in sorted(pmc) if k[:3] in ("SQ_", "GRB", "FET", "WRI") or
+    if pmc.get("TCC_REQ_sum"):
+        # The scattered `rec` gathers of the pair kernel: one L2 request per lane and gather when the gathered block does not
+        # sit in the CU's L1 (long columns).  MI355X_MICROARCH.md, "Indexed rows": rows served from an XCD's L2 arrive at
+        # 16.8-18.8 TB/s chip-wide; at 64 B per request that is ~2.8e11 requests/s.  Long columns ran AT that rate with one
+        # pair per gather, which is why they now run two pairs per gather.
+        req = pmc["TCC_REQ_sum"]
+        roof["l2_requests_per_launch"] = req
+        roof["l2_requests_per_s"] = req / k1_avg_s
+        roof["l2_GBs_at_64B_per_request"] = req * 64.0 / k1_avg_s / 1e9
+        roof["l2_frac_of_guide_gather_rate"] = req * 64.0 / k1_avg_s / 1e9 / 17800.0
+        if pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None and (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]) > 0:
+            roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+        if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            roof["l1_hit_rate"] = 1.0 - req / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] if pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] > req else 0.0
+    roof["pmc"] = {k: pmc[k] for k in sorted(pmc) if k[:3] in ("SQ_", "GRB", "FET", "WRI", "TCC", "TCP") or
                    k in ("src_hash", "taken", "k1_ms_in_pmc_pass", "valu_mix_hot_loop", "valu_mix_note")}
     return roof
 

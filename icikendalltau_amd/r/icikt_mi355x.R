@@ -7,7 +7,10 @@
 #   ici_kt()     (R/RcppExports.R:62-64)   -> one .Call for one pair   (ici_kt_gpu)
 #   computation$split_fun(split_comparisons, ici_split, ...)  (R/kendalltau.R:158)
 #                                          -> ONE .Call for all chunks, n_gpu GPUs inside it (ici_split_all_gpu)
-# Everything around them (setup_missing_matrix, setup_comparisons, scale_and_reshape) is the
+#   ici_kendalltau(return_matrix = TRUE) below its argument checks (R/kendalltau.R:117-176)
+#                                          -> ONE .Call for the whole matrix (ici_kendalltau_gpu): exclusion rule,
+#                                             pair kernels and scale_and_reshape on the device
+# With the first three, everything around them (setup_missing_matrix, setup_comparisons, scale_and_reshape) is the
 # reference's own R code and stays untouched.
 
 .icikt_warn = c(
@@ -81,6 +84,36 @@ ici_kt_gpu = function(x, y, perspective = "local", alternative = "two.sided", co
         "\nvar: ", f(var), "\nz_b: ", f(s_adjusted / sqrt(var)), "\ntau: ", f(out[["tau"]]),
         "\ntau_max:", f(out[["tau_max"]]), "\npvalue: ", f(out[["pvalue"]]), "\n", sep = "")
   }
+  out
+}
+
+# Replacement for the whole body of ici_kendalltau() below its argument checks when return_matrix = TRUE
+# (R/kendalltau.R:117-176): setup_missing_matrix, the pair list, ici_split over all chunks and scale_and_reshape run
+# inside ONE .Call on the device(s) -- no masked copy of the matrix, no data.frame of n (n - 1) / 2 rows, no name-indexed
+# fill of five matrices.  `data_matrix` is the RAW matrix; the result has the reference's names and shapes
+# (cor, raw, pvalue, taumax, completeness: S x S with dimnames; keep: S x n_feature logical; run_time).
+# include_only: handled by the reference's own setup_comparisons() (its three forms), whose pair list is handed over.
+ici_kendalltau_gpu = function(data_matrix, global_na = c(NA, Inf, 0), perspective = "global", scale_max = TRUE,
+                              diag_good = TRUE, include_only = NULL, alternative = "two.sided", continuity = FALSE,
+                              device = 0L, n_gpu = 1L) {
+  storage.mode(data_matrix) = "double"
+  samples = colnames(data_matrix)
+  if (is.null(samples)) { samples = paste0("s", seq_len(ncol(data_matrix))); colnames(data_matrix) = samples }
+  pi = pj = NULL
+  if (!is.null(include_only) || !diag_good) {   # the reference's own filter; all pairs of the triangle need no list
+    cmp = do.call(rbind, setup_comparisons(samples, include_only, diag_good, 1L))
+    pi = match(cmp[, 1], samples); pj = match(cmp[, 2], samples)
+  }
+  t1 = Sys.time()
+  res = .Call("icikt_R_matrix", data_matrix, as.double(global_na), pi, pj, perspective, alternative, continuity,
+              scale_max, diag_good, as.integer(device), as.integer(n_gpu))
+  t2 = Sys.time()
+  for (code in 2:4) for (k in seq_len(res$reason_counts[code + 1])) warning(.icikt_warn[[as.character(code)]], call. = FALSE)
+  out = res[c("cor", "raw", "pvalue", "taumax", "completeness")]
+  for (nm in names(out)) dimnames(out[[nm]]) = list(samples, samples)
+  out$keep = res$keep
+  dimnames(out$keep) = list(samples, rownames(data_matrix))
+  out$run_time = as.numeric(difftime(t2, t1, units = "secs"))
   out
 }
 

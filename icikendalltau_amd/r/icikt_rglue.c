@@ -18,6 +18,15 @@
  *                     R/kendalltau.R:158 (HIP must not be driven from forked multicore workers)
  *       want_counts   TRUE: also the P x 11 integer counts record (the numbers src/kendallc.cpp:342-363 prints)
  *       returns list(raw, pvalue, taumax, completeness, reason[, counts]) of length-P vectors
+ *   .Call("icikt_R_matrix", data_matrix, global_na, pi, pj, perspective, alternative, continuity, scale_max, diag_good,
+ *         device, n_gpu)
+ *       ici_kendalltau(return_matrix = TRUE) below its argument checks in ONE call (icikt_matrix_f64 /
+ *       icikt_matrix_multi_f64): the exclusion rule of setup_missing_matrix (R/utils.R:1-23) inside the pre-pass,
+ *       the pair kernels, scale_and_reshape (R/kendalltau.R:357-421) on the device, one copy of five S x S matrices
+ *       back -- no 523 776-row data.frame, no name-indexed fill.  data_matrix is the RAW features x samples matrix
+ *       (NOT exclude_data); global_na the values to exclude (NA, Inf, 0, ...); pi / pj NULL = all combn pairs.
+ *       returns list(cor, raw, pvalue, taumax, completeness, keep, reason_counts): five S x S numeric matrices, the
+ *       logical S x n_feat `keep` matrix of R/kendalltau.R:417 and the pairs per reason code 0..4
  *   .Call("icikt_R_missingness", exclude_data, pi, pj, device) -> numeric(P)
  * Errors become R errors (Rf_error), as BEGIN_RCPP/END_RCPP does (src/RcppExports.cpp:84,95);
  * per-pair degenerate cases are returned as NA_real_ x4 plus a reason code so that the R wrapper can
@@ -125,6 +134,62 @@ SEXP icikt_R_pairs(SEXP x, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative,
   return res;
 }
 
+SEXP icikt_R_matrix(SEXP x, SEXP global_na, SEXP pi, SEXP pj, SEXP perspective, SEXP alternative, SEXP continuity,
+                    SEXP scale_max, SEXP diag_good, SEXP device, SEXP n_gpu) {
+  if (!Rf_isReal(x) || !Rf_isMatrix(x)) Rf_error("icikt: data_matrix must be a double matrix");
+  const int64_t n_feat = Rf_nrows(x), n_samp = Rf_ncols(x);
+  const int ngpu = Rf_asInteger(n_gpu) > 1 ? Rf_asInteger(n_gpu) : 1;
+  icikt_ctx *ctx = (ngpu == 1) ? get_ctx(Rf_asInteger(device)) : NULL;
+  icikt_multi *multi = (ngpu > 1) ? get_multi(Rf_asInteger(device), ngpu) : NULL;
+  /* global_na: NA_real_ / NaN select "missing", +-Inf "infinite", anything else is compared with == (R/utils.R:1-23) */
+  const int n_na = Rf_isNull(global_na) ? 0 : (int)XLENGTH(global_na);
+  double *gna = (double *)R_alloc(n_na > 0 ? n_na : 1, sizeof(double));
+  for (int k = 0; k < n_na; ++k) gna[k] = Rf_isReal(global_na) ? REAL(global_na)[k] : Rf_asReal(global_na);
+  int64_t P = 0;
+  int32_t *pi0 = NULL, *pj0 = NULL;
+  if (!Rf_isNull(pi)) {
+    P = XLENGTH(pi);
+    if (XLENGTH(pj) != P) Rf_error("icikt: pi and pj differ in length");
+    pi0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+    pj0 = (int32_t *)R_alloc(P > 0 ? P : 1, sizeof(int32_t));
+    for (int64_t p = 0; p < P; ++p) { pi0[p] = INTEGER(pi)[p] - 1; pj0[p] = INTEGER(pj)[p] - 1; }
+  }
+  const char *nm[] = {"cor", "raw", "pvalue", "taumax", "completeness", "keep", "reason_counts", ""};
+  SEXP res = PROTECT(Rf_mkNamed(VECSXP, nm));
+  /* the library writes the five matrices contiguously: one REALSXP of 5 S^2, split afterwards without a second pass
+     over the host (the matrices are symmetric: R's column-major order is either order) */
+  double *out5 = (double *)R_alloc((size_t)(5 * n_samp * n_samp > 0 ? 5 * n_samp * n_samp : 1), sizeof(double));
+  uint8_t *keep = (uint8_t *)R_alloc((size_t)(n_samp * n_feat > 0 ? n_samp * n_feat : 1), 1);
+  int64_t rc5[5] = {0, 0, 0, 0, 0};
+  int rc;
+  if (multi) {
+    rc = icikt_matrix_multi_f64(multi, REAL(x), n_feat, n_samp, n_feat, gna, n_na, pi0, pj0, P, perspective_code(perspective),
+                                alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u,
+                                Rf_asLogical(scale_max) ? 1 : 0, Rf_asLogical(diag_good) ? 1 : 0, out5, keep, rc5);
+    if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_multi_last_error(multi), rc);
+  } else {
+    rc = icikt_matrix_f64(ctx, REAL(x), n_feat, n_samp, n_feat, gna, n_na, pi0, pj0, P, perspective_code(perspective),
+                          alternative_code(alternative), Rf_asLogical(continuity) ? 1 : 0, 0u,
+                          Rf_asLogical(scale_max) ? 1 : 0, Rf_asLogical(diag_good) ? 1 : 0, out5, keep, rc5);
+    if (rc != ICIKT_SUCCESS) Rf_error("icikt: %s (code %d)", icikt_last_error(ctx), rc);
+  }
+  for (int f = 0; f < 5; ++f) {
+    SEXP m = PROTECT(Rf_allocMatrix(REALSXP, (int)n_samp, (int)n_samp));
+    memcpy(REAL(m), out5 + (size_t)f * n_samp * n_samp, (size_t)n_samp * n_samp * sizeof(double));
+    SET_VECTOR_ELT(res, f, m);
+    UNPROTECT(1);
+  }
+  SEXP k = PROTECT(Rf_allocMatrix(LGLSXP, (int)n_samp, (int)n_feat));   /* keep = t(!exclude_loc): samples x features */
+  for (int64_t c = 0; c < n_samp; ++c)
+    for (int64_t r = 0; r < n_feat; ++r) LOGICAL(k)[r * n_samp + c] = keep[c * n_feat + r] ? TRUE : FALSE;
+  SET_VECTOR_ELT(res, 5, k);
+  SEXP rcv = PROTECT(Rf_allocVector(REALSXP, 5));
+  for (int f = 0; f < 5; ++f) REAL(rcv)[f] = (double)rc5[f];
+  SET_VECTOR_ELT(res, 6, rcv);
+  UNPROTECT(3);
+  return res;
+}
+
 SEXP icikt_R_missingness(SEXP x, SEXP pi, SEXP pj, SEXP device) {
   if (!Rf_isReal(x) || !Rf_isMatrix(x)) Rf_error("icikt: exclude_data must be a double matrix");
   const int64_t n_feat = Rf_nrows(x), n_samp = Rf_ncols(x), P = XLENGTH(pi);
@@ -143,6 +208,7 @@ SEXP icikt_R_missingness(SEXP x, SEXP pi, SEXP pj, SEXP device) {
 
 static const R_CallMethodDef CallEntries[] = {
     {"icikt_R_pairs", (DL_FUNC)&icikt_R_pairs, 9},
+    {"icikt_R_matrix", (DL_FUNC)&icikt_R_matrix, 11},
     {"icikt_R_missingness", (DL_FUNC)&icikt_R_missingness, 4},
     {NULL, NULL, 0}};
 

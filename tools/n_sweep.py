@@ -6,7 +6,7 @@ from icikendalltau_amd import _lib
 from bench import make_matrix
 
 ns = [int(a) for a in sys.argv[1:]] or [2000, 5000, 10000, 16000, 17000, 25000, 26000, 40000, 65535]
-variants = [dict(), dict(np="1"), dict(np="1", pend="g"), dict(np="1", pend="l"), dict(np="2", pend="g"), dict(np="2", pend="g", wpb="4"), dict(np="2", pend="g", wpb="2")]
+variants = [dict(), dict(np="1"), dict(np="1", pend="g"), dict(np="1", pend="l"), dict(np="2", pend="g"), dict(np="2", pend="g", wpb="1"), dict(np="2", pend="g", wpb="3")]
 ctx = _lib.Context(0)
 for n in ns:
     S = 512

@@ -67,7 +67,11 @@ def hot_loops(want, verbose=False):
 def hot_loop_mix(want):
     """{"full": n, "half": n, "permlane": n, "ds": n, "salu": n, ...} of the innermost hot loop of kernel `want`."""
     # the innermost loop that holds the compare chain AND gathers rows (a step of the walk)
-    a, b, cnt, _ = next(x for x in hot_loops(want) if x[2].get("global", 0) > 0)
+    # (the one-pair / two-pair long-column kernels have two such loops: the one with the PACKED chain -- v_perm_b32 -- is the
+    #  one that runs on columns without odd-positioned tie groups, i.e. on every benchmark workload)
+    loops = [x for x in hot_loops(want, verbose=True) if x[2].get("global", 0) > 0]
+    packed = [x for x in loops if any("v_perm_b32" in l for l in x[3])]
+    a, b, cnt, _ = (packed or loops)[0]
     return {"kernel": want, "full": cnt.get("vF", 0), "half": cnt.get("vH", 0), "permlane": cnt.get("v8", 0),
             "ds": cnt.get("ds", 0), "global": cnt.get("global", 0), "salu_and_waits": cnt.get("s", 0)}
 

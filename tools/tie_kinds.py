@@ -1,7 +1,7 @@
-"""Instructions per step KIND of the pair kernel on tied data: fits, over the tie-sweep matrices,
-    SQ_INSTS_x (per K1 launch, rocprofv3 --pmc: tools/pmc_tie.sh)  =  sum over kinds of steps_kind x c_kind + tasks x c_task
-by least squares, with the steps per kind taken from the diagnostic build (tools/step_stats.py).  Six matrices
-(continuous, ~5000, 1000, 200, 50, 10 distinct values per column), four unknowns (hot, MIXED, GROUP step; per task).
+"""Where the pair kernel's instructions go on tied data: per tie-sweep matrix (10 000 x 256,
+columns rounded to ~L distinct values, 5 % missing) the steps a task takes by KIND and their rows (diagnostic build,
+tools/step_stats.py) beside the vector / scalar / LDS instructions of a K1 launch (rocprofv3 --pmc, tools/pmc_tie.sh),
+per task, per step and per row of the streamed column (a row of a task = one row of two pairs).
 
     python tools/tie_kinds.py gpurun_out/<tag>_step_stats.md gpurun_out/<tag>_pmc_tie.log
 """
@@ -33,18 +33,16 @@ def steps(L, kind):
     if kind == "hot":
         return k.get("hot_loop", (0, 0))[0] + k.get("hot_in_main", (0, 0))[0]
     return k.get(kind, (0, 0))[0]
-A = np.array([[steps(L, k) for k in kinds] + [cases[L]["kinds"].get("setup", (0, 0))[0]] for L in levels], dtype=float)
-print("| distinct values | steps per task: hot / MIXED / GROUP | rows per MIXED / GROUP step | VALU per launch | SALU per launch |")
-print("|---|---|---|---|---|")
-for i, L in enumerate(levels):
-    t = A[i, 3] or 1
+print("| distinct values | steps per task: hot / MIXED / GROUP | rows per MIXED / GROUP step | VALU per task | per step | per row | SALU per row | LDS per row | VALU per row vs continuous |")
+print("|---|---|---|---|---|---|---|---|---|")
+base = None
+for L in levels:
     k = cases[L]["kinds"]
-    print(f"| {L or 'continuous'} | {A[i,0]/t:.1f} / {A[i,1]/t:.1f} / {A[i,2]/t:.1f} | {k.get('mixed',(0,0))[1]:.1f} / {k.get('group',(0,0))[1]:.1f} | "
-          f"{counters[L]['SQ_INSTS_VALU']:.3e} | {counters[L]['SQ_INSTS_SALU']:.3e} |")
-print()
-print("| instructions per step (least squares over the matrices) | hot | MIXED | GROUP | per task (set-up, tail, reductions) |")
-print("|---|---|---|---|---|")
-for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
-    y = np.array([counters[L][name] for L in levels])
-    c, *_ = np.linalg.lstsq(A, y, rcond=None)
-    print(f"| {name} | {c[0]:.0f} | {c[1]:.0f} | {c[2]:.0f} | {c[3]:.0f} |")
+    tasks = k.get("setup", (2, 0))[0] / 2.0            # the set-up mark is stamped twice per task
+    st = [steps(L, kd) / tasks for kd in kinds]
+    rows = sum(k.get(kd, (0, 0))[0] * k.get(kd, (0, 0))[1] for kd in ("hot_loop", "hot_in_main", "mixed", "group", "tail")) / tasks
+    v, sa, ld = (counters[L][c] / tasks for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
+    if base is None:
+        base = v / rows
+    print(f"| {L or 'continuous'} | {st[0]:.0f} / {st[1]:.0f} / {st[2]:.0f} | {k.get('mixed',(0,0))[1]:.1f} / {k.get('group',(0,0))[1]:.1f} | "
+          f"{v:.0f} | {v / max(sum(st), 1):.0f} | {v / rows:.2f} | {sa / rows:.2f} | {ld / rows:.2f} | {v / rows / base:.2f} |")

@@ -99,68 +99,53 @@ struct K1Plan {
 K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
-  // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per half,
-  // pend in LDS.  Longer columns: one pair per wave on all 64 lanes (measured crossover between n = 10 000 and
-  // 11 000, tools/n_sweep.py); pend stays in LDS while that still leaves 12 waves per CU (n <~ 32 000), beyond
-  // that the LDS state is what limits occupancy and pend moves to a per-wave slot in global memory (slower
-  // steps when the streamed column has tie groups).
+  // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per 32-lane half.
+  // Longer columns: pairs on the whole wave -- TWO per wave, one after the other, while eight waves of two pairs fit a
+  // CU's LDS (n <~ 60 000), else one.  The two share the streamed column and the rec block, so one 8-byte gather per row
+  // serves both: the pair kernel of long columns was bound by the L2's request rate (64 requests per wave and gather; the
+  // block never sits in an L1), not by instruction issue (round 3: a quarter fewer vector instructions changed nothing
+  // at n = 50 000).  Measured (tools/n_sweep.py, 512 columns, one pair -> two pairs per wave): n = 20 000 1.32e7 -> 1.68e7
+  // pairs/s, 30 000 8.2e6 -> 1.12e7, 36 000 6.7e6 -> 9.4e6, 50 000 4.9e6 -> 5.8e6, 60 000 4.1e6 -> 4.9e6; at 65 535 the two
+  // pairs' LDS state leaves 4-6 waves per CU and one pair per wave wins (3.7e6 vs 2.7e6).
+  // No kernel keeps a second bitset for open tie groups any more (`pend`, in LDS or in per-wave global slots with a
+  // persistent grid: rounds 1-2): the plan keys pend / gridmult / gridcap of icikt_debug_set_plan are accepted and ignored.
   const bool half_ok = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
   int np = half_ok ? 2 : 1;
-  // few pairs: twice the waves hide the latency of a step better than two pairs per wave share their loads while
-  // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
-  // 780 pairs, 0.209 vs 0.230 ms, two pairs per wave from 1 128 pairs on, 0.231 vs 0.242 ms; all 4 560 pairs:
-  // 0.337 vs 0.416 ms)
-  if (n_pairs <= (int64_t)4 * n_cu) np = 1;
-  {
-    const size_t full = (size_t)icikt::k1_lds_stride(pv.Wp, 0) * (8 + 8 + 2) + icikt::K1_TL_BYTES;  // seen, pend, ppre + counts
-    pl.pend_global = !half_ok && full * 12 > lds_cap;   // measured: LDS wins at 20 000 (+10 %) and 30 000, global from 35 000 on
-  }
-  // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable);
-  // a plan without a kernel variant falls back to one pair per wave
-  if (ov.pend >= 0) pl.pend_global = ov.pend != 0;
-  // Long columns with pend in global memory: TWO pairs per wave again, one after the other on the whole wave.  They
-  // share the streamed column and the rec block, so one 8-byte gather per row serves both: the pair kernel of such
-  // columns is bound by the L2's request rate (64 requests per wave and gather; the block never sits in an L1), not by
-  // instruction issue (round 3: a quarter fewer vector instructions changed nothing at n = 50 000).
-  // Measured (tools/n_sweep.py, 512 columns): n = 20 000 1.33e7 -> 1.73e7 pairs/s, 30 000 8.2e6 -> 1.04e7, 36 000 6.9e6 ->
-  // 8.5e6, 50 000 4.92e6 -> 5.36e6; at 65 535 the two pairs' LDS state leaves 4-6 waves per CU and one pair per wave wins
-  // (3.72e6 vs 3.14e6): taken while eight waves of two pairs fit a CU.
   {
     const size_t two = 2 * ((size_t)icikt::k1_lds_stride(pv.Wp, 0) * 8 + icikt::K1_TL_BYTES);
-    if (!half_ok && ov.pend != 0 && n_pairs > (int64_t)4 * n_cu && 8 * two <= lds_cap) {
-      np = 2;
-      pl.pend_global = true;
-    }
+    if (!half_ok && 7 * two <= lds_cap) np = 2;   // (65 535 rows: seven single-wave workgroups, 3.96e6 vs 3.74e6)
   }
-  if (ov.np == 1 || (ov.np == 2 && (half_ok || pl.pend_global))) np = ov.np;
+  // few pairs: twice the waves hide the latency of a step better than two pairs per wave share their loads while
+  // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
+  // 780 pairs, 0.209 vs 0.230 ms, two pairs per wave from 1 128 pairs on, 0.231 vs 0.242 ms)
+  if (n_pairs <= (int64_t)4 * n_cu) np = 1;
+  pl.pend_global = false;
+  // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable)
+  if (ov.np == 1 || ov.np == 2) np = ov.np;
   int wpb = 4;
+  if (!half_ok && np == 2) {   // fewer than two four-wave workgroups of two pairs fit: single-wave workgroups fill the LDS
+    const size_t two = 2 * ((size_t)icikt::k1_lds_stride(pv.Wp, 0) * 8 + icikt::K1_TL_BYTES);
+    if (8 * two > lds_cap) wpb = 1;
+  }
   if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
   if (ov.half >= 0) pl.opts = ov.half ? 1 : 0;
-  int tg_max = 128;  // bits 8..: joint ties of multi-step groups by tie-group list while B has at most this many groups
-                     // (measured on 10 000-row columns: list mode wins at 50 groups, row mode at 200: tools/tie_sweep.py)
+  int tg_max = 128;  // bits 8..: joint ties of a closing group from the gathered column's tie-group list while it has at
+                     // most this many groups (the kernels cap it at 128: two / four listed groups per lane), else row by row
   if (ov.has_tgmax) tg_max = std::max(-1, std::min(1 << 20, ov.tgmax));
   pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
   if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
-  // half-wave hot step: a half rebuilds a prefix with half_items words per lane, unpredicated, so the
-  // LDS arrays of such a kernel are padded to 32 * half_items words
+  // half-wave kernels: a half rebuilds a prefix with half_items words per lane, unpredicated, so the LDS arrays of such
+  // a kernel are padded to 32 * half_items words; every other plan runs pairs on the whole wave
   pl.half_items = icikt::k1_half_items(pv.Wp);
-  const bool seq2 = np == 2 && pl.pend_global;   // two pairs per wave, each on the whole wave (k1_pairs<2, true, 0>)
-  if (seq2) {
+  if (np != 2 || !half_ok || !(pl.opts & 1)) {
     pl.opts &= ~1;
     pl.half_items = 0;
-    // (four waves per workgroup: 2 x 8.4 KB of LDS per wave at n = 50 000 -> two workgroups per CU; three workgroups of
-    //  three waves hold one wave more and run slower, 5.12e6 vs 5.36e6)
-  } else if (np != 2 || pl.pend_global || pl.half_items > icikt::ICIKT_HALF_ITEMS_MAX || !(pl.opts & 1)) {
-    pl.opts &= ~1;
-    pl.half_items = 0;
-    np = 1;
   }
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items));  // seen + prefix slots (no pend)
-  else  // one pair per wave: seen [, pend], the two-level counts [, ppre]
-    pl.perpair_bytes = (int)((size_t)pl.stride * (pl.pend_global ? 8 : (8 + 8 + 2)) + icikt::K1_TL_BYTES);
+  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items));  // seen + prefix slots
+  else pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
@@ -281,43 +266,39 @@ int upload_units(icikt_ctx* c) {
 // One launch of the pair kernel over tasks [first, first + count) of the uploaded task list, on c->stream.
 int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   if (count <= 0) return ICIKT_SUCCESS;
-  // With pend in LDS every wave takes one task (grid = all tasks): measured 9 % faster on c4 than persistent
-  // waves, which run in lockstep and end on a ragged last round.  With pend in global memory every launched
-  // wave owns a slot of it: the grid is what the chip holds at once and the waves fetch tasks, in order, from
-  // one counter per XCD group (k1_pairs: why the order matters for the L2).
-  int per_cu = 0;
-  HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.pend_global, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
-  if (per_cu < 1) per_cu = 1;
+  // Half-wave kernels: every wave takes one task (grid = all tasks; workgroups start in order, and the kernel's XCD-aware
+  // block mapping keeps the tasks of one gathered block on one XCD's L2): measured 9 % faster on c4 than persistent
+  // waves, which run in lockstep and end on a ragged last round.  Whole-wave kernels (long columns, few and long
+  // tasks per CU): when the task list is longer than what the chip holds, the grid is what the chip holds and the waves
+  // FETCH their tasks, in order, from one counter per XCD group (k1_pairs: why the order matters for the L2) -- a wave
+  // that has finished goes on at once instead of waiting for the other waves of its workgroup to retire (c5: +2.4 %).
   const int want = (count + pl.wpb - 1) / pl.wpb;
-  int blocks = want;
-  if (pl.pend_global) {
+  int blocks = std::max(1, want);
+  int per_cu = 0;
+  bool persistent = false;
+  if (pl.half_items == 0) {
+    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, false, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
+    if (per_cu < 1) per_cu = 1;
     const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
     const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
-    blocks = (int)std::min<int64_t>(want, mult * resident);
-    // test hook: a grid far smaller than the task list makes every persistent wave run many tasks in a row
-    // (slot reuse, the per-XCD task counters, the in-order fetch) whatever the chip would hold
-    if (c->plan_ov.grid_cap > 0) blocks = std::min(blocks, c->plan_ov.grid_cap);
-  }
-  blocks = std::max(blocks, 1);
-  if (c->plan_ov.verbose)
-    fprintf(stderr, "[icikt] K1 plan: np=%d pend=%s half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d, tasks=%d (from %d)\n",
-            pl.np, pl.pend_global ? "global" : "lds", pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount,
-            blocks, count, first);
-  if (pl.pend_global) {
-    const size_t pend_elems = (size_t)blocks * pl.wpb * pl.np * pl.stride;
-    if (pend_elems > c->d_pend_bits.cap) {
-      HIPCHK(c, c->d_pend_bits.reserve(pend_elems));
-      HIPCHK(c, c->d_pend_pre.reserve(pend_elems));
-      // slots start (and are left by every task) all zero
-      HIPCHK(c, hipMemsetAsync(c->d_pend_bits.p, 0, c->d_pend_bits.cap * sizeof(unsigned long long), c->stream));
-      HIPCHK(c, hipMemsetAsync(c->d_pend_pre.p, 0, c->d_pend_pre.cap * sizeof(uint32_t), c->stream));
+    int64_t cap = mult * resident;
+    // test hook: a grid far smaller than the task list makes every persistent wave run many tasks in a row (the per-XCD
+    // task counters, the in-order fetch, the re-initialisation of a wave's LDS state) whatever the chip would hold
+    if (c->plan_ov.grid_cap > 0) cap = std::min<int64_t>(cap, c->plan_ov.grid_cap);
+    if (want > cap) {
+      blocks = (int)std::max<int64_t>(cap, 1);
+      persistent = true;
+      HIPCHK(c, c->d_task_ctr.reserve(8));
+      HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
     }
-    HIPCHK(c, c->d_task_ctr.reserve(8));
-    HIPCHK(c, hipMemsetAsync(c->d_task_ctr.p, 0, 8 * sizeof(int), c->stream));
   }
+  if (c->plan_ov.verbose)
+    fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d%s, tasks=%d (from %d)\n",
+            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount, blocks,
+            persistent ? " (persistent)" : "", count, first);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
-                             pl.pend_global, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, c->d_pend_bits.p,
-                             c->d_pend_pre.p, c->d_task_ctr.p, pl.opts, c->stream));
+                             false, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, nullptr, nullptr,
+                             persistent ? c->d_task_ctr.p : nullptr, pl.opts, c->stream));
   return ICIKT_SUCCESS;
 }
 

@@ -1892,7 +1892,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const int items = (Wp + 63) >> 6;
   const int IT = tl_items(Wp);                              // one pair per wave: words of seen owned by a lane
   const uint32_t magic = tl_magic(IT);
-  static_assert((NP == 1 && HI == 0) || (NP == 2 && HI > 0 && !PG) || (NP == 2 && HI == 0 && PG), "k1_pairs variants");
+  static_assert(!PG && ((NP == 1 && HI == 0) || (NP == 2 && HI > 0) || (NP == 2 && HI == 0)), "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
   constexpr bool fast_ties = !PG;                           // MIXED / GROUP steps instead of the general step
@@ -1909,9 +1909,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // the compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used to keep across the loop in
   // scratch (5.6 KB of spill stores per wave, 1.5 GB per c4 launch) are gone.
   // The kernel has no workgroup barrier, so the waves of a workgroup run independently.
+  // (round 3: the per-wave global pend slots are gone, the persistent grid stays for the whole-wave kernels when the host
+  //  passes task counters -- more tasks than the chip holds waves: a wave that has finished fetches the next task at once
+  //  instead of waiting for the three other waves of its workgroup to retire)
   int task = gwave, t_lo = 0, t_hi = n_tasks;
   int* my_ctr = task_ctr;
-  if (PG) {
+  const bool persist = (HI == 0) && task_ctr != nullptr;   // wave-uniform
+  if (persist) {
     const int ng = min(8, (int)gridDim.x);
     const int xg = (int)blockIdx.x % ng;
     const int chunk = (n_tasks + ng - 1) / ng;
@@ -1962,8 +1966,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     hiG[k] = pv.hirow + ((int64_t)(gcol >> 1) * pv.n_pad) * 2 + (gcol & 1);   // interleaved like rec: index 2 * row
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
-    // (half-wave kernels count a closing group's joint ties with at most four listed groups per lane)
-    ntgB[k] = (!(opts & 2) && ntg_raw <= (half_mode ? min(tg_max, 128) : tg_max)) ? ntg_raw : -1;
+    // (a closing group's joint ties are counted with at most four / two listed groups per lane: half-wave / whole-wave kernels)
+    ntgB[k] = (!(opts & 2) && ntg_raw <= min(tg_max, 128)) ? ntg_raw : -1;
     g_oddtie = g_oddtie || (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
@@ -1971,21 +1975,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     unsigned char* wbase = smem + ((size_t)wave * NP + k) * (size_t)perpair_bytes;
     S[k].L.seen = reinterpret_cast<unsigned long long*>(wbase);
     if (HI == 0) {
-      // one pair per wave: seen | [pend] | two-level counts (loc, lb, hist: TL_BYTES) | [ppre]; L.spre = the counts
-      unsigned long long* after_seen = S[k].L.seen + Wp4;
-      if (PG) {
-        S[k].L.spre = reinterpret_cast<uint16_t*>(after_seen);
-        Pg[k].bits = pend_bits + ((size_t)gwave * NP + k) * (size_t)Wp4;
-        Pg[k].pre = pend_pre + ((size_t)gwave * NP + k) * (size_t)Wp4;
-        Pg[k].pre16 = nullptr;
-        for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
-      } else {
-        Pg[k].bits = after_seen;
-        S[k].L.spre = reinterpret_cast<uint16_t*>(after_seen + Wp4);
-        Pg[k].pre16 = S[k].L.spre + TL_BYTES / 2;
-        Pg[k].pre = nullptr;
-        for (int w = lane; w < Wp4; w += 64) { S[k].L.seen[w] = 0ull; Pg[k].bits[w] = 0ull; Pg[k].pre16[w] = 0; }
-      }
+      // a pair on the whole wave: seen | two-level counts (loc, lb, hist, locg: TL_BYTES); L.spre = the counts.  No `pend`
+      // (round 3): as in the half-wave kernels a tie group of the streamed column is queried first and inserted when it closes
+      S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
+      Pg[k].bits = nullptr; Pg[k].pre16 = nullptr; Pg[k].pre = nullptr;
+      for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
       for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
     } else {
@@ -2063,6 +2057,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool grp_open = false;   // half-wave kernels: likewise; grp_start = first position of the open group
   int grp_start = 0, grp_entries = 0;   // grp_entries: steps of the open group so far
   uint32_t sv_k0 = 0, sv_k1 = 0, sv_h = 0;   // the open group's first step: its rows' values, still in registers when the second step closes it
+  uint32_t sv_kw[NP], sv_hw[NP], sneg[NP];     // whole-wave kernels: the same per pair (lane = row); sneg: what is subtracted from a pair's dis
+#pragma unroll
+  for (int k = 0; k < NP; ++k) { sv_kw[k] = 0u; sv_hw[k] = 0u; sneg[k] = 0u; }
   int pos = 0;
   ICIKT_ST_MARK(6, 0)
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
@@ -2499,10 +2496,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       pre_n0 = n0_next;
     }
     if (fast_ties && !half_mode) {
-      // a GROUP step needs the last position of every row's tie group in the gathered column -> gathered one step
-      // ahead, beside the rec values
-      hi_ok = kind == 2;   // after a GROUP step the next one is most likely a GROUP step too (MIXED steps need no ends)
-      if (hi_ok) hi_pre = gload_u16(hiG[0], 2u * r0);
+      // a GROUP step of a pair in row mode needs the last position of every row's tie group in the gathered column ->
+      // gathered one step ahead, beside the rec values (both columns of the block in one entry)
+      bool any_row = false;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) any_row = any_row || (ntgB[k] < 0);
+      hi_ok = kind == 2 && any_row;   // after a GROUP step the next one is most likely a GROUP step too
+      if (hi_ok) hi_pre = gload_u32(hi_blk, r0);
     }
     if constexpr (half_mode) {
       // the next step is a GROUP step and a pair counts its joint ties row by row: the ends of the rows' tie groups
@@ -2679,32 +2679,154 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         ICIKT_ST_MARK(3, nact)
       }
     } else if constexpr (fast_ties) {
-      // ---- fast tie step of a one-pair kernel with pend in LDS ------------------------------------------------------
-      constexpr int SW = 64;
-      const uint32_t rkS = rk[0], rowS = row;
-      SegState st;
-      st.seen = (lds_u64p)S[0].L.seen;
-      st.spre = (lds_u16p)S[0].L.spre;
-      st.pend = (lds_u64p)Pg[0].bits;
-      SegCounts c;
+      // ---- tie step of a whole-wave kernel: one pair, or two one after the other (they share the streamed column, hence
+      //      the step; lane = row) -----------------------------------------------------------------------------------
       if (kind == 1) {
-        c = seg_mixed_step<SW, HI>(st, F, nact, rkS, IT, magic, lane);
-      } else {
-        // last position of the row's tie group in the gathered column
-        const uint32_t hiA = hi_now_ok ? hi_now : gload_u16(hiG[0], 2u * rowS);
-        const bool rowmode = ntgB[0] < 0;
-        const bool single = closes && !seg_open;   // the group starts and ends in this step
-        c = seg_group_step<SW, HI>(st, nact, single, closes, rowmode, rkS, hiA, seg_cfill, IT, magic, lane);
-        seg_cfill = c.cfill;
-        seg_open = !closes;
-        if (closes) {
-          const bool any_list = ntgB[0] >= 0;
-          if (ntgB[0] > 0) S[0].tie += close_group_ties_lds(Pg[0], tgB[0], ntgB[0], Wp, items, lane);
-          if (!single || any_list) seg_group_close<SW, HI>(st, Wp4, lane);
+        // MIXED: complete groups of at most k1_ks(false) rows; seen and its counts only
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          SegState st;
+          st.seen = (lds_u64p)S[k].L.seen;
+          st.spre = (lds_u16p)S[k].L.spre;
+          st.pend = (lds_u64p)nullptr;
+          const SegCounts c = seg_mixed_step<64, HI>(st, F, nact, rk[k], IT, magic, lane);
+          S[k].dis += c.dis; sneg[k] += c.neg; S[k].tie += c.tie;
         }
+        ICIKT_ST_MARK(2, nact)
+      } else {
+        // GROUP: the design of the half-wave kernels (above) on 64 lanes and the two-level counts -- phase A queries while
+        // `seen` stands still, the group's rows enter `seen` when it closes (one or two steps: from registers, each step's
+        // rows with an incremental update of the counts; longer: streamed again, the counts rebuilt once), joint ties from
+        // range counts before / after (list mode: <= 2 listed groups per lane; row mode: per row, phase C)
+        bool any_row = false;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) any_row = any_row || (ntgB[k] < 0);
+        if (!grp_open) { grp_start = pos_step; grp_entries = 0; }
+        TwoLevel T[NP];
+        uint32_t hk[NP];
+        const uint32_t hv = any_row ? (hi_now_ok ? hi_now : gload_u32(hi_blk, row)) : 0u;
+        auto rangeT = [&](const TwoLevel& Tk, uint32_t r) -> uint32_t {   // r = lo | hi << 16
+          return tl_query(Tk, (r >> 16) + 1u, IT, magic) - tl_query(Tk, r & 0xFFFFu, IT, magic);
+        };
+        auto cell_others = [&](const TwoLevel& Tk, uint32_t kq, uint32_t h) -> uint32_t {
+          return tl_query(Tk, h + 1u, IT, magic) - tl_query(Tk, kq >> 16, IT, magic) - 1u;
+        };
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          T[k] = tl_view(S[k].L.seen, S[k].L.spre);
+          hk[k] = comp[k] ? (hv >> 16) : (hv & 0xFFFFu);
+          // phase A: rows of strictly higher groups below each row's tie group
+          const uint32_t c = valid ? tl_query(T[k], rk[k] >> 16, IT, magic) : 0u;
+          S[k].dis += c;
+          if (ntgB[k] < 0) S[k].tie2 -= valid ? (tl_query(T[k], hk[k] + 1u, IT, magic) - c) : 0u;
+        }
+        if (closes) {
+          const int kept = grp_entries;
+          const int grp_end = pos;                                  // (pos has moved on to the next step)
+          uint32_t bef[NP][2];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              bef[k][i] = 0u;
+              const int g = (int)lane + 64 * i;
+              if (g < ntgB[k]) bef[k][i] = rangeT(T[k], tgB[k][g]);
+            }
+          }
+          wave_lds_fence();
+          // phase B: the group's rows enter `seen`
+          if (kept <= 1) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              if (kept == 1) {
+                seen_insert(S[k].L.seen, sv_kw[k] & 0xFFFFu);
+                tl_update(T[k], true, sv_kw[k] & 0xFFFFu, IT, magic, lane);
+                wave_lds_fence();
+              }
+              if (valid) seen_insert(S[k].L.seen, rk[k] & 0xFFFFu);
+              tl_update(T[k], valid, rk[k] & 0xFFFFu, IT, magic, lane);
+              wave_lds_fence();
+            }
+          } else {
+            uint32_t rw = gload_u16(ord, (uint32_t)grp_start + lane);
+            uint32_t rw_n = gload_u16(ord, (uint32_t)grp_start + 64u + lane);
+            for (int p = grp_start; p < grp_end; p += 64) {
+              uint32_t rkc[NP];
+              if (NP == 2) {
+                const uint2 rv = gload_rec2(rec_blk, rw);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) rkc[k] = comp[k] ? rv.y : rv.x;
+              } else {
+                rkc[0] = gload_u32(rec_blk, 2u * rw + comp[0]);
+              }
+              rw = rw_n;
+              rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
+              if (p + (int)lane < grp_end) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) seen_insert(S[k].L.seen, rkc[k] & 0xFFFFu);
+              }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NP; ++k) tl_rebuild<false>(T[k], nullptr, Wp4, lane);
+            wave_lds_fence();
+          }
+          // list mode: C(rows of the group in the listed tie group, 2)
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int g = (int)lane + 64 * i;
+              if (g < ntgB[k]) {
+                const uint32_t c = rangeT(T[k], tgB[k][g]) - bef[k][i];
+                S[k].tie += c * (c - 1u) / 2u;
+              }
+            }
+          }
+          // phase C (row mode): rows of the group in each row's cell, the row itself excluded
+          if (any_row) {
+            if (kept <= 1) {
+#pragma unroll
+              for (int k = 0; k < NP; ++k) {
+                if (ntgB[k] < 0) {
+                  uint32_t e = valid ? cell_others(T[k], rk[k], hk[k]) : 0u;
+                  if (kept == 1) e += cell_others(T[k], sv_kw[k], sv_hw[k]);
+                  S[k].tie2 += e;
+                }
+              }
+            } else {
+              uint32_t rw = gload_u16(ord, (uint32_t)grp_start + lane);
+              uint32_t rw_n = gload_u16(ord, (uint32_t)grp_start + 64u + lane);
+              for (int p = grp_start; p < grp_end; p += 64) {
+                uint32_t rkc[NP];
+                if (NP == 2) {
+                  const uint2 rv = gload_rec2(rec_blk, rw);
+#pragma unroll
+                  for (int k = 0; k < NP; ++k) rkc[k] = comp[k] ? rv.y : rv.x;
+                } else {
+                  rkc[0] = gload_u32(rec_blk, 2u * rw + comp[0]);
+                }
+                const uint32_t hvc = gload_u32(hi_blk, rw);
+                rw = rw_n;
+                rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
+                const bool w = p + (int)lane < grp_end;
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                  if (ntgB[k] < 0) S[k].tie2 += w ? cell_others(T[k], rkc[k], comp[k] ? (hvc >> 16) : (hvc & 0xFFFFu)) : 0u;
+              }
+            }
+          }
+          grp_open = false;
+        } else {
+          if (grp_entries == 0) {   // (a step that does not close has 64 rows)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { sv_kw[k] = rk[k]; sv_hw[k] = hk[k]; }
+          }
+          ++grp_entries;
+          grp_open = true;
+        }
+        ICIKT_ST_MARK(3, nact)
       }
-      dis_half += c.dis; dis_half_neg += c.neg; seg_tie += c.tie; seg_tie2 += c.tie2;
-      if (kind == 1) { ICIKT_ST_MARK(2, nact) } else { ICIKT_ST_MARK(3, nact) }
     } else {
     // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
     {
@@ -2772,51 +2894,42 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(mine ? tl : 0u);
       }
     } else {
-    // The group's bitset: pend in LDS where the kernel has one.  With pend in global memory (long columns) the
-    // tail uses `seen` instead -- nothing queries it any more -- so that the rows missing in the streamed column
-    // cost LDS atomics, not one global atomic each (measured on the full c5 matrix, whose 1 GB of prepared state
-    // pushes the per-wave pend slots out of the Infinity Cache: 1.8e6 -> see DESIGN.md pairs/s).
-    PendG Pt[NP];
+      // Whole-wave kernels: the same -- every row that is not in `seen` by now belongs to this last group, so it has
+      // (size of g) - (rows of g in seen) rows in a listed tie group g of the gathered column; its rows only gather and
+      // add their lo.
+      uint32_t tl[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (PG) {
-        Pt[k].bits = S[k].L.seen;
-        Pt[k].pre16 = S[k].L.spre;
-        Pt[k].pre = nullptr;
-        if (ntgB[k] > 0)
-          for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
-      } else {
-        Pt[k] = Pg[k];
+      for (int k = 0; k < NP; ++k) {
+        const TwoLevel Tk = tl_view(S[k].L.seen, S[k].L.spre);
+        tl[k] = 0u;
+        for (int g = (int)lane; g < ntgB[k]; g += 64) {
+          const uint32_t r = tgB[k][g];
+          const uint32_t in_seen = tl_query(Tk, (r >> 16) + 1u, IT, magic) - tl_query(Tk, r & 0xFFFFu, IT, magic);
+          const uint32_t c = (r >> 16) - (r & 0xFFFFu) + 1u - in_seen;
+          tl[k] += c * (c - 1u) / 2u;
+        }
+        S[k].tie += tl[k];
       }
-    }
-    wave_lds_fence();
-    uint32_t row_next = r0;
-    for (int p = last_start; p < n; p += 64) {
-      const int kpos = p + (int)lane;
-      uint32_t rk[NP];
-      if (NP == 2) {
-        const uint2 rv = gload_rec2(rec_blk, row_next);
+      uint32_t row_next = r0;
+      for (int p = last_start; p < n; p += 64) {
+        const int kpos = p + (int)lane;
+        uint32_t rkt[NP];
+        if (NP == 2) {
+          const uint2 rv = gload_rec2(rec_blk, row_next);
 #pragma unroll
-        for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
-      } else {
-        rk[0] = gload_u32(rec_blk, 2u * row_next + comp[0]);
-      }
-      row_next = gload_u16(ord, (uint32_t)(kpos + 64));
-      if (kpos < n) {
+          for (int k = 0; k < NP; ++k) rkt[k] = comp[k] ? rv.y : rv.x;
+        } else {
+          rkt[0] = gload_u32(rec_blk, 2u * row_next + comp[0]);
+        }
+        row_next = gload_u16(ord, (uint32_t)(kpos + 64));
+        if (kpos < n) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          S[k].dis += rk[k] >> 16;
-          if (ntgB[k] > 0) p_or<false>(Pt[k], (int)((rk[k] & 0xFFFFu) >> 6), 1ull << (rk[k] & 63u));
+          for (int k = 0; k < NP; ++k) S[k].dis += rkt[k] >> 16;
         }
       }
-    }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const uint32_t tl = (ntgB[k] > 0) ? close_group_ties<false>(Pt[k], tgB[k], ntgB[k], Wp, items, lane) : 0u;
-      S[k].tie += tl;
       const unsigned long long m = (unsigned long long)(n - last_start);
-      corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl);
-    }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) corr[k] = m * (m - 1ull) / 2ull - wave_sum_u64(tl[k]);
     }
     ICIKT_ST_MARK(5, n - last_start)
   }
@@ -2825,7 +2938,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   for (int k = 0; k < NP; ++k) {
     const bool mine = (NP == 1) || ((lane >= 32u) == (k == NP - 1));   // per-lane accumulators of this pair
     const unsigned long long dis = wave_sum_u64(S[k].dis) + wave_sum_u64(mine ? dis_half : 0u) +
-                                   0ull - wave_sum_u64(mine ? dis_half_neg : 0u) - corr[k];
+                                   0ull - wave_sum_u64(mine ? dis_half_neg : 0u) - wave_sum_u64(sneg[k]) - corr[k];
     const unsigned long long ntie = wave_sum_u64(S[k].tie) + wave_sum_u64(mine ? seg_tie : 0u) +
                                     ((wave_sum_u64(S[k].tie2) + wave_sum_u64(mine ? seg_tie2 : 0u)) >> 1);
     const unsigned long long cbs = wave_sum_u64(cb[k]);
@@ -2842,12 +2955,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   wave_lds_fence();
   ICIKT_ST_MARK(6, 0)
   ICIKT_ST_FLUSH
-    if (PG) {
+    if (persist) {
       int t = 0;
       if (lane == 0u) t = atomicAdd(my_ctr, 1);
       task = t_lo + __builtin_amdgcn_readfirstlane(t);
     }
-  } while (PG && task < t_hi);  // task loop
+  } while (persist && task < t_hi);  // task loop
 }
 
 
@@ -3482,9 +3595,10 @@ static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
       default: break;
     }
   }
-  if (np == 2 && pend_global && half_items == 0) return &k1_pairs<2, true, 0>;
+  if (pend_global) return nullptr;   // (no kernel keeps an open-group bitset any more)
+  if (np == 2 && half_items == 0) return &k1_pairs<2, false, 0>;
   if (np != 1) return nullptr;
-  return pend_global ? &k1_pairs<1, true, 0> : &k1_pairs<1, false, 0>;
+  return &k1_pairs<1, false, 0>;
 }
 
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,

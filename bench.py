@@ -185,7 +185,7 @@ def _pmc_pass(config: str, counters, outdir: str, timeout_s: int):
     return {c: sum(v) / len(v) for c, v in agg.items()}, info   # one row per dispatch and counter: the mean per dispatch
 
 
-K1_KERNEL_OF = {"c3": "k1_pairsILi2ELb0ELi5", "c4": "k1_pairsILi2ELb0ELi5", "c5": "k1_pairsILi2ELb1ELi0"}   # plan_k1's choice
+K1_KERNEL_OF = {"c3": "k1_pairsILi2ELi5E", "c4": "k1_pairsILi2ELi5E", "c5": "k1_pairsILi2ELi0E"}   # plan_k1's choice
 
 
 def static_valu_mix(config: str):

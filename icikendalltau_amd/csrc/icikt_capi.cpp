@@ -87,7 +87,6 @@ int timer_end(icikt_ctx* c, int k, uint32_t flags) {
 // launch plan of the pair kernel for a given n
 struct K1Plan {
   int np;            // pairs per wave: 2 (one per half, consecutive pairs with the same pi) or 1
-  bool pend_global;  // open-group bitset in global memory (long columns) instead of LDS
   int wpb;           // waves per workgroup
   size_t lds_bytes;
   int perpair_bytes;
@@ -119,7 +118,6 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
   // 780 pairs, 0.209 vs 0.230 ms, two pairs per wave from 1 128 pairs on, 0.231 vs 0.242 ms)
   if (n_pairs <= (int64_t)4 * n_cu) np = 1;
-  pl.pend_global = false;
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable)
   if (ov.np == 1 || ov.np == 2) np = ov.np;
   int wpb = 4;
@@ -277,7 +275,7 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   int per_cu = 0;
   bool persistent = false;
   if (pl.half_items == 0) {
-    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, false, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
+    HIPCHK(c, icikt::k1_blocks_per_cu(pl.np, pl.half_items, pl.wpb, pl.lds_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
     const int64_t resident = (int64_t)per_cu * c->prop.multiProcessorCount;
     const int64_t mult = c->plan_ov.grid_mult > 0 ? c->plan_ov.grid_mult : 1;
@@ -297,7 +295,7 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
             pl.np, pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount, blocks,
             persistent ? " (persistent)" : "", count, first);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
-                             false, pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes, nullptr, nullptr,
+                             pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes,
                              persistent ? c->d_task_ctr.p : nullptr, pl.opts, c->stream));
   return ICIKT_SUCCESS;
 }
@@ -362,7 +360,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
   c->tgroups.release(); c->tprog.release(); c->tmask.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
-  c->d_pend_bits.release(); c->d_pend_pre.release(); c->d_task_ctr.release();
+  c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
   c->d_out5.release(); c->d_keep.release(); c->d_red.release(); c->d_pi_all.release(); c->d_pj_all.release();
   for (int k = 0; k < ICIKT_K_COUNT; ++k)
@@ -1515,12 +1513,6 @@ int icikt_selftest(icikt_ctx* c) {
       if (c->plan_ov.verbose) fprintf(stderr, "[icikt] selftest lane %u: lane_xor pass mask %u\n", l, h[448 + l]);
       return fail(c, ICIKT_E_HIP, "selftest: lane_xor mismatch");
     }
-    if (l > 0 && h[512 + l] < h[512 + l - 1]) return fail(c, ICIKT_E_HIP, "selftest: wave_sort_u32 not sorted");
-  }
-  {  // the sort is a permutation of its input
-    unsigned long long want = 0, got = 0;
-    for (uint32_t l = 0; l < 64; ++l) { want += (l * 2654435761u) >> 8; got += h[512 + l]; }
-    if (want != got) return fail(c, ICIKT_E_HIP, "selftest: wave_sort_u32 lost values");
   }
   // half-wave all-pairs: per 32-lane half, #{(a, j): a before j, q_a < lo_j}; the lanes' shares are summed
   for (uint32_t half = 0; half < 2; ++half) {

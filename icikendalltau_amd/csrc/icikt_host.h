@@ -61,8 +61,6 @@ struct icikt_ctx {
   bool raw_valid = false;  // d_raw holds the pair kernel's counts for the current prepared matrix and pair list
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<icikt::PairRaw> d_raw;
-  DevBuf<unsigned long long> d_pend_bits;  // per launched wave and pair: open-group bitset (global)
-  DevBuf<uint32_t> d_pend_pre;
   DevBuf<int> d_task_ctr;  // persistent pair kernel: one task counter per XCD group, zeroed before every launch
   std::vector<int32_t> h_pi, h_pj, h_units;
   // a combn range [combn_begin, combn_end) of combn(combn_S, 2) set by icikt_set_pairs_combn: the device arrays are

@@ -875,149 +875,14 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
 // Rows that enter `seen` together are compared all-pairs in registers: DPP shifts inside a 16-lane row and
 // balanced rotations between rows (wave_allpairs: 64 rows of one pair; half_allpairs: 32 rows of each of
 // two pairs), one v_sub_co_u32_dpp + v_addc_co_u32 per compare.
-// Rows of an A tie group that is still open wait in `pend` (prefix ppre) and are merged when the group
-// closes; pend also yields the joint ties (compare_both, kendallc.cpp:33-51) of groups spanning steps.
+// The rows of an A tie group are queried while `seen` stands still and inserted together when the group closes (GROUP
+// steps); its joint ties (compare_both, kendallc.cpp:33-51) come from range counts of `seen` before and after.
+// (Rounds 1-2 kept the open group's rows in a second bitset `pend` -- in LDS, or in per-wave global slots with a
+// persistent grid for long columns -- and a general out-of-line step that re-sorted the lanes of mixed steps.)
 struct WaveLds {
   unsigned long long* seen;
   uint16_t* spre;
 };
-
-// `pend` and its prefix live in LDS beside seen/spre for short columns; for long ones (PG = true) they
-// live in GLOBAL memory, one private slot per launched wave and pair: only steps that meet a tie group of
-// the streamed column touch them (on continuous data: the missing-value group), and keeping them out of
-// LDS halves the per-pair LDS state when that state is what limits the waves per CU.  A global slot is
-// all zero between tasks (every open group is merged at the latest in the last step).  Lanes of the wave
-// hand data to each other through it, so reads bypass the CU's L1 (agent-scope relaxed atomics = sc1) and
-// phases are separated by s_waitcnt vmcnt(0).  Measured: global pend costs c4 (10 % missing, n = 10 000)
-// +50 % and gains c5 (n = 50 000) 15 %.
-struct PendG {
-  unsigned long long* bits;
-  uint32_t* pre;     // PG = true : u32 prefix in global memory
-  uint16_t* pre16;   // PG = false: u16 prefix in LDS
-};
-
-__device__ __forceinline__ unsigned long long g_ld64(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t g_ld32(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void g_st64(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void g_st32(uint32_t* p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void g_or64(unsigned long long* p, unsigned long long v) {
-  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// pend accessors: PG selects global (L1-bypassing) or LDS
-template <bool PG> __device__ __forceinline__ unsigned long long p_ld(const PendG& P, int w) {
-  return PG ? g_ld64(&P.bits[w]) : P.bits[w];
-}
-template <bool PG> __device__ __forceinline__ void p_st(const PendG& P, int w, unsigned long long v) {
-  if (PG) g_st64(&P.bits[w], v); else P.bits[w] = v;
-}
-template <bool PG> __device__ __forceinline__ void p_or(const PendG& P, int w, unsigned long long v) {
-  if (PG) g_or64(&P.bits[w], v); else atomicOr(&P.bits[w], v);
-}
-template <bool PG> __device__ __forceinline__ uint32_t p_ldpre(const PendG& P, int w) {
-  return PG ? g_ld32(&P.pre[w]) : (uint32_t)P.pre16[w];
-}
-template <bool PG> __device__ __forceinline__ void p_stpre(const PendG& P, int w, uint32_t v) {
-  if (PG) g_st32(&P.pre[w], v); else P.pre16[w] = (uint16_t)v;
-}
-template <bool PG> __device__ __forceinline__ void wave_pend_fence() {
-  if (PG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// prefix popcounts of bits[0..Wp) (LDS); optionally first merges the pend bitset merge_from into bits
-// and clears it.
-// Lane l owns words [l*items, (l+1)*items).
-template <bool PG>
-__device__ __forceinline__ void rebuild_prefix(unsigned long long* bits, uint16_t* pre,
-                                               const PendG* merge_from, int Wp, int items,
-                                               uint32_t lane) {
-  const int base = (int)lane * items;
-  if (items <= 4) {
-    uint32_t pc[4];
-    uint32_t local = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = base + i;
-      pc[i] = 0;
-      if (i < items && w < Wp) {
-        unsigned long long v = bits[w];
-        if (merge_from) {
-          v |= p_ld<PG>(*merge_from, w);
-          bits[w] = v;
-          p_st<PG>(*merge_from, w, 0ull);
-        }
-        pc[i] = (uint32_t)__popcll(v);
-      }
-      local += pc[i];
-    }
-    uint32_t run = wave_incl_scan(local) - local;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = base + i;
-      if (i < items && w < Wp) pre[w] = (uint16_t)run;
-      run += pc[i];
-    }
-    return;
-  }
-  uint32_t local = 0;
-  for (int i = 0; i < items; ++i) {
-    const int w = base + i;
-    if (w < Wp) {
-      unsigned long long v = bits[w];
-      if (merge_from) {
-        v |= p_ld<PG>(*merge_from, w);
-        bits[w] = v;
-        p_st<PG>(*merge_from, w, 0ull);
-      }
-      local += (uint32_t)__popcll(v);
-    }
-  }
-  uint32_t run = wave_incl_scan(local) - local;
-  for (int i = 0; i < items; ++i) {
-    const int w = base + i;
-    if (w < Wp) {
-      pre[w] = (uint16_t)run;
-      run += (uint32_t)__popcll(bits[w]);
-    }
-  }
-}
-
-__device__ __forceinline__ uint32_t prefix_query(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
-  const uint32_t w = pos >> 6;
-  return (uint32_t)pre[w] + (uint32_t)__popcll(bits[w] & low_mask64(pos & 63u));
-}
-
-template <bool PG>
-__device__ __forceinline__ uint32_t pend_query(const PendG& P, uint32_t pos) {
-  const int w = (int)(pos >> 6);
-  return p_ldpre<PG>(P, w) + (uint32_t)__popcll(p_ld<PG>(P, w) & low_mask64(pos & 63u));
-}
-
-template <bool PG>
-__device__ __forceinline__ void pend_rebuild(const PendG& P, int Wp, int items, uint32_t lane) {
-  const int base = (int)lane * items;
-  uint32_t local = 0;
-  for (int i = 0; i < items; ++i) {
-    const int w = base + i;
-    if (w < Wp) local += (uint32_t)__popcll(p_ld<PG>(P, w));
-  }
-  uint32_t run = wave_incl_scan(local) - local;
-  for (int i = 0; i < items; ++i) {
-    const int w = base + i;
-    if (w < Wp) {
-      p_stpre<PG>(P, w, run);
-      run += (uint32_t)__popcll(p_ld<PG>(P, w));
-    }
-  }
-}
 
 // ---- half-wave hot step: one pair per 32-lane half, 32 rows per sub-step --------------------------
 // In-step all-pairs without a shift chain: VOP2 instructions take a DPP control on src0, and inside a
@@ -1345,10 +1210,9 @@ __device__ __forceinline__ void tl_update_rows(const TwoLevel& T, uint32_t q) {
   atomicAdd(reinterpret_cast<unsigned long long*>(T.locg) + o, 0x0001000100010000ull << (16u * (j >> 2)));
 }
 
-// Recompute loc, locg and lb from the words of seen (optionally OR-ing `merge_from` into seen first and clearing it).
-// NW: words of seen (and of the pend array) that exist (even: k1_lds_stride); owners past them own nothing.
-template <bool PG>
-__device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge_from, int NW, uint32_t lane) {
+// Recompute loc, locg and lb from the words of seen (after a long tie group's rows have been OR-ed into it).
+// NW: words of seen that exist (even: k1_lds_stride); owners past them own nothing.
+__device__ __forceinline__ void tl_rebuild(const TwoLevel& T, int NW, uint32_t lane) {
   constexpr int IT = 16;
   const uint32_t base = lane * (uint32_t)IT;
   ulonglong2* b2 = reinterpret_cast<ulonglong2*>(T.seen + base);
@@ -1358,16 +1222,7 @@ __device__ __forceinline__ void tl_rebuild(const TwoLevel& T, const PendG* merge
   for (int i = 0; i < (IT >> 1); ++i) {
     const int w = (int)base + 2 * i;
     ulonglong2 v = make_ulonglong2(0ull, 0ull);
-    if (w < NW) {
-      v = b2[i];
-      if (merge_from) {
-        v.x |= p_ld<PG>(*merge_from, w);
-        v.y |= p_ld<PG>(*merge_from, w + 1);
-        b2[i] = v;
-        p_st<PG>(*merge_from, w, 0ull);
-        p_st<PG>(*merge_from, w + 1, 0ull);
-      }
-    }
+    if (w < NW) v = b2[i];
     if ((i & 1) == 0) {  // words 2i, 2i+1 open group i / 2
       grun = run;
       gpack |= (unsigned long long)grun << (16 * (i >> 1));
@@ -1438,231 +1293,26 @@ __device__ __forceinline__ void rebuild_prefix_half(const unsigned long long* bi
   half_pre_store<HI>(pre, l, half_incl_scan(run), c);
 }
 
-template <int K, int J>
-__device__ __forceinline__ uint32_t wave_sort_stage(uint32_t v, uint32_t lane) {
-  const uint32_t other = lane_xor<J>(v, lane);
-  const bool up = (lane & (uint32_t)K) == 0u;  // K == 64: every lane
-  const bool lower = (lane & (uint32_t)J) == 0u;
-  return (lower == up) ? min(v, other) : max(v, other);
-}
-__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t v, uint32_t lane) {
-  v = wave_sort_stage<2, 1>(v, lane);
-  v = wave_sort_stage<4, 2>(v, lane); v = wave_sort_stage<4, 1>(v, lane);
-  v = wave_sort_stage<8, 4>(v, lane); v = wave_sort_stage<8, 2>(v, lane); v = wave_sort_stage<8, 1>(v, lane);
-  v = wave_sort_stage<16, 8>(v, lane); v = wave_sort_stage<16, 4>(v, lane); v = wave_sort_stage<16, 2>(v, lane);
-  v = wave_sort_stage<16, 1>(v, lane);
-  v = wave_sort_stage<32, 16>(v, lane); v = wave_sort_stage<32, 8>(v, lane); v = wave_sort_stage<32, 4>(v, lane);
-  v = wave_sort_stage<32, 2>(v, lane); v = wave_sort_stage<32, 1>(v, lane);
-  v = wave_sort_stage<64, 32>(v, lane); v = wave_sort_stage<64, 16>(v, lane); v = wave_sort_stage<64, 8>(v, lane);
-  v = wave_sort_stage<64, 4>(v, lane); v = wave_sort_stage<64, 2>(v, lane); v = wave_sort_stage<64, 1>(v, lane);
-  return v;
-}
-
 // state of one pair inside a wave
 struct PairState {
   WaveLds L;
   uint32_t dis, tie, tie2;
 };
 
-// General step of one pair on all 64 lanes, after the `seen` query.  k1_pairs cuts steps at tie-group
-// boundaries of the streamed column, so a step is either (a) up to 64 rows of complete groups (F & 1 set, Fn
-// true: nothing stays open) or (b) a piece of one group that is longer than a step (F == 1 with !Fn: its first
-// piece; F == 0: a later piece, the last one when Fn).  The code below also covers an open group that closes
-// in the middle of a step followed by further groups, which that cutting never produces.  Rare on continuous
-// data, so it is a real (noinline) call that takes its state by value and returns the three counter
-// increments: the hot step's registers stay small.
-struct StepCounts { uint32_t dis, tie, tie2; };
-struct StepAcc { WaveLds L; uint32_t dis, tie, tie2; };
-
-// Joint ties of an A tie group that is complete in pend (its rows' B-positions): for every tie group of B
-// (list tg, ntg entries) the rows in it contribute C(c, 2).  Rebuilds pend's prefix first.
-template <bool PG>
-__device__ __forceinline__ uint32_t close_group_ties(const PendG& Pg, const uint32_t* tg, int ntg, int Wp, int items,
-                                                     uint32_t lane) {
-  wave_pend_fence<PG>();
-  wave_lds_fence();
-  pend_rebuild<PG>(Pg, Wp, items, lane);
-  wave_pend_fence<PG>();
-  wave_lds_fence();
-  uint32_t t = 0;
-  for (int g = (int)lane; g < ntg; g += 64) {
-    const uint32_t r = tg[g];
-    const uint32_t c = pend_query<PG>(Pg, (r >> 16) + 1u) - pend_query<PG>(Pg, r & 0xFFFFu);
-    t += c * (c - 1u) / 2u;
-  }
-  return t;
-}
-
-template <bool PG, bool LONGR>
-__device__ __attribute__((noinline)) StepCounts pair_step_rest(const WaveLds Lw, const PendG Pg,
-                                                               const unsigned long long F,
-                                                               const bool Fn, const bool valid,
-                                                               uint32_t row, uint32_t q, uint32_t lo,
-                                                               const uint16_t* hiG, const uint32_t* tg, const int ntg,
-                                                               const int Wp, const int items,
-                                                               const uint32_t lane) {
-  // Two ways to count the joint ties (compare_both, kendallc.cpp:33-51) of an A tie group that spans steps:
-  //   list mode (ntg >= 0): B has few tie groups; the group's rows just collect in pend and, when the group
-  //     closes, each tie group of B contributes C(rows of the group inside it, 2).  A step inside the
-  //     missing-value group of A then costs one query and one atomic OR.
-  //   row mode (ntg < 0): every row asks pend how many earlier rows of its A group share its B group.
-  const bool list = ntg >= 0;
-  StepAcc S;
-  S.L = Lw; S.dis = 0; S.tie = 0; S.tie2 = 0;
-  // one pair per wave (LONGR): seen's counts are the two-level structure; half-wave kernels: the flat prefix
-  const int IT = tl_items(Wp);
-  const uint32_t magic = tl_magic(IT);
-  auto merge_pend_into_seen = [&]() {
-    if (LONGR) tl_rebuild<PG>(tl_view(S.L.seen, S.L.spre), &Pg, k1_lds_stride(Wp, 0), lane);
-    else rebuild_prefix<PG>(S.L.seen, S.L.spre, &Pg, Wp, items, lane);
-  };
-  const int first_start = (F != 0ull) ? (int)__builtin_ctzll(F) : 64;
-  const int last_start = (F != 0ull) ? 63 - (int)__builtin_clzll(F) : 0;
-  const bool olane = valid && ((int)lane < first_start);          // rows of the group open from earlier steps
-  const bool tlane = valid && (F != 0ull) && ((int)lane >= last_start);  // rows of the step's last group
-  // (2) pairs inside this step
-  if (F == ~0ull) {
-    // every lane starts its own group: no ties in the streamed column in this step (64 valid lanes)
-    S.dis += wave_allpairs(q, lo, lane);
-  } else if (F != 0ull) {
-    // mixed step: several tie groups of the streamed column (contiguous lane ranges) in one step.  Rows tied
-    // in the streamed column are not discordant, and rows tied in both columns are joint ties.  The order of
-    // the rows INSIDE a group is free, so the lanes are first re-sorted by (group, q descending): then for two
-    // rows of one group the earlier lane has the larger q, "q_a < lo_j" is false by itself, and the plain
-    // all-pairs count of the step is already the count over different groups; rows of one group that share a
-    // tie group of the gathered column become neighbours, so the joint ties are run lengths.  q, lo and row
-    // keep their new lanes for the rest of the step (group membership per lane is unchanged).
-    const uint32_t xg = (uint32_t)__popcll(F & ((2ull << lane) - 1ull));   // 1..64, non-decreasing over the lanes
-    const uint32_t key = valid ? ((xg << 22) | ((0xFFFFu - (q & 0xFFFFu)) << 6) | lane) : 0xFFFFFFFFu;
-    const uint32_t src = (wave_sort_u32(key, lane) & 63u) << 2;          // invalid lanes stay behind the valid ones
-    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)q);
-    const uint32_t lo2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)lo);
-    const uint32_t row2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)row);
-    if (valid) { q = q2; lo = lo2; row = row2; }
-    S.dis += wave_allpairs(q, valid ? lo : 0u, lane);
-    // joint ties inside the step: earlier lanes of my run of equal (group, lo)
-    const uint32_t pk = valid ? ((xg << 16) | lo) : 0xFFFFFFFFu;
-    const uint32_t pprev = dpp_wave_shr1(0xFFFFFFFEu, pk);
-    const unsigned long long starts = __ballot(!valid || pk != pprev);
-    const unsigned long long upto = starts & ((2ull << lane) - 1ull);      // lane 0 is always a start
-    const uint32_t c3 = lane - (63u - (uint32_t)__builtin_clzll(upto));
-    // list mode: groups that pass through pend are counted when they close, not here
-    const bool counted_here = list ? (valid && !olane && (Fn || !tlane)) : valid;
-    S.tie += counted_here ? c3 : 0u;
-  }
-  // F == 0: the whole step lies inside one open group: nothing is discordant in-step
-
-  // (3) rows of a group that is still open from earlier steps
-  uint32_t ph = 0, ebefore = 0;
-  if ((F & 1ull) == 0ull) {
-    if (list) {
-      if (F != 0ull) {
-        // the open group closes in this step: rows of the later groups also see its earlier rows (in pend)
-        wave_pend_fence<PG>();
-        pend_rebuild<PG>(Pg, Wp, items, lane);
-        wave_pend_fence<PG>();
-        wave_lds_fence();
-        if (valid && !olane) S.dis += pend_query<PG>(Pg, lo);
-      }
-    } else if (olane) {
-      // joint ties with the group's rows of earlier steps
-      ph = (uint32_t)hiG[2u * row] + 1u;
-      ebefore = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
-      S.tie += ebefore;
-    } else if (valid) {
-      // rows of later groups of this step also see the open group's earlier rows, still in pend
-      S.dis += pend_query<PG>(Pg, lo);
-    }
-  }
-
-  // (4) insert this step's rows
-  wave_lds_fence();
-  wave_pend_fence<PG>();
-  const unsigned long long bit = 1ull << (q & 63u);
-  const uint32_t qw = (q & 0xFFFFu) >> 6;
-  if (F == 0ull) {
-    if (valid) p_or<PG>(Pg, (int)qw, bit);
-    if (list) {
-      if (Fn) {
-        S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
-        wave_pend_fence<PG>();
-        merge_pend_into_seen();
-      }
-    } else {
-      wave_pend_fence<PG>();
-      pend_rebuild<PG>(Pg, Wp, items, lane);
-      wave_pend_fence<PG>();
-      // in-step joint ties: sum over rows of (#rows of this step in the same tie group of the gathered
-      // column, itself included) = after - before; twice the tie count is that sum minus the rows
-      if (valid) {
-        const uint32_t after = pend_query<PG>(Pg, ph) - pend_query<PG>(Pg, lo);
-        S.tie2 += after - ebefore - 1u;
-      }
-      if (Fn) {
-        wave_pend_fence<PG>();
-        merge_pend_into_seen();
-      }
-    }
-  } else {
-    const bool ins_seen = !olane && valid && (Fn || !tlane);
-    if (olane) p_or<PG>(Pg, (int)qw, bit);
-    else if (ins_seen) atomicOr(&S.L.seen[qw], bit);
-    if (list && (F & 1ull) == 0ull) S.tie += close_group_ties<PG>(Pg, tg, ntg, Wp, items, lane);
-    wave_lds_fence();
-    wave_pend_fence<PG>();
-    if ((F & 1ull) == 0ull) {
-      merge_pend_into_seen();
-    } else if (LONGR) {  // nothing to merge: the inserted rows update the counts
-      tl_update(tl_view(S.L.seen, S.L.spre), ins_seen, q, IT, magic, lane);
-    } else {
-      rebuild_prefix<PG>(S.L.seen, S.L.spre, nullptr, Wp, items, lane);
-    }
-    if (!Fn) {
-      wave_pend_fence<PG>();
-      if (tlane) p_or<PG>(Pg, (int)qw, bit);
-      if (!list) {
-        wave_pend_fence<PG>();
-        pend_rebuild<PG>(Pg, Wp, items, lane);
-      }
-    }
-  }
-  wave_lds_fence();
-  wave_pend_fence<PG>();
-  StepCounts out;
-  out.dis = S.dis; out.tie = S.tie; out.tie2 = S.tie2;
-  return out;
-}
-
-// out-of-line form for the fast tie steps (keeps the hot loop's register allocation independent of it)
-__device__ __attribute__((noinline)) uint32_t close_group_ties_lds(const PendG Pg, const uint32_t* tg, const int ntg,
-                                                                   const int Wp, const int items, const uint32_t lane) {
-  return close_group_ties<false>(Pg, tg, ntg, Wp, items, lane);
-}
-
-// ---- fast tie steps (pend in LDS: half-wave kernels and one pair per wave up to n ~ 25 000) ---------------------
-// The general step above runs ONE pair on 64 lanes and re-sorts the lanes of a step that holds several tie groups
-// (21 exchange stages), which made tied data 3 .. 4 times slower than continuous data.  Two cheaper step kinds
-// cover every flag pattern; a "segment" is the lanes of one pair: a 32-lane half (two pairs per wave advance
-// together, as in the hot step) or the whole wave.
-//   MIXED  up to SEG rows of COMPLETE groups of at most k1_ks() rows each.  The plain all-pairs count of the step
-//          also counts pairs inside a group; those are the pairs (lane - d, lane), d = 1 .. group size - 1, so d
-//          whole-wave shifts of q and lo give, per lane, the spurious count (q_prev < lo_me) and the joint ties
-//          (lo_prev == lo_me).  The loop ends with the largest group of the step: no sort.
-//   GROUP  up to SEG rows of ONE group (a piece of it, or all of it).  Rows of one group are never discordant with
-//          each other: no all-pairs at all.  They collect in `pend` and are merged into `seen` when the group
-//          closes.  Joint ties = for every row the rows of the group in its tie group [lo, hi] of the gathered
-//          column: popcounts of the one .. few words of pend that the range covers, before the step's rows are
-//          inserted (earlier pieces) and after (this piece: each pair seen from both sides, hence tie2); the cell
-//          lo == 0 (the gathered column's fill group, the one range that is routinely hundreds of words long) is a
-//          running count per group instead.  No prefix over pend is ever built.
+// ---- tie steps of the whole-wave kernels ------------------------------------------------------------------------
+//   MIXED  up to 64 rows of COMPLETE groups of at most k1_ks(false) rows each (seg_mixed_step).  The plain all-pairs
+//          count of the step also counts pairs inside a group; those are the pairs (lane - d, lane), d = 1 .. group
+//          size - 1, so d whole-wave shifts of q and lo give, per lane, the spurious count (q_prev < lo_me) and the
+//          joint ties (lo_prev == lo_me).  The loop ends with the largest group of the step: no sort.
+//   GROUP  up to 64 rows of ONE group (a piece of it, or all of it): in k1_pairs, the design of the half-wave kernels.
 typedef __attribute__((address_space(3))) unsigned long long* lds_u64p;
 typedef __attribute__((address_space(3))) uint16_t* lds_u16p;
 // MIXED steps take groups of up to this many rows (the correction loop costs ~10 instructions per row of the
 // step's largest group); longer groups get GROUP steps of their own.  A whole wave amortises a longer loop.
 __host__ __device__ constexpr int k1_ks(bool half) { return half ? 32 : 20; }
 
-struct SegState {   // per-lane LDS views of the lane's pair
-  lds_u64p seen, pend;
+struct SegState {   // LDS views of a pair
+  lds_u64p seen;
   lds_u16p spre;
 };
 struct SegCounts { uint32_t dis, neg, tie, tie2, cfill; };
@@ -1729,113 +1379,6 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
   return c;
 }
 
-// MIXED step of a half-wave kernel: two sub-steps of up to 32 rows of COMPLETE groups each (no group straddles them:
-// k0_tie_program), BOTH pairs.  It is the hot step on those rows -- lanes past a sub-step's rows carry q = 64 W (a
-// position in the guard word of `seen`, above every real one) and lo = 0: they never count, are never counted, query 0
-// and insert a bit no query reaches -- with two changes to the in-step pairs: the flags of pairs INSIDE a tie group
-// (PrepView::tmask, cut once per column by the pre-pass) do not count as discordant, and a second chain in the other
-// direction tells which of those pairs are joint ties: rows of one group of the streamed column with neither
-// q_a < lo_j nor q_j < lo_a share a tie group of the gathered column (its groups are disjoint position ranges).
-// Cost: the hot step + one more chain + ~15 instructions, whatever the sizes of the groups (round 2: a shift loop of
-// 14 instructions per row of the step's largest group).
-// GROUP step.  `single`: the group starts and ends in this step (wave-uniform).  `rowmode` (per lane = per pair):
-// joint ties are counted row by row from cell popcounts; otherwise (the gathered column has few tie groups, which
-// may be thousands of rows long) the rows only collect in pend and the caller counts them from the column's tie
-// group list when the group closes (close_group_ties).  A single-step group of a row-mode pair needs no pend at
-// all: its rows are inserted into `seen` directly and "after - before" cancels the rows of earlier groups.
-template <int SEG, int HI>
-__device__ __forceinline__ SegCounts seg_group_step(const SegState st, const int nact_in, const bool single_in,
-                                                              const bool closes_in, const bool rowmode, const uint32_t rk,
-                                                              const uint32_t hi_in, const uint32_t cfill, const int IT_in,
-                                                              const uint32_t magic_in, const uint32_t lane) {
-  const int nact = __builtin_amdgcn_readfirstlane(nact_in);   // wave-uniform arguments back to scalar registers
-  const bool single = __builtin_amdgcn_readfirstlane((int)single_in) != 0;
-  const bool closes = __builtin_amdgcn_readfirstlane((int)closes_in) != 0;
-  const int IT = __builtin_amdgcn_readfirstlane(IT_in);
-  const uint32_t magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)magic_in);
-  unsigned long long* seen = (unsigned long long*)st.seen;
-  uint16_t* spre = (uint16_t*)st.spre;
-  const uint32_t sl = (SEG == 32) ? (lane & 31u) : lane;
-  const bool valid = (int)sl < nact;
-  const uint32_t q = valid ? (rk & 0xFFFFu) : 0xFFFFFFFFu;
-  const uint32_t lo = valid ? (rk >> 16) : 0u;
-  const uint32_t hi = valid ? hi_in : 0u;
-  const bool direct = single && rowmode;                       // per lane
-  unsigned long long* tgt = (unsigned long long*)(direct ? st.seen : st.pend);   // receives the rows; cells are counted in it
-  SegCounts c;
-  c.neg = 0;
-  const uint32_t cnt = seg_query<SEG, HI>(seen, spre, lo, IT, magic);
-  c.dis = valid ? cnt : 0u;
-  // the cell lo == 0 of a row-mode pair: a running count per group
-  const bool infill = valid && rowmode && lo == 0u;
-  const unsigned long long mf = __ballot(infill);
-  const uint32_t kin = (SEG == 32) ? (uint32_t)__builtin_popcount((lane >= 32u) ? (uint32_t)(mf >> 32) : (uint32_t)mf)
-                                   : (uint32_t)__popcll(mf);
-  c.tie = (sl == 0u) ? (kin * (kin - 1u) / 2u + kin * cfill) : 0u;   // once per pair (kin == 0 without row mode)
-  c.cfill = closes ? 0u : (cfill + kin);
-  // every other cell of a row-mode pair: rows of the group in [lo, hi], read from the words the range covers
-  const bool cellv = valid && rowmode && !infill;
-  const uint32_t w0 = lo >> 6, w1 = hi >> 6;
-  const unsigned long long m0 = ~0ull << (lo & 63u), m1 = (2ull << (hi & 63u)) - 1ull;
-  const bool any_wide = __ballot(cellv && (w1 > w0 + 1u)) != 0ull;   // a cell of more than two words (rare)
-  auto cell_count = [&]() -> uint32_t {
-    if (!any_wide) {  // both words of every cell in one round trip
-      const unsigned long long a = cellv ? tgt[w0] : 0ull, b = (cellv && w1 > w0) ? tgt[w0 + 1u] : 0ull;
-      return (uint32_t)__popcll(a & m0 & ((w1 == w0) ? m1 : ~0ull)) + (uint32_t)__popcll(b & m1);
-    }
-    uint32_t n = 0;
-    for (uint32_t i = 0; __ballot(cellv && (w0 + i <= w1)) != 0ull; ++i) {
-      const uint32_t w = w0 + i;
-      const bool act = cellv && w <= w1;
-      const unsigned long long v = act ? tgt[w] : 0ull;
-      const unsigned long long m = ((w == w0) ? m0 : ~0ull) & ((w == w1) ? m1 : ~0ull);
-      n += (uint32_t)__popcll(v & m);
-    }
-    return n;
-  };
-  const uint32_t before = cell_count();
-  wave_lds_fence();
-  if (valid) seen_insert(tgt, q);
-  wave_lds_fence();
-  const uint32_t after = cell_count();
-  c.tie += (cellv && !single) ? before : 0u;        // rows of earlier pieces in my cell (pend holds this group only)
-  c.tie2 = cellv ? (after - before - 1u) : 0u;      // rows of this piece in my cell, me excluded: every pair twice
-  // rows that went into seen directly: its counts follow
-  if (SEG == 64) {
-    if (direct) tl_update(tl_view(seen, spre), valid, q, IT, magic, lane);   // wave-uniform (one pair)
-  } else if (single && __ballot(rowmode) != 0ull) {
-    rebuild_prefix_half<(HI > 0 ? HI : 1)>(seen, spre, sl);   // a list-mode half rebuilds the same values
-  }
-  wave_lds_fence();
-  return c;
-}
-
-// a group closes: its rows, collected in pend, become visible in seen
-template <int SEG, int HI>
-__device__ __attribute__((noinline)) void seg_group_close(const SegState st, const int NW_in, const uint32_t lane) {
-  const int NW = __builtin_amdgcn_readfirstlane(NW_in);   // words of seen / pend that exist
-  unsigned long long* seen = (unsigned long long*)st.seen;
-  unsigned long long* pend = (unsigned long long*)st.pend;
-  uint16_t* spre = (uint16_t*)st.spre;
-  if (SEG == 64) {
-    PendG P;
-    P.bits = pend; P.pre = nullptr; P.pre16 = nullptr;
-    tl_rebuild<false>(tl_view(seen, spre), &P, NW, lane);
-  } else {
-    const uint32_t sl = lane & 31u;
-    constexpr int H = (HI > 0 ? HI : 1);
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      const uint32_t w = sl * (uint32_t)H + (uint32_t)i;
-      seen[w] |= pend[w];
-      pend[w] = 0ull;
-    }
-    wave_lds_fence();
-    rebuild_prefix_half<H>(seen, spre, sl);
-  }
-  wave_lds_fence();
-}
-
 // Diagnostic build only (-DICIKT_STEP_STATS, tools/step_stats.py; in the product build no stamp executes): per step
 // kind the steps taken, their rows and the wave cycles (s_memtime) spent in them, summed over all waves.
 //   kind 0 hot loop   1 hot step met in the main loop   2 MIXED   3 GROUP (with its closes)   4 general step (pend in
@@ -1858,18 +1401,18 @@ __device__ unsigned long long g_step_stats[24];
 #define ICIKT_ST_FLUSH
 #endif
 
-// Variants: <1, PG, 0> one pair per wave (any n; PG = pend in global memory) and <2, false, HI> two pairs per
-// wave, one per half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild.
+// Variants: <2, HI> two pairs per wave, one per 32-lane half, HI = 1..ICIKT_HALF_ITEMS_MAX words per lane in a half's
+// prefix rebuild (n <= 18 336); <2, 0> two pairs per wave, one after the other on the whole wave (long columns); <1, 0>
+// one pair on the whole wave (any n).
 // A task is (pair, pair or -1).  The two pairs of a task share their STREAMED column (pj) and their gathered
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
-template <int NP, bool PG, int HI>
+template <int NP, int HI>
 __global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
                                                                      // Two long-column pairs per wave: the LDS state allows 2-3 waves per SIMD, 3 leave 168 VGPRs
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
-         int perpair_bytes, unsigned long long* __restrict__ pend_bits, uint32_t* __restrict__ pend_pre,
-         int* __restrict__ task_ctr, int opts) {
+         int perpair_bytes, int* __restrict__ task_ctr, int opts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   // XCD-aware mapping: consecutive tasks share their gathered block, so keep them on one XCD
@@ -1889,29 +1432,25 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // (from the exec-mask count, not from threadIdx.x: the thread id would stay live -- and spill -- to the task's end)
   const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int Wp4 = k1_lds_stride(Wp, HI);                    // stride of the per-pair arrays (host: plan_k1)
-  const int items = (Wp + 63) >> 6;
   const int IT = tl_items(Wp);                              // one pair per wave: words of seen owned by a lane
   const uint32_t magic = tl_magic(IT);
-  static_assert(!PG && ((NP == 1 && HI == 0) || (NP == 2 && HI > 0) || (NP == 2 && HI == 0)), "k1_pairs variants");
+  static_assert((NP == 1 && HI == 0) || NP == 2, "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
-  constexpr bool fast_ties = !PG;                           // MIXED / GROUP steps instead of the general step
 
-  // PG (pend in global memory, one slot per LAUNCHED wave): persistent waves, the grid is what the chip holds, and
-  // a wave FETCHES its next task from a counter.  Workgroups are dealt round-robin over the 8 XCDs, so the
-  // workgroups with equal blockIdx % 8 share an XCD: each such group owns one contiguous eighth of the task list
-  // and its own counter.  Tasks are then started in order, as a grid that covers the task list starts its
-  // workgroups in order: the waves of an XCD stay within a few hundred consecutive tasks = one or two gathered
-  // blocks (400 KB each at n = 50 000) that live in its 4 MB L2.  (Striding over the task list instead lets the
-  // waves drift apart by tens of rounds on a 2-million-task list; measured on the full c5 matrix: 55 % L2 misses,
-  // 7 TB fetched, 2.0e6 pairs/s, against 2 % misses for a grid that covers the list.)
-  // Otherwise (pend in LDS) the grid covers the task list and a wave takes exactly one task: without a task loop
-  // the compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used to keep across the loop in
-  // scratch (5.6 KB of spill stores per wave, 1.5 GB per c4 launch) are gone.
+  // Half-wave kernels: the grid covers the task list and a wave takes exactly one task -- without a task loop the
+  // compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used to keep across the loop in scratch
+  // (5.6 KB of spill stores per wave, 1.5 GB per c4 launch) are gone.
+  // Whole-wave kernels with more tasks than the chip holds waves (the host passes task counters): PERSISTENT waves, the
+  // grid is what the chip holds and a wave FETCHES its next task from a counter -- a wave that has finished goes on at
+  // once instead of waiting for the other waves of its workgroup to retire.  Workgroups are dealt round-robin over the 8
+  // XCDs, so the workgroups with equal blockIdx % 8 share an XCD: each such group owns one contiguous eighth of the task
+  // list and its own counter.  Tasks are then started in order, as a grid that covers the task list starts its workgroups
+  // in order: the waves of an XCD stay within a few hundred consecutive tasks = one or two gathered blocks (400 KB each
+  // at n = 50 000) that live in its 4 MB L2.  (Striding over the task list instead lets the waves drift apart by tens of
+  // rounds on a 2-million-task list; measured on the full c5 matrix: 55 % L2 misses, 7 TB fetched, 2.0e6 pairs/s,
+  // against 2 % misses for a grid that covers the list.)
   // The kernel has no workgroup barrier, so the waves of a workgroup run independently.
-  // (round 3: the per-wave global pend slots are gone, the persistent grid stays for the whole-wave kernels when the host
-  //  passes task counters -- more tasks than the chip holds waves: a wave that has finished fetches the next task at once
-  //  instead of waiting for the three other waves of its workgroup to retire)
   int task = gwave, t_lo = 0, t_hi = n_tasks;
   int* my_ctr = task_ctr;
   const bool persist = (HI == 0) && task_ctr != nullptr;   // wave-uniform
@@ -1949,7 +1488,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t* tgB[NP];     // few tie groups in the gathered column: joint ties of multi-step groups are
   int ntgB[NP];                // counted at group close from this list (-1: row mode)
   PairState S[NP];
-  PendG Pg[NP];
   uint32_t cb[NP], gg[NP];
   bool g_oddtie = false;       // a gathered column has a tie group that starts at an odd position
   const uint32_t* rec_blk;
@@ -1978,7 +1516,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // a pair on the whole wave: seen | two-level counts (loc, lb, hist, locg: TL_BYTES); L.spre = the counts.  No `pend`
       // (round 3): as in the half-wave kernels a tie group of the streamed column is queried first and inserted when it closes
       S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
-      Pg[k].bits = nullptr; Pg[k].pre16 = nullptr; Pg[k].pre = nullptr;
       for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
       for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
@@ -1986,7 +1523,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // half-wave kernels: seen | prefix slots of seen (32 lanes x 16 B).  No `pend`: the rows of a tie group of the
       // streamed column are queried first and inserted when the group closes (GROUP steps below)
       S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
-      Pg[k].bits = nullptr; Pg[k].pre16 = nullptr; Pg[k].pre = nullptr;
       for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
     }
@@ -2020,9 +1556,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // Every row outside it is above it, so for a row r of the group
   //   #{j above : b_j < b_r} = lo_r - #{j in the group : b_j < b_r},
   // and summed over the group:  sum(lo_r) - (C(m, 2) - T),  m = rows of the group, T = its joint ties.
-  // The group's rows then only gather, add lo and (for T) collect in pend.  Used when the gathered columns are
-  // in list mode and the group is longer than one step: the step loop ends at its first position last_start
-  // and a gather-only loop runs the rest.
+  // The group's rows then only gather and add lo; T needs no insertion either: every row that is not in `seen` when
+  // the group begins belongs to it, so it has (size of g) - (rows of g in seen) rows in a listed tie group g of the
+  // gathered column.  Used when the gathered columns are in list mode and the group is longer than one step: the
+  // step loop ends at its first position last_start and a gather-only loop runs the rest.
   int last_start;
   bool closed_form = true;
 #pragma unroll
@@ -2045,15 +1582,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const int end_main = closed_form ? last_start : n;
 
   // Steps are cut at tie-group boundaries of the streamed column: a step holds up to 64 rows of COMPLETE
-  // groups (then nothing of it stays open: no pend, no merge), or a piece of ONE group that is longer than a
-  // step (the open-group path of pair_step_rest).  pos = first position of the step, nact = its rows, F =
-  // group-start flags of its rows, Fn = "the row after the step starts a group".
+  // groups (HOT / MIXED), or a piece of ONE longer group (GROUP).  pos = first position of the step, nact = its
+  // rows, F = group-start flags of its rows, Fn = "the row after the step starts a group".
   const uint32_t partner_addr = half_partner_addr(lane);
   uint32_t dis_half = 0, dis_half_neg = 0;  // half-wave steps: lane (h, l) counts dis_half - dis_half_neg for pair h
   // fast tie steps: per lane, for the lane's pair (half-wave kernels: lanes >= 32 belong to the second pair)
   // (their counts and subtrahends go into dis_half / dis_half_neg: the same per-lane convention, two registers fewer)
-  uint32_t seg_tie = 0, seg_tie2 = 0, seg_cfill = 0;
-  bool seg_open = false;   // a GROUP step left its group open (wave-uniform: the pairs share the streamed column)
+  uint32_t seg_tie = 0, seg_tie2 = 0;
   bool grp_open = false;   // half-wave kernels: likewise; grp_start = first position of the open group
   int grp_start = 0, grp_entries = 0;   // grp_entries: steps of the open group so far
   uint32_t sv_k0 = 0, sv_k1 = 0, sv_h = 0;   // the open group's first step: its rows' values, still in registers when the second step closes it
@@ -2405,8 +1940,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const int remaining = end_main - pos;
       const bool reach_end = remaining <= 64;
       if (remaining < 64) F &= (1ull << remaining) - 1ull;
-      if constexpr (fast_ties) {
-        // ---- fast tie steps: HOT (64 singleton rows), MIXED (complete groups of <= KS rows) or GROUP -----------
+      {
+        // ---- tie steps: HOT (64 singleton rows), MIXED (complete groups of <= KS rows) or GROUP -----------
         constexpr int SW = half_mode ? 32 : 64;                  // rows a segment takes per step
         const int avail = reach_end ? remaining : 64;            // rows the window shows
         const int lim = min(remaining, SW);
@@ -2445,16 +1980,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           }
           Fn = closes;
         }
-      } else if ((F & 1ull) == 0ull) {           // inside a group that is longer than a step
-        if (F == 0ull) { nact = reach_end ? remaining : 64; Fn = reach_end || fnbit; }
-        else { nact = (int)__builtin_ctzll(F); F = 0ull; Fn = true; }   // its last piece
-      } else if (reach_end || fnbit) {           // the window ends where a group ends
-        nact = reach_end ? remaining : 64;
-        Fn = true;
-      } else {                                   // the window's last group is incomplete: stop in front of it
-        const int L = 63 - (int)__builtin_clzll(F);
-        if (L == 0) { nact = 64; Fn = false; }   // ... unless it is all there is: a group longer than a step begins
-        else { nact = L; F &= (1ull << L) - 1ull; Fn = true; }
       }
       if (((pos + nact) >> 6) != wc) {  // the window moves on by one flag word at most (nact <= 64)
         fw0 = fw1;
@@ -2495,7 +2020,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       rk_ok = true;
       pre_n0 = n0_next;
     }
-    if (fast_ties && !half_mode) {
+    if (!half_mode) {
       // a GROUP step of a pair in row mode needs the last position of every row's tie group in the gathered column ->
       // gathered one step ahead, beside the rec values (both columns of the block in one entry)
       bool any_row = false;
@@ -2510,7 +2035,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       hi_ok = tprog_kind(e_next) == TPROG_KIND_GROUP && ((ntgB[0] < 0) || (ntgB[NP - 1] < 0));
       if (hi_ok) hi_pre = gload_u32(hi_blk, r0);   // (lane = row: both columns of the block in one entry)
     }
-    uint32_t q[NP], lo[NP];
 
     if (all_fast) {
       hot_step(rk, std::false_type{});
@@ -2678,7 +2202,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
         ICIKT_ST_MARK(3, nact)
       }
-    } else if constexpr (fast_ties) {
+    } else {
       // ---- tie step of a whole-wave kernel: one pair, or two one after the other (they share the streamed column, hence
       //      the step; lane = row) -----------------------------------------------------------------------------------
       if (kind == 1) {
@@ -2688,7 +2212,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           SegState st;
           st.seen = (lds_u64p)S[k].L.seen;
           st.spre = (lds_u16p)S[k].L.spre;
-          st.pend = (lds_u64p)nullptr;
           const SegCounts c = seg_mixed_step<64, HI>(st, F, nact, rk[k], IT, magic, lane);
           S[k].dis += c.dis; sneg[k] += c.neg; S[k].tie += c.tie;
         }
@@ -2768,7 +2291,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             }
             wave_lds_fence();
 #pragma unroll
-            for (int k = 0; k < NP; ++k) tl_rebuild<false>(T[k], nullptr, Wp4, lane);
+            for (int k = 0; k < NP; ++k) tl_rebuild(T[k], Wp4, lane);
             wave_lds_fence();
           }
           // list mode: C(rows of the group in the listed tie group, 2)
@@ -2827,31 +2350,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
         ICIKT_ST_MARK(3, nact)
       }
-    } else {
-    // ---- general step (tie groups in the streamed column, open groups, the last partial step) ----------
-    {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        q[k] = valid ? (rk[k] & 0xFFFFu) : 0xFFFFFFFFu;  // never "below" anything
-        lo[k] = valid ? (rk[k] >> 16) : 0u;              // nothing is below 0
-        // (1) rows of strictly higher groups of the streamed column that are already in `seen`
-        const uint32_t cnt = (HI == 0) ? tl_query(tl_view(S[k].L.seen, S[k].L.spre), lo[k], IT, magic)
-                                       : prefix_query(S[k].L.seen, S[k].L.spre, lo[k]);
-        S[k].dis += valid ? cnt : 0u;
-      }
     }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const StepCounts c = pair_step_rest<PG, (HI == 0)>(S[k].L, Pg[k], F, Fn, valid, row, q[k], lo[k],
-                                              hiG[k], tgB[k], ntgB[k], Wp, items, lane);
-      S[k].dis += c.dis; S[k].tie += c.tie; S[k].tie2 += c.tie2;
-    }
-    ICIKT_ST_MARK(4, nact)
-    }  // general step
   }
 
-  // the rows of the last tie group of the streamed column: gather, add lo, collect in pend; then the group's
-  // joint ties T from pend and the correction C(m, 2) - T of the summed lo's
+  // the rows of the last tie group of the streamed column: gather, add lo; then the group's joint ties T from range
+  // counts of `seen` and the correction C(m, 2) - T of the summed lo's
   unsigned long long corr[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) corr[k] = 0ull;
@@ -3394,7 +2897,7 @@ __global__ void k_selftest(uint32_t* out) {
                     (lane_xor<8>(t5, lane) == ((lane ^ 8u) * 5u + 1u) ? 8u : 0u) |
                     (lane_xor<16>(t5, lane) == ((lane ^ 16u) * 5u + 1u) ? 16u : 0u) |
                     (lane_xor<32>(t5, lane) == ((lane ^ 32u) * 5u + 1u) ? 32u : 0u);
-  out[512 + lane] = wave_sort_u32((lane * 2654435761u) >> 8, lane);  // the host checks the sequence is sorted
+  out[512 + lane] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3576,50 +3079,47 @@ hipError_t k1_wide_blocks_per_cu(size_t lds_bytes, int* out) {
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, reinterpret_cast<const void*>(k1_wide), 64, lds_bytes);
 }
 
-typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int,
-                        unsigned long long*, uint32_t*, int*, int);
+typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int, int*, int);
 
-// The half-wave hot step exists for two pairs per wave with pend in LDS, one kernel per half_items
-// (1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild: n <= 2 040 * half_items - 24)
-static k1_fn_t k1_select(int np, bool pend_global, int half_items) {
-  if (np == 2 && !pend_global) {
+// Half-wave kernels: one per half_items (1..ICIKT_HALF_ITEMS_MAX words per lane in a half's prefix rebuild:
+// n <= 2 040 * half_items - 24); half_items == 0: pairs on the whole wave, one or two per wave
+static k1_fn_t k1_select(int np, int half_items) {
+  if (np == 2) {
     switch (half_items) {
-      case 1: return &k1_pairs<2, false, 1>;
-      case 2: return &k1_pairs<2, false, 2>;
-      case 3: return &k1_pairs<2, false, 3>;
-      case 4: return &k1_pairs<2, false, 4>;
-      case 5: return &k1_pairs<2, false, 5>;
-      case 6: return &k1_pairs<2, false, 6>;
-      case 7: return &k1_pairs<2, false, 7>;
-      case 9: return &k1_pairs<2, false, 9>;
-      default: break;
+      case 0: return &k1_pairs<2, 0>;
+      case 1: return &k1_pairs<2, 1>;
+      case 2: return &k1_pairs<2, 2>;
+      case 3: return &k1_pairs<2, 3>;
+      case 4: return &k1_pairs<2, 4>;
+      case 5: return &k1_pairs<2, 5>;
+      case 6: return &k1_pairs<2, 6>;
+      case 7: return &k1_pairs<2, 7>;
+      case 9: return &k1_pairs<2, 9>;
+      default: return nullptr;
     }
   }
-  if (pend_global) return nullptr;   // (no kernel keeps an open-group bitset any more)
-  if (np == 2 && half_items == 0) return &k1_pairs<2, false, 0>;
-  if (np != 1) return nullptr;
-  return &k1_pairs<1, false, 0>;
+  if (np != 1 || half_items != 0) return nullptr;
+  return &k1_pairs<1, 0>;
 }
 
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
-                     const int32_t* pj, PairRaw* raw, int np, bool pend_global, int half_items, int wpb, int blocks,
-                     size_t lds_bytes, int perpair_bytes, unsigned long long* pend_bits, uint32_t* pend_pre,
-                     int* task_ctr, int opts, hipStream_t s) {
+                     const int32_t* pj, PairRaw* raw, int np, int half_items, int wpb, int blocks,
+                     size_t lds_bytes, int perpair_bytes, int* task_ctr, int opts, hipStream_t s) {
   if (n_tasks <= 0 || blocks <= 0) return hipSuccess;
-  k1_fn_t fn = k1_select(np, pend_global, half_items);
+  k1_fn_t fn = k1_select(np, half_items);
   if (!fn) return hipErrorInvalidValue;
   (void)hipGetLastError();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds_bytes, s, pv, tasks, n_tasks, pi, pj, raw,
-                     perpair_bytes, pend_bits, pend_pre, task_ctr, opts);
+                     perpair_bytes, task_ctr, opts);
   return hipGetLastError();
 }
 
 // resident workgroups per CU of the pair kernel for a launch shape (occupancy query)
-hipError_t k1_blocks_per_cu(int np, bool pend_global, int half_items, int wpb, size_t lds_bytes, int* out) {
-  k1_fn_t fn = k1_select(np, pend_global, half_items);
+hipError_t k1_blocks_per_cu(int np, int half_items, int wpb, size_t lds_bytes, int* out) {
+  k1_fn_t fn = k1_select(np, half_items);
   if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);

@@ -1,11 +1,12 @@
-"""The long-column pair kernel k1_pairs<1, true, 0> under -m gpu: `pend` in global memory, a persistent grid whose
-waves FETCH many tasks in order from per-XCD counters and reuse one pend slot that every task must leave all zero
-(icikt_capi.cpp: icikt_run_dev, "pend_global"; icikt_kernels.hip: the task loop of k1_pairs).  The natural plan of
+"""The long-column pair kernels under -m gpu: pairs on the whole wave (k1_pairs<1, 0> / <2, 0>: one pair, or two one after
+the other), a persistent grid whose waves FETCH many tasks in order from per-XCD counters and re-initialise their LDS
+state per task (icikt_capi.cpp: launch_pair_tasks; icikt_kernels.hip: the task loop of k1_pairs).  The natural plan of
 the small matrices an oracle can afford gives every wave at most one task, so the grid is capped through
 icikt_debug_set_plan("gridcap=...") -- every wave then runs ten or more tasks back to back -- plus one natural-plan
 case with more tasks than resident waves, the c4b configuration (Bernoulli(0.1) missingness,
 a fifth of the columns in the reference's int32-wrap regime, src/kendallc.cpp:112-114) and the column lengths on
-either side of the 15-bit packed two-step count of the one-pair kernels (n = 32 768)."""
+either side of the 15-bit packed two-step count (n = 32 768).  (Rounds 1-2 kept open tie groups in a second bitset
+`pend`, for long columns in per-wave global slots: the plan key `pend` is still accepted and ignored.)"""
 import numpy as np
 import pytest
 
@@ -57,9 +58,8 @@ def _all_pairs_vs_oracle(ctx, X, perspectives=("global", "local")):
 @pytest.mark.parametrize("n", [33000, 50000, 65535])
 def test_persistent_waves_run_many_tasks(plan_ctx, n):
     """276 pairs on a grid capped at 8 workgroups = 32 waves: every wave fetches eight or nine tasks in a row from its
-    XCD group's counter and reuses its global pend slot after tasks that opened, extended and merged tie groups.
-    All pairs, both perspectives, counts bit-exact.  Then a matrix of another length on the SAME context: a new
-    stride meets whatever the earlier tasks left in the slots."""
+    XCD group's counter, after tasks that opened, extended and closed tie groups.  All pairs, both perspectives,
+    counts bit-exact.  Then a matrix of another length on the SAME context."""
     plan_ctx.debug_set_plan({"np": 1, "pend": "g", "gridcap": 8})
     X = _tied_matrix(n, 24, seed=n)
     _all_pairs_vs_oracle(plan_ctx, X)
@@ -76,11 +76,11 @@ def test_persistent_waves_run_many_tasks(plan_ctx, n):
 
 @pytest.mark.parametrize("n", [18400, 33000, 50000])
 def test_two_pairs_per_wave_long_columns(plan_ctx, n):
-    """k1_pairs<2, true, 0>: two pairs of a long column per wave, one after the other on the whole wave, sharing the
+    """k1_pairs<2, 0>: two pairs of a long column per wave, one after the other on the whole wave, sharing the
     streamed column and one 8-byte gather per row; the packed two-step chains of the two pairs take turns (pair 1 counts
     its first singleton step alone).  Tied, left-censored, scattered-missing and half-missing columns -- every general
-    step of the pair kernel with two pairs in flight -- on a capped grid (every wave runs several tasks: both pairs'
-    global pend slots are reused) and on the library's own grid; all pairs, both perspectives, counts bit-exact; an odd
+    step of the pair kernel with two pairs in flight -- on a capped grid (every wave runs several tasks) and on the
+    library's own grid; all pairs, both perspectives, counts bit-exact; an odd
     column count leaves tasks with a single pair."""
     X = _tied_matrix(n, 19, seed=n + 7)
     plan_ctx.debug_set_plan({"np": 2, "pend": "g", "gridcap": 4})

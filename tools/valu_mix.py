@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of a K1 hot loop (development aid).
 
-    python tools/valu_mix.py [kernel-substring]        default: k1_pairsILi2ELb0ELi5  (the c4 kernel)
+    python tools/valu_mix.py [kernel-substring]        default: k1_pairsILi2ELi5E  (the c4 kernel)
 
 Compiles icikt_kernels.hip to gfx950 assembly, finds the innermost loop that holds the packed in-step chain
 (`row_shr:15`) and classifies its vector instructions by the issue classes measured in tools/ubench/valu_rate.hip:
@@ -77,7 +77,7 @@ def hot_loop_mix(want):
 
 
 if __name__ == "__main__":
-    want = next((x for x in sys.argv[1:] if not x.startswith("-")), "k1_pairsILi2ELb0ELi5")
+    want = next((x for x in sys.argv[1:] if not x.startswith("-")), "k1_pairsILi2ELi5E")
     for a, b, cnt, seg in hot_loops(want, verbose="-v" in sys.argv):
         nF, nH, n8 = cnt.get("vF", 0), cnt.get("vH", 0), cnt.get("v8", 0)
         print(f"loop at lines {a}..{b} ({cnt['_inner_loops']} inner loops): VALU full-rate {nF}, half-rate {nH}, "

@@ -1309,7 +1309,7 @@ typedef __attribute__((address_space(3))) unsigned long long* lds_u64p;
 typedef __attribute__((address_space(3))) uint16_t* lds_u16p;
 // MIXED steps take groups of up to this many rows (the correction loop costs ~10 instructions per row of the
 // step's largest group); longer groups get GROUP steps of their own.  A whole wave amortises a longer loop.
-__host__ __device__ constexpr int k1_ks(bool half) { return half ? 32 : 20; }
+__host__ __device__ constexpr int k1_ks(bool half) { return half ? 32 : 32; }
 
 struct SegState {   // LDS views of a pair
   lds_u64p seen;

@@ -2347,6 +2347,49 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           }
           ++grp_entries;
           grp_open = true;
+          // The group goes on.  Its further FULL steps only query (phase A): they run in a loop of their own, without
+          // the window logic per step -- a group of thousands of rows (few distinct values; a fill group met in row
+          // mode) is then a stream of gathers and queries.  The group's end: the first group start at or after pos,
+          // 64 flag words per probe (lane l reads word pos / 64 + l).
+          // (probed once the group has filled two steps: shorter groups close from registers and never get here)
+          int gend = pos;
+          if (grp_entries == 2) gend = end_main;
+          for (int wb = pos >> 6; wb < W && grp_entries == 2; wb += 64) {
+            const int w = wb + (int)lane;
+            unsigned long long f = (w < W) ? gf[w] : 0ull;
+            if (w == (pos >> 6)) f &= ~0ull << (pos & 63);
+            const unsigned long long any = __ballot(f != 0ull);
+            if (any != 0ull) {
+              const int l0 = (int)__builtin_ctzll(any);
+              const unsigned long long f0 =
+                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f, l0) |
+                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f >> 32), l0) << 32);
+              gend = min(end_main, (wb + l0) * 64 + (int)__builtin_ctzll(f0));
+              break;
+            }
+          }
+          if (pos + 64 < gend) {
+            uint32_t hvn = any_row ? (hi_ok ? hi_pre : gload_u32(hi_blk, r0)) : 0u;   // the next step's rows are in r0
+            do {
+              uint32_t rkl[NP];
+              take_rk(rkl);                           // (rk_ok: the ring moved on by a 64-row step)
+              const uint32_t hvl = hvn;
+              pos += 64;
+              advance64();
+              if (any_row) hvn = gload_u32(hi_blk, r0);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) {
+                const uint32_t c = tl_query(T[k], rkl[k] >> 16, IT, magic);
+                S[k].dis += c;
+                if (ntgB[k] < 0) S[k].tie2 -= tl_query(T[k], (comp[k] ? (hvl >> 16) : (hvl & 0xFFFFu)) + 1u, IT, magic) - c;
+              }
+              ++grp_entries;
+              ICIKT_ST_MARK(3, 64)
+            } while (pos + 64 < gend);
+            hi_pre = hvn;
+            hi_ok = any_row;
+            fw_word = -1;                             // the flag window is read again
+          }
         }
         ICIKT_ST_MARK(3, nact)
       }

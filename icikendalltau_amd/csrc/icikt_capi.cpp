@@ -9,7 +9,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -372,6 +374,8 @@ void icikt_ctx_destroy(icikt_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_tasks) (void)hipHostFree(c->pinned_tasks);
+  for (auto& ps : c->out_pinned)
+    if (ps.p) (void)hipHostFree(ps.p);
   for (auto& e : c->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
@@ -793,6 +797,56 @@ HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
   return HostLock::Refused;
 }
 
+// Host-side copies into / out of the library's pinned buffers, on a few threads: one core moves ~10 GB/s, the c4
+// matrix is 82 MB and PCIe takes it in 1.8 ms.  `rows` pieces of `row_bytes`, strides in bytes (a contiguous copy: one row).
+static void par_copy2d(void* dst, size_t dst_stride, const void* src, size_t src_stride, size_t row_bytes, size_t rows) {
+  const size_t total = row_bytes * rows;
+  unsigned nt = (unsigned)std::min<size_t>(8, total / ((size_t)2 << 20));
+  if (rows == 1 && nt > 1) {   // a contiguous copy: cut it into nt pieces
+    const size_t piece = ((total / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    try {
+      for (unsigned t = 1; t < nt; ++t) {
+        const size_t off = (size_t)t * piece;
+        if (off >= total) break;
+        th.emplace_back([=]() { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, total - off)); });
+      }
+      memcpy(dst, src, std::min(piece, total));
+    } catch (...) {
+      for (auto& t : th) t.join();
+      memcpy(dst, src, total);   // could not start threads: one core does it all
+      return;
+    }
+    for (auto& t : th) t.join();
+    return;
+  }
+  nt = (unsigned)std::min<size_t>(std::max(1u, nt), rows);
+  auto work = [=](size_t r0, size_t r1) {
+    for (size_t r = r0; r < r1; ++r)
+      memcpy(static_cast<char*>(dst) + r * dst_stride, static_cast<const char*>(src) + r * src_stride, row_bytes);
+  };
+  if (nt <= 1) { work(0, rows); return; }
+  std::vector<std::thread> th;
+  const size_t per = (rows + nt - 1) / nt;
+  size_t done_to = per;   // the calling thread takes the first share
+  try {
+    for (unsigned t = 1; t < nt; ++t) {
+      const size_t r0 = (size_t)t * per, r1 = std::min(rows, r0 + per);
+      if (r0 >= rows) break;
+      th.emplace_back(work, r0, r1);
+      done_to = r1;
+    }
+  } catch (...) {
+    for (auto& t : th) t.join();
+    work(done_to, rows);       // the shares no thread took
+    work(0, std::min(per, rows));
+    return;
+  }
+  work(0, std::min(per, rows));
+  for (auto& t : th) t.join();
+}
+static void par_memcpy(void* dst, const void* src, size_t bytes) { par_copy2d(dst, 0, src, 0, bytes, 1); }
+
 int ensure_bounce(icikt_ctx* c, size_t need) {
   if (c->pinned_bytes >= need) return ICIKT_SUCCESS;
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -814,7 +868,8 @@ int ensure_bounce(icikt_ctx* c, size_t need) {
 //   mode 0            pageable copies through the runtime's own staging path: only for matrices below kLockMin
 //                     bytes, never selected for larger ones (icikt_host.h)
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister, bool pipelined) {
+                       int64_t col_end, uint32_t flags, const void** deferred_unregister, bool pipelined,
+                       const std::function<int(size_t, int64_t)>* on_chunk) {
   if (deferred_unregister) *deferred_unregister = nullptr;
   c->chunk_col_end.clear();
   const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
@@ -834,7 +889,9 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
     const double* src0 = X + col_begin * ld;
     const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
-    int mode = (span < kLockMin) ? 0 : (c->h2d_mode < 0 ? 1 : c->h2d_mode);
+    // (default: staged -- the library does not page-lock the caller's memory unless told to: icikt_host.h)
+    int mode = (span < kLockMin) ? 0 : (c->h2d_mode < 0 ? 2 : c->h2d_mode);
+    if (mode == 2 && c->h2d_mode < 0 && !c->force_reg_fail && range_pinned_already(src0, span)) mode = 3;   // page-locked by the caller: copied as it is
     bool registered = false;
     if (mode == 1) {
       const HostLock lk = lock_host(c, src0, span, hipHostRegisterDefault);
@@ -858,7 +915,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
         char* stage = static_cast<char*>(c->pinned) + (size_t)(k & 1) * (size_t)chunk * col_bytes;
         if (k >= 2) e = hipEventSynchronize(c->ev_copy[1 + ((k - 2) % 3)]);  // the copy that last used this half
         if (e != hipSuccess) break;
-        for (int64_t j = 0; j < nc; ++j) memcpy(stage + (size_t)j * col_bytes, X + (c0 + j) * ld, col_bytes);
+        par_copy2d(stage, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc);
         e = hipMemcpyAsync(dst, stage, (size_t)nc * col_bytes, hipMemcpyHostToDevice, c->copy_stream);
       } else {
         e = hipMemcpy2DAsync(dst, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc,
@@ -876,6 +933,8 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
         }
         if (e == hipSuccess && rc == 0) e = hipEventRecord(c->ev_chunk[(size_t)k], c->prep_stream);
         if (e == hipSuccess && rc == 0) c->chunk_col_end.push_back(c0 + nc);
+        // the caller's work for this chunk (its pair-kernel launch) is enqueued NOW, before the host stages the next chunk
+        if (e == hipSuccess && rc == 0 && on_chunk) rc = (*on_chunk)((size_t)k, c0 + nc);
       } else {
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
         if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
@@ -933,18 +992,17 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   }
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true);
-  if (rc) return rc;
-  c->prepared = true;
-  const double t_enq = ms_since();
   const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
-  const size_t nchunks = c->chunk_col_end.size();
   const bool all_combn = c->combn_S == n_samp && c->combn_begin == 0 && c->combn_end == n_samp * (n_samp - 1) / 2;
-  double t_built = 0, t_up = 0;
+  double t_enq = 0, t_built = 0, t_up = 0;
+  int rc = ICIKT_SUCCESS;
+  size_t nchunks = 0;
   if (all_combn) {
     // All pairs of the upper triangle: a chunk's tasks are arithmetic.  They are written chunk by chunk straight into a
-    // pinned buffer, copied asynchronously and launched -- the first launch is enqueued a fraction of a millisecond into
-    // the call, no host copy of the pair list is ever made.  Order inside a chunk: gathered block, then streamed
+    // pinned buffer, copied asynchronously and launched AS SOON AS the chunk's copy and pre-pass are enqueued (the
+    // callback below runs inside upload_and_prepare's chunk loop: with staged transfers the host is busy copying the
+    // next chunk into its pinned buffer meanwhile) -- the first launch is enqueued a fraction of a millisecond into the
+    // call, no host copy of the pair list is ever made.  Order inside a chunk: gathered block, then streamed
     // column (the order build_units gives: a block's rec table stays in cache); a task is the two pairs (2a, j),
     // (2a + 1, j) that share their streamed column j, the pair (2a, 2a + 1) runs alone.
     const int64_t S = n_samp;
@@ -959,10 +1017,8 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
     }
     int32_t* u = static_cast<int32_t*>(c->pinned_tasks);
     size_t nt = 0;
-    rc = timer_begin(c, ICIKT_K_PAIRS, flags);
     int64_t cb = 0;
-    for (size_t q = 0; q < nchunks && rc == 0; ++q) {
-      const int64_t ce = c->chunk_col_end[q];
+    const std::function<int(size_t, int64_t)> on_chunk = [&](size_t q, int64_t ce) -> int {
       const size_t first = nt;
       if (pl.np == 2) {
         for (int64_t a2 = 0; a2 < ce; a2 += 2) {          // gathered block: columns a2, a2 + 1
@@ -979,17 +1035,27 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
       }
       cb = ce;
       const size_t cnt = nt - first;
-      if (cnt == 0) continue;
+      if (cnt == 0) return ICIKT_SUCCESS;
       hipError_t e = hipMemcpyAsync(c->d_unit_start.p + 2 * first, u + 2 * first, cnt * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_chunk[q], 0);
-      if (e != hipSuccess) { rc = fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e)); break; }
-      rc = launch_pair_tasks(c, pl, (int)first, (int)cnt);
-    }
+      if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e));
+      return launch_pair_tasks(c, pl, (int)first, (int)cnt);
+    };
+    rc = timer_begin(c, ICIKT_K_PAIRS, flags);
+    if (rc == 0) rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true, &on_chunk);
+    if (rc) { (void)hipStreamSynchronize(c->prep_stream); return rc; }
+    c->prepared = true;
+    nchunks = c->chunk_col_end.size();
     c->n_units = (int)nt;
     c->wpb = 0;               // (h_units does not hold this list: a later device-resident run rebuilds it)
     c->units_dirty = true;
-    t_built = t_up = ms_since();
+    t_enq = t_built = t_up = ms_since();
   } else {
+  rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true, nullptr);
+  if (rc) return rc;
+  c->prepared = true;
+  t_enq = ms_since();
+  nchunks = c->chunk_col_end.size();
   build_units(c, pl.np);
   // tasks by the chunk of their last column (a stable counting sort: inside a chunk the cache-friendly order stays)
   const int T = c->n_units;
@@ -1054,7 +1120,9 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
 
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
-  const HostLock lk = bytes >= kLockMin ? lock_host(c, src, bytes, hipHostRegisterDefault) : HostLock::Already;
+  const HostLock lk = bytes < kLockMin ? HostLock::Already
+                     : (c->h2d_mode == 1 ? lock_host(c, src, bytes, hipHostRegisterDefault)
+                        : ((!c->force_reg_fail && range_pinned_already(src, bytes)) ? HostLock::Already : HostLock::Refused));
   if (lk == HostLock::Refused) {
     // through the library's pinned bounce buffer, a chunk at a time
     const size_t cap = (size_t)8 << 20;
@@ -1062,7 +1130,7 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
     if (rc) return rc;
     for (size_t off = 0; off < bytes; off += cap) {
       const size_t m = std::min(cap, bytes - off);
-      memcpy(c->pinned, static_cast<const char*>(src) + off, m);
+      par_memcpy(c->pinned, static_cast<const char*>(src) + off, m);
       hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, c->pinned, m, hipMemcpyHostToDevice, c->stream);
       const hipError_t es = hipStreamSynchronize(c->stream);
       if (e == hipSuccess) e = es;
@@ -1081,14 +1149,23 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
   if (bytes >= kLockMin) {
-    const HostLock lk = lock_host(c, dst, bytes, hipHostRegisterDefault);
+    const HostLock lk = c->h2d_mode == 1 ? lock_host(c, dst, bytes, hipHostRegisterDefault)
+                        : ((!c->force_reg_fail && range_pinned_already(dst, bytes)) ? HostLock::Already : HostLock::Refused);
     if (lk == HostLock::Locked) c->locked_out.push_back(dst);
     if (lk == HostLock::Refused) {
-      // into a pinned allocation of the library's; finish_downloads() moves it to the caller's array
-      icikt_ctx::Bounce b{nullptr, dst, bytes};
-      HIPCHK(c, hipHostMalloc(&b.pinned, bytes, hipHostMallocDefault));
-      c->bounced_out.push_back(b);
-      HIPCHK(c, hipMemcpyAsync(b.pinned, src, bytes, hipMemcpyDeviceToHost, c->stream));
+      // into a pinned buffer of the library's (kept from call to call: slot = position among the call's downloads);
+      // finish_downloads() moves it to the caller's array
+      const size_t slot = c->bounced_out.size();
+      if (slot >= c->out_pinned.size()) c->out_pinned.resize(slot + 1);
+      auto& ps = c->out_pinned[slot];
+      if (ps.bytes < bytes) {
+        if (ps.p) (void)hipHostFree(ps.p);
+        ps.p = nullptr; ps.bytes = 0;
+        HIPCHK(c, hipHostMalloc(&ps.p, bytes, hipHostMallocDefault));
+        ps.bytes = bytes;
+      }
+      c->bounced_out.push_back(icikt_ctx::Bounce{ps.p, dst, bytes});
+      HIPCHK(c, hipMemcpyAsync(ps.p, src, bytes, hipMemcpyDeviceToHost, c->stream));
       return ICIKT_SUCCESS;
     }
   }
@@ -1100,10 +1177,8 @@ int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
 void finish_downloads(icikt_ctx* c, bool ok) {
   for (void* p : c->locked_out) (void)hipHostUnregister(p);
   c->locked_out.clear();
-  for (auto& b : c->bounced_out) {
-    if (ok) memcpy(b.dst, b.pinned, b.bytes);
-    (void)hipHostFree(b.pinned);
-  }
+  for (auto& b : c->bounced_out)
+    if (ok) par_memcpy(b.dst, b.pinned, b.bytes);
   c->bounced_out.clear();
 }
 

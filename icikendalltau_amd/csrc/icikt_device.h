@@ -120,15 +120,16 @@ constexpr int K1_TL_BYTES = 1024 + 256 + 256 + 512 + 64;   // (+ 64: the closed-
 // lane)
 __host__ __device__ inline int k1_half_pre(int half_items) { return 32 * (half_items > 8 ? 16 : 8) * 2; }
 
-// half-wave K1 kernels exist for 1..7 and 9 words per lane of a half's prefix rebuild: n <= 18 336 (the packed
-// in-step compares of those kernels need positions below 2^15).  8 words per lane put the lanes' words at a 64-byte
-// stride, an 8-way LDS bank conflict per read (measured at half the speed of one pair per wave), so such columns
-// run the 9-word kernel.  11 and 13 words per lane were built and measured too: +2 % at n = 20 000, -6 % at 24 000
-// against one pair per wave (20 popcounts and more per rebuild, 2 waves per SIMD) -- not kept.
-constexpr int ICIKT_HALF_ITEMS_MAX = 9;
+// half-wave K1 kernels exist for 1..7, 9, 11, 13 and 15 words per lane of a half's prefix rebuild: n <= 30 656 (the packed
+// in-step compares of those kernels need positions -- the guard position 64 W included -- below 2^15).  An EVEN number of
+// words per lane from 8 on puts the lanes' words at a stride of 64 / 128 bytes, an 8- / 16-way LDS bank conflict per read
+// (8 words measured at half the speed of one pair per wave), so such columns run the next odd kernel.  (Round 2 measured
+// 11 and 13 words per lane at 2 waves per SIMD -- the LDS state with `pend` allowed no more -- and did not keep them;
+// without `pend` they run 4 waves per SIMD.)
+constexpr int ICIKT_HALF_ITEMS_MAX = 15;
 __host__ __device__ inline int k1_half_items(int Wp) {
   const int hi = (Wp + 31) >> 5;
-  return hi == 8 ? 9 : hi;
+  return (hi >= 8 && (hi & 1) == 0) ? hi + 1 : hi;
 }
 
 // Stride (in 64-bit words) of a pair's LDS / pend arrays in K1, shared by the kernel and the host plan.  The

@@ -59,6 +59,7 @@ struct icikt_ctx {
   int64_t pairs_nsamp = -1;  // largest column index + 1 seen in the list
   int n_units = 0;
   int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
+  int tied_state = -1;     // 18 337 .. 30 656 rows: do the prepared columns hold many tie groups (1), not (0), not asked yet (-1)
   bool raw_valid = false;  // d_raw holds the pair kernel's counts for the current prepared matrix and pair list
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<icikt::PairRaw> d_raw;

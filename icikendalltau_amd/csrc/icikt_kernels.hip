@@ -332,17 +332,19 @@ __device__ __forceinline__ void k0_step_masks(const unsigned long long* gf, cons
   tmask[(uint32_t)pos + o] = m;
 }
 
-// The whole workgroup builds the program: (A) every position's would-be step, in parallel, into E (u16 per position, LDS);
-// (B) one wave follows the chain from pos0 -- one LDS read per step instead of a hundred dependent scalar operations --
-// writes the entries and lists the MIXED steps; (C) the waves share out the MIXED steps and write their rows' masks.
-// scratch: E (n u16) | list of MIXED step positions (u16) | crossT (32 x 64 u32); `cnt`: one shared int.
+// The whole workgroup builds the program, a WINDOW of TPROG_WIN positions at a time: (A) every position's would-be step,
+// in parallel, into E (u16 per position of the window, LDS); (B) one wave follows the chain from where it stands -- one
+// LDS read per step instead of a hundred dependent scalar operations -- while the step STARTS inside the window, writes
+// the entries and lists the MIXED steps; (C) the waves share out the window's MIXED steps and write their rows' masks.
+// scratch: E (TPROG_WIN u16) | list of MIXED step positions (TPROG_LIST u16: a MIXED step of complete groups that does
+// not reach 33 rows is followed by a longer group, so a window starts at most TPROG_WIN / 17 of them) | crossT (32 x 64
+// u32); `cnt`: three shared ints (MIXED steps of the window; the chain's position and entry count between windows).
+constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;
 __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
                                       int n, int W, uint32_t* prog, uint2* tmask, int tid, int nthreads) {
   const uint32_t lane = (uint32_t)tid & 63u;
   const int wave = tid >> 6, nwaves = nthreads >> 6;
   k0_cross_table(crossT, tid, nthreads);
-  for (int p = tid; p < n; p += nthreads) E[p] = (uint16_t)k0_step_at(gf, n, W, p);
-  __syncthreads();
   if (wave == 0) {
     int first_cont = n;   // first position that continues a group
     for (int w = (int)lane; w < W; w += 64) {
@@ -352,24 +354,37 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     }
     first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
     const int hot_until = (first_cont < n) ? first_cont - 1 : n;
-    int pos = (hot_until >> 6) << 6, ne = 0, nm = 0;
-    while (pos < n) {
-      const uint32_t e = (uint32_t)E[pos];
-      if (lane == 0u) {
-        prog[ne] = e;
-        if (tprog_kind(e) == TPROG_KIND_MIXED) mlist[nm] = (uint16_t)pos;
-      }
-      nm += (tprog_kind(e) == TPROG_KIND_MIXED) ? 1 : 0;
-      ++ne;
-      pos += (int)tprog_rows(e);
-    }
-    if (lane == 0u) { prog[ne] = 0u; *cnt = nm; }
+    if (lane == 0u) { cnt[1] = (hot_until >> 6) << 6; cnt[2] = 0; }
   }
   __syncthreads();
-  const int nm = *cnt;
-  for (int i = wave; i < nm; i += nwaves) {
-    const int pos = (int)mlist[i];
-    k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos], tmask, lane);
+  for (int win = (cnt[1] / TPROG_WIN) * TPROG_WIN; win < n; win += TPROG_WIN) {
+    const int wend = min(n, win + TPROG_WIN);
+    for (int p = win + tid; p < wend; p += nthreads) E[p - win] = (uint16_t)k0_step_at(gf, n, W, p);
+    __syncthreads();
+    if (wave == 0) {
+      int pos = cnt[1], ne = cnt[2], nm = 0;
+      while (pos < wend) {
+        const uint32_t e = (uint32_t)E[pos - win];
+        if (lane == 0u) {
+          prog[ne] = e;
+          if (tprog_kind(e) == TPROG_KIND_MIXED) mlist[nm] = (uint16_t)(pos - win);
+        }
+        nm += (tprog_kind(e) == TPROG_KIND_MIXED) ? 1 : 0;
+        ++ne;
+        pos += (int)tprog_rows(e);
+      }
+      if (lane == 0u) {
+        if (wend == n) prog[ne] = 0u;
+        cnt[0] = nm; cnt[1] = pos; cnt[2] = ne;
+      }
+    }
+    __syncthreads();
+    const int nm = cnt[0];
+    for (int i = wave; i < nm; i += nwaves) {
+      const int pos = win + (int)mlist[i];
+      k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos - win], tmask, lane);
+    }
+    __syncthreads();   // (E and the list are rewritten by the next window)
   }
 }
 
@@ -681,9 +696,9 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     }
     if (tid == 0) sh_bits_lds[W] = 0ull;
     __syncthreads();
-    // scratch in the sort tile / rec staging area (48 KB, copied out above): E 18 432 u16 | crossT 2 048 u32 | list 1 536 u16
+    // scratch in the sort tile / rec staging area (48 KB, copied out above): E TPROG_WIN u16 | crossT 2 048 u32 | list
     uint16_t* E = reinterpret_cast<uint16_t*>(sh_sort);
-    uint32_t* crossT = reinterpret_cast<uint32_t*>(E + 18432);
+    uint32_t* crossT = reinterpret_cast<uint32_t*>(E + TPROG_WIN);
     uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
     k0_tie_program(sh_bits_lds, E, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
                    pv.tmask + (int64_t)c * pv.n_ord, tid, K0_THREADS);
@@ -763,9 +778,9 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
   __shared__ uint32_t kx_cross[32 * 64];   // k0_tie_program's scratch: cross table, would-be steps, MIXED step list
-  __shared__ uint16_t kx_E[18432];
-  __shared__ uint16_t kx_list[1536];
-  __shared__ int kx_cnt;
+  __shared__ uint16_t kx_E[TPROG_WIN];
+  __shared__ uint16_t kx_list[TPROG_LIST];
+  __shared__ int kx_cnt[3];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   const int c = col_begin + (int)blockIdx.x;
@@ -854,7 +869,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     unsigned long long* gfl = reinterpret_cast<unsigned long long*>(prevs);   // the scan arrays are free now: 1032 ints = 516 words
     for (int w = (int)threadIdx.x; w <= W; w += 64 * KX_WAVES) gfl[w] = gf[w];
     __syncthreads();
-    k0_tie_program(gfl, kx_E, kx_list, kx_cross, &kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+    k0_tie_program(gfl, kx_E, kx_list, kx_cross, kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride,
                    pv.tmask + (int64_t)c * pv.n_ord, (int)threadIdx.x, 64 * KX_WAVES);
   }
 }
@@ -1408,7 +1423,7 @@ __device__ unsigned long long g_step_stats[24];
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, int HI>
-__global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
+__global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : (HI > 9) ? 5 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
                                                                      // Two long-column pairs per wave: the LDS state allows 2-3 waves per SIMD, 3 leave 168 VGPRs
 k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
          const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, PairRaw* __restrict__ raw,
@@ -3138,6 +3153,9 @@ static k1_fn_t k1_select(int np, int half_items) {
       case 6: return &k1_pairs<2, 6>;
       case 7: return &k1_pairs<2, 7>;
       case 9: return &k1_pairs<2, 9>;
+      case 11: return &k1_pairs<2, 11>;
+      case 13: return &k1_pairs<2, 13>;
+      case 15: return &k1_pairs<2, 15>;
       default: return nullptr;
     }
   }

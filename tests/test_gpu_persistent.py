@@ -92,6 +92,33 @@ def test_two_pairs_per_wave_long_columns(plan_ctx, n):
     assert np.array_equal(two[0], one[0], equal_nan=True) and np.array_equal(two[1], one[1])
 
 
+@pytest.mark.parametrize("n", [18337, 22529, 26624, 30656])
+def test_half_wave_kernels_11_to_15_words(plan_ctx, n):
+    """18 337 .. 30 656 rows: both kernel families fit -- the half-wave kernels with 11, 13 and 15 words per lane (the
+    column's tie program cut in two windows of 16 384 positions by the pre-pass) and two pairs on the whole wave; the
+    library chooses by the columns' tie groups (matrix_tied).  Each family forced, and the library's own choice, on tied /
+    censored / scattered-missing columns: all pairs, both perspectives, against the oracle; the families agree bit for
+    bit on the doubles too."""
+    X = _tied_matrix(n, 20, seed=n)
+    plan_ctx.debug_set_plan({"half": 1})
+    _all_pairs_vs_oracle(plan_ctx, X)
+    h = plan_ctx.pairs(X, perspective="global")
+    plan_ctx.debug_set_plan({"half": 0})
+    w = plan_ctx.pairs(X, perspective="global")
+    plan_ctx.debug_set_plan(None)
+    d = plan_ctx.pairs(X, perspective="global")
+    for a, b in ((h, w), (h, d)):
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    # ... and continuous columns (the library takes the whole-wave kernels), through the pipelined host path as well
+    rng = np.random.default_rng(n)
+    Y = np.asfortranarray(rng.standard_normal((n, 130)))
+    Y[rng.random(Y.shape) < 0.02] = np.nan
+    ref = plan_ctx.pairs(Y, perspective="global")
+    plan_ctx.debug_set_plan({"half": 1})
+    got = plan_ctx.pairs(Y, perspective="global")
+    assert np.array_equal(ref[0], got[0], equal_nan=True) and np.array_equal(ref[1], got[1])
+
+
 def test_persistent_grid_natural_plan(hip_ctx):
     """36 000 x 128 = 8 128 tasks against the ~5 000 waves the chip holds at that length: the library's own plan
     makes waves take a second task.  Oracle on 300 sampled pairs, count identities on all."""

@@ -11,6 +11,9 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <string>
 #include <vector>
@@ -408,6 +411,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   if (c->pinned_tasks) (void)hipHostFree(c->pinned_tasks);
   for (auto& ps : c->out_pinned)
     if (ps.p) (void)hipHostFree(ps.p);
+  if (c->copy_pool) { icikt::host::destroy_copy_pool(c->copy_pool); c->copy_pool = nullptr; }
   for (auto& e : c->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
@@ -832,54 +836,104 @@ HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
 }
 
 // Host-side copies into / out of the library's pinned buffers, on a few threads: one core moves ~10 GB/s, the c4
-// matrix is 82 MB and PCIe takes it in 1.8 ms.  `rows` pieces of `row_bytes`, strides in bytes (a contiguous copy: one row).
-static void par_copy2d(void* dst, size_t dst_stride, const void* src, size_t src_stride, size_t row_bytes, size_t rows) {
+// matrix is 82 MB and PCIe takes it in 1.8 ms.  The threads belong to the context (started on first use, parked on a
+// condition variable between copies: creating and joining seven threads per chunk cost ~0.2 ms a time, a millisecond of
+// a c4 call); a copy is cut into parts that the workers and the calling thread take from a shared counter.
+struct CopyPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  const std::function<void(unsigned)>* job = nullptr;
+  unsigned nparts = 0, done = 0;
+  std::atomic<unsigned> next{0};
+  unsigned long long gen = 0;
+  bool stop = false;
+  unsigned active = 0;   // workers that hold the current job (a copy is over when all parts are done AND nobody holds it)
+  void worker() {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* f;
+      unsigned n;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen; f = job; n = nparts;
+        if (!f) continue;          // woke after the copy was over
+        ++active;
+      }
+      unsigned mine = 0;
+      for (unsigned i = next.fetch_add(1); i < n; i = next.fetch_add(1)) { (*f)(i); ++mine; }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        done += mine;
+        --active;
+        if (done == nparts && active == 0) cv_done.notify_one();
+      }
+    }
+  }
+  bool start(unsigned n) {
+    try {
+      while (th.size() < n) th.emplace_back(&CopyPool::worker, this);
+    } catch (...) {}
+    return !th.empty();
+  }
+  void run(unsigned n, const std::function<void(unsigned)>& f) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f; nparts = n; done = 0; next.store(0); ++gen;
+    }
+    cv_work.notify_all();
+    unsigned mine = 0;
+    for (unsigned i = next.fetch_add(1); i < n; i = next.fetch_add(1)) { f(i); ++mine; }
+    std::unique_lock<std::mutex> lk(m);
+    done += mine;
+    cv_done.wait(lk, [&] { return done == nparts && active == 0; });
+    job = nullptr;
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_work.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+void destroy_copy_pool(void* p) { delete static_cast<CopyPool*>(p); }
+
+// `rows` pieces of `row_bytes`, strides in bytes (a contiguous copy: one row)
+static void par_copy2d(icikt_ctx* c, void* dst, size_t dst_stride, const void* src, size_t src_stride, size_t row_bytes, size_t rows) {
   const size_t total = row_bytes * rows;
   unsigned nt = (unsigned)std::min<size_t>(8, total / ((size_t)2 << 20));   // (12 threads measured slower than 8 on the pool's boxes)
-  if (rows == 1 && nt > 1) {   // a contiguous copy: cut it into nt pieces
-    const size_t piece = ((total / nt) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    try {
-      for (unsigned t = 1; t < nt; ++t) {
-        const size_t off = (size_t)t * piece;
-        if (off >= total) break;
-        th.emplace_back([=]() { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, total - off)); });
-      }
-      memcpy(dst, src, std::min(piece, total));
-    } catch (...) {
-      for (auto& t : th) t.join();
-      memcpy(dst, src, total);   // could not start threads: one core does it all
-      return;
-    }
-    for (auto& t : th) t.join();
+  CopyPool* pool = nullptr;
+  if (nt > 1) {
+    if (!c->copy_pool) { try { c->copy_pool = new CopyPool(); } catch (...) { c->copy_pool = nullptr; } }
+    pool = static_cast<CopyPool*>(c->copy_pool);
+    if (!pool || !pool->start(7)) pool = nullptr;
+  }
+  if (!pool) {   // small, or no threads to be had: one core does it all
+    for (size_t r = 0; r < rows; ++r)
+      memcpy(static_cast<char*>(dst) + r * dst_stride, static_cast<const char*>(src) + r * src_stride, row_bytes);
     return;
   }
-  nt = (unsigned)std::min<size_t>(std::max(1u, nt), rows);
-  auto work = [=](size_t r0, size_t r1) {
+  if (rows == 1) {   // a contiguous copy: pieces of ~1 MB
+    const size_t piece = (size_t)1 << 20;
+    const unsigned parts = (unsigned)((total + piece - 1) / piece);
+    const std::function<void(unsigned)> f = [=](unsigned i) {
+      const size_t off = (size_t)i * piece;
+      memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, total - off));
+    };
+    pool->run(parts, f);
+    return;
+  }
+  const size_t per = std::max<size_t>(1, ((size_t)1 << 20) / std::max<size_t>(row_bytes, 1));   // rows per part: ~1 MB
+  const unsigned parts = (unsigned)((rows + per - 1) / per);
+  const std::function<void(unsigned)> f = [=](unsigned i) {
+    const size_t r0 = (size_t)i * per, r1 = std::min(rows, r0 + per);
     for (size_t r = r0; r < r1; ++r)
       memcpy(static_cast<char*>(dst) + r * dst_stride, static_cast<const char*>(src) + r * src_stride, row_bytes);
   };
-  if (nt <= 1) { work(0, rows); return; }
-  std::vector<std::thread> th;
-  const size_t per = (rows + nt - 1) / nt;
-  size_t done_to = per;   // the calling thread takes the first share
-  try {
-    for (unsigned t = 1; t < nt; ++t) {
-      const size_t r0 = (size_t)t * per, r1 = std::min(rows, r0 + per);
-      if (r0 >= rows) break;
-      th.emplace_back(work, r0, r1);
-      done_to = r1;
-    }
-  } catch (...) {
-    for (auto& t : th) t.join();
-    work(done_to, rows);       // the shares no thread took
-    work(0, std::min(per, rows));
-    return;
-  }
-  work(0, std::min(per, rows));
-  for (auto& t : th) t.join();
+  pool->run(parts, f);
 }
-static void par_memcpy(void* dst, const void* src, size_t bytes) { par_copy2d(dst, 0, src, 0, bytes, 1); }
+static void par_memcpy(icikt_ctx* c, void* dst, const void* src, size_t bytes) { par_copy2d(c, dst, 0, src, 0, bytes, 1); }
 
 int ensure_bounce(icikt_ctx* c, size_t need) {
   if (c->pinned_bytes >= need) return ICIKT_SUCCESS;
@@ -941,7 +995,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_copy[0], 0);
     if (e == hipSuccess && pipelined) e = hipStreamWaitEvent(c->prep_stream, c->ev_copy[0], 0);
     int k = 0;
-    const int64_t first_chunk = chunk;   // (a short first chunk was measured: five chunks staged 0.6 ms slower than four)
+    const int64_t first_chunk = chunk;   // (a short first chunk was measured twice: no gain -- what the last pair-kernel launch waits for is the last chunk's pre-pass, which finds no free CU until the launch before it drains)
     for (int64_t c0 = col_begin, step = first_chunk; c0 < col_end && e == hipSuccess && rc == 0; c0 += step, step = chunk, ++k) {
       const int64_t nc = std::min<int64_t>(step, col_end - c0);
       double* dst = c->d_X.p + (size_t)c0 * (size_t)n_feat;
@@ -950,7 +1004,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
         char* stage = static_cast<char*>(c->pinned) + (size_t)(k & 1) * (size_t)chunk * col_bytes;
         if (k >= 2) e = hipEventSynchronize(c->ev_copy[1 + ((k - 2) % 3)]);  // the copy that last used this half
         if (e != hipSuccess) break;
-        par_copy2d(stage, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc);
+        par_copy2d(c, stage, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc);
         e = hipMemcpyAsync(dst, stage, (size_t)nc * col_bytes, hipMemcpyHostToDevice, c->copy_stream);
       } else {
         e = hipMemcpy2DAsync(dst, col_bytes, X + c0 * ld, (size_t)ld * sizeof(double), col_bytes, (size_t)nc,
@@ -1169,7 +1223,7 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
     if (rc) return rc;
     for (size_t off = 0; off < bytes; off += cap) {
       const size_t m = std::min(cap, bytes - off);
-      par_memcpy(c->pinned, static_cast<const char*>(src) + off, m);
+      par_memcpy(c, c->pinned, static_cast<const char*>(src) + off, m);
       hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, c->pinned, m, hipMemcpyHostToDevice, c->stream);
       const hipError_t es = hipStreamSynchronize(c->stream);
       if (e == hipSuccess) e = es;
@@ -1217,7 +1271,7 @@ void finish_downloads(icikt_ctx* c, bool ok) {
   for (void* p : c->locked_out) (void)hipHostUnregister(p);
   c->locked_out.clear();
   for (auto& b : c->bounced_out)
-    if (ok) par_memcpy(b.dst, b.pinned, b.bytes);
+    if (ok) par_memcpy(c, b.dst, b.pinned, b.bytes);
   c->bounced_out.clear();
 }
 

@@ -69,6 +69,7 @@ struct icikt_ctx {
   // filled by a kernel at once, the host copies (h_pi / h_pj: only the host-built task lists read them) on demand
   int64_t combn_S = -1, combn_begin = 0, combn_end = 0;
   bool h_pairs_valid = false;
+  void* copy_pool = nullptr;      // worker threads of the staged transfers' host-side copies (icikt_capi.cpp: CopyPool)
   void* pinned_tasks = nullptr;   // pinned staging of the task list the pipelined host path generates chunk by chunk
   size_t pinned_tasks_bytes = 0;
   bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
@@ -184,6 +185,7 @@ enum class HostLock { Locked /* by this call: unregister afterwards */, Already 
 HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags);
 // grow c->pinned to at least `need` bytes (no copy may be in flight from or into it)
 int ensure_bounce(icikt_ctx* c, size_t need);
+void destroy_copy_pool(void* pool);
 // H2D on c->stream, complete (and the host range released) on return
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 // after the stream that carries download() copies has been synchronised: end the page-locking of their targets and

@@ -951,8 +951,9 @@ __device__ __forceinline__ uint32_t half_count(uint32_t q, uint32_t lo, uint32_t
 
 // ---- both 32-row sub-steps of a half-wave step in one chain (hot steps) -----------------------------------------
 // The in-step pairs of a sub-step need registers only, so the two sub-steps of a 64-row step are counted TOGETHER,
-// one in each 16-bit half of the operands (positions of a half-wave kernel are < 16 384 = 14 bits):
-//     A = 0x3FFF - q   (what a row offers)        B = 0x4000 + lo   (what a row compares with)
+// one in each 16-bit half of the operands (positions of a half-wave kernel -- the guard position 64 W included -- are
+// below 2^15: n <= 30 656):
+//     A = 0x7FFF - q   (what a row offers)        B = lo   (what a row compares with)
 //     A_a + B_j = 0x7FFF + lo_j - q_a :  bit 15 set  <=>  q_a < lo_j,  and nothing carries into the upper half.
 // One DPP add per shift distance serves 2 x 64 compares, and its two flag bits (15, 31) are shifted into a bit
 // vector by two full-rate instructions (v_lshrrev, v_and_or) -- the carry forms of half_allpairs (v_sub_co_dpp +

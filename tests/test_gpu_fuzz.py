@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("seed,big,cases", [(11, False, 120), (12, False, 120), (13, False, 120), (14, True, 40)])
-def test_random_sweep(plan_ctx, seed, big, cases, tmp_path, monkeypatch):
+@pytest.mark.parametrize("seed,mode,cases", [(11, "", 120), (12, "", 120), (13, "", 120), (14, "big", 40),
+                                             (15, "mid", 60), (16, "ext", 300)])
+def test_random_sweep(plan_ctx, seed, mode, cases, tmp_path, monkeypatch):
     import fuzz_gpu
 
-    monkeypatch.setattr(fuzz_gpu, "BIG", big)  # long columns only (10 000 .. 65 535 rows)
+    monkeypatch.setattr(fuzz_gpu, "BIG", mode == "big")  # long columns only (10 000 .. 65 535 rows)
+    monkeypatch.setattr(fuzz_gpu, "MID", mode == "mid")  # 16 000 .. 31 000 rows, two more tie models
+    monkeypatch.setattr(fuzz_gpu, "EXT", mode == "ext")  # the default lengths with those models
 
     monkeypatch.chdir(tmp_path)          # failing inputs are dumped under ./gpurun_out
     os.makedirs("gpurun_out", exist_ok=True)

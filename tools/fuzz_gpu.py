@@ -5,7 +5,11 @@ levels, blocks of equal values, constants), a missingness pattern (random, left-
 a K1 launch plan override (pairs per wave, pend placement, half-wave step, joint-tie mode), then compares
 counts bit-exactly and the four doubles within 1e-10 for both perspectives.
 
-    python tools/fuzz_gpu.py [cases] [seed] [big]
+    python tools/fuzz_gpu.py [cases] [seed] [big|mid|ext]
+
+`mid`: 16 000 .. 31 000 rows (both kernel families of 18 337 .. 30 656 rows, the windows of the tie program) with
+two more value models: many small tie groups (n / 2 .. n / 40 distinct values) and a tied region beside a
+continuous one.  `ext`: the default lengths with those two models.
 """
 import os
 import sys
@@ -19,11 +23,19 @@ from oracle import oracle as O
 
 ATOL = 1e-10
 BIG = False  # set by main(): argv[3] == 'big'
+MID = False  # set by main(): argv[3] == 'mid'
+EXT = False  # set by main(): argv[3] == 'ext' (the default lengths with the two extra value models)
 
 
 def make_column(rng, n):
-    kind = rng.integers(0, 8)
-    if kind == 0:
+    kind = rng.integers(0, 10 if (MID or EXT) else 8)
+    if kind == 8:  # many small tie groups
+        x = np.round(rng.standard_normal(n) * n / (2.5 * float(rng.choice([2, 4, 8, 24, 40]))))
+    elif kind == 9:  # half of the column tied in small groups, half continuous
+        x = rng.standard_normal(n)
+        lowhalf = x < np.median(x)
+        x[lowhalf] = np.round(x[lowhalf] * float(rng.choice([50, 500, 3000])))
+    elif kind == 0:
         x = rng.standard_normal(n)
     elif kind == 1:
         x = np.round(rng.standard_normal(n) * rng.choice([0.5, 2, 10, 100]))
@@ -63,6 +75,8 @@ def one_case(ctx, rng, case):
     r = rng.random()
     if BIG:  # long columns only: the one-pair-per-wave kernels, pend in LDS and in global memory
         n = int(rng.integers(10000, 65536))
+    elif MID:
+        n = int(rng.integers(16000, 31000))
     elif r < 0.55:
         n = int(rng.integers(1, 700))
     elif r < 0.9:
@@ -70,7 +84,7 @@ def one_case(ctx, rng, case):
     else:
         n = int(rng.integers(6000, 40000))
     S = int(rng.integers(2, 9)) if n < 6000 else int(rng.integers(2, 5))
-    if BIG:
+    if BIG or MID:
         S = int(rng.integers(2, 4))
     X = np.asfortranarray(np.stack([make_column(rng, n) for _ in range(S)], axis=1))
     if rng.random() < 0.3 and S > 2:  # correlated columns: shared rows missing, shared ties
@@ -115,8 +129,10 @@ def one_case(ctx, rng, case):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    global BIG
+    global BIG, MID, EXT
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+    MID = len(sys.argv) > 3 and sys.argv[3] == "mid"
+    EXT = len(sys.argv) > 3 and sys.argv[3] == "ext"
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
     os.makedirs("gpurun_out", exist_ok=True)

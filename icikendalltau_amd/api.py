@@ -106,10 +106,17 @@ class MultiHipEngine(HipEngine):
         self._single = None
         self.flags = _lib.FLAG_EXACT_INT64 if exact_int64 else 0
 
-    def missingness(self, X, pi, pj):  # a bitset popcount: one device is plenty
+    def _one(self):
         if self._single is None:
             self._single = _lib.default_context(self.ctx.devices[0])
-        return self._single.missingness(X, pi, pj)
+        return self._single
+
+    def missingness(self, X, pi, pj):  # a bitset popcount: one device is plenty
+        return self._one().missingness(X, pi, pj)
+
+    def pairs_complete(self, X, pi, pj):  # kt_fast's per-pair masking path exists on one device only
+        out, _cnt, rsn = self._one().pairs_complete(X, pi, pj, "two.sided", False, self.flags)
+        return out, rsn
 
 
 def _default_engine():
@@ -190,12 +197,21 @@ def ici_kt(x, y, perspective="local", alternative="two.sided", continuity=False,
     return IciKtResult(out[0])
 
 
+def _na_rm(a: np.ndarray) -> np.ndarray:
+    """The non-missing values of `a`.  NOT np.nanmax / np.nanmin: R's NA_real_ -- the pattern the library returns for a
+    pair without a result, and what a matrix read from an .rda file holds -- is a SIGNALLING NaN, and the C fmax / fmin
+    behind numpy's NaN-skipping reductions answer NaN for one (the running maximum is lost wherever such a cell meets
+    the scalar tail of the reduction)."""
+    a = np.asarray(a)
+    return a[~np.isnan(a)]
+
+
 def _ici_kt_report(x, y, perspective, continuity, out4, k) -> str:
     """The text ici_kt(output != "simple") writes to Rcout (src/kendallc.cpp:342-363), rebuilt from the counts
     record: integers print as integers, doubles as std::to_string prints them ("%f")."""
     keep = ~(np.isnan(x) & np.isnan(y)) if perspective == "local" else np.ones(x.shape[0], bool)
     x2, y2 = x[keep].copy(), y[keep].copy()
-    min_x, min_y = np.nanmin(x2) - 0.1, np.nanmin(y2) - 0.1          # :214-215
+    min_x, min_y = _na_rm(x2).min() - 0.1, _na_rm(y2).min() - 0.1    # :214-215
     x2[np.isnan(x2)] = min_x
     y2[np.isnan(y2)] = min_y
     sum_obs = len(np.unique(np.stack([x2, y2], axis=1), axis=0)) + 1  # joint runs + 1 (:261-263)
@@ -501,7 +517,8 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
 
     # scale_and_reshape
     if scale_max:
-        max_cor = np.nanmax(taumax) if np.any(~np.isnan(taumax)) else np.nan  # max(taumax, na.rm = TRUE)
+        have = _na_rm(taumax)                                           # max(taumax, na.rm = TRUE)
+        max_cor = have.max() if have.size else np.nan
         cor = raw / max_cor
     else:
         cor = raw.copy()

@@ -29,3 +29,23 @@ def test_random_sweep(plan_ctx, seed, mode, cases, tmp_path, monkeypatch):
         if status == "FAIL":
             bad.append(desc)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("mode,seed,cases", [("", 21, 400), ("multi2", 22, 150)])
+def test_random_front_end_sweep(hip_ctx, mode, seed, cases, tmp_path, monkeypatch):
+    """tools/fuzz_matrix.py: ici_kendalltau through the one-call matrix entry and through the pair-list route, kt_fast,
+    pairwise_completeness on the HIP engine (one device; two ranks on it) against the same front-end on the oracle."""
+    import fuzz_matrix
+    from icikendalltau_amd import api
+    from tests.oracle_engine import OracleEngine
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(seed)
+    hip = api.MultiHipEngine(devices=[0, 0]) if mode == "multi2" else api.HipEngine()
+    orc = OracleEngine()
+    bad = []
+    for case in range(cases):
+        status, desc = fuzz_matrix.one_case(rng, case, hip, orc)
+        if status == "FAIL":
+            bad.append(desc)
+    assert not bad, "\n".join(bad)

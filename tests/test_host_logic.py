@@ -144,6 +144,26 @@ def test_warnings_and_na_rows():
         api.ici_kt([1.0, 2.0], [2.0], engine=ENG)
 
 
+def test_scaling_skips_na_pairs_wherever_they_sit():
+    """max(taumax, na.rm = TRUE) (R/kendalltau.R:368-373) over results that hold R's NA_real_ -- a SIGNALLING NaN, for
+    which numpy's NaN-skipping reductions are not safe (C fmax answers NaN for one): NA pairs in the middle and at the
+    end of the pair list, and the maximum in front of them."""
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((60, 4))
+    X[:5, 0] = np.nan                  # taumax < 1 for every pair but (s2, s3)
+    X[:, 3] = 4.25                     # a constant column: its three pairs are NA, the last two of the list among them
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = api.ici_kendalltau(X, global_na=[np.nan], colnames=_names(4), return_matrix=False, engine=ENG)["cor"]
+    tm, raw, cor = r["taumax"].to_numpy()[:6], r["raw"].to_numpy()[:6], r["cor"].to_numpy()[:6]
+    assert np.isnan(tm).tolist() == [False, False, True, False, True, True]
+    assert tm.view(np.uint64)[2] == 0x7FF00000000007A2        # NA_real_, not a quiet NaN
+    best = max(t for t in tm if t == t)
+    assert best == tm[3] == 1.0 and tm[0] < 1.0
+    ok = ~np.isnan(tm)
+    assert np.array_equal(cor[ok], raw[ok] / best) and np.all(np.isnan(cor[~ok]))
+
+
 def test_setup_comparisons_order_and_cores():
     pi, pj, core = api.setup_comparisons(_names(5), ncore=3)
     assert list(zip(pi, pj))[:5] == [(0, 1), (0, 2), (0, 3), (0, 4), (1, 2)]  # utils::combn order

@@ -49,3 +49,21 @@ def test_random_front_end_sweep(hip_ctx, mode, seed, cases, tmp_path, monkeypatc
         if status == "FAIL":
             bad.append(desc)
     assert not bad, "\n".join(bad)
+
+
+def test_random_transfer_path_sweep(plan_ctx, tmp_path, monkeypatch):
+    """tools/fuzz_pipe.py: matrices of 9 .. 48 MB with a random leading dimension through icikt_pairs_f64 /
+    icikt_matrix_f64 in one piece and pipelined by chunks (random transfer mode and pairs per wave): the same bytes."""
+    import fuzz_gpu
+    import fuzz_pipe
+
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("gpurun_out", exist_ok=True)
+    monkeypatch.setattr(fuzz_gpu, "MID", False)   # (fuzz_pipe switches the ten value models on)
+    rng = np.random.default_rng(31)
+    bad = []
+    for case in range(40):
+        status, desc = fuzz_pipe.one_case(plan_ctx, rng, case)
+        if status == "FAIL":
+            bad.append(desc)
+    assert not bad, "\n".join(bad)

@@ -472,7 +472,8 @@ static int check_col_range(icikt_ctx* c, int64_t n_samp, int64_t col_begin, int6
   if (col_begin < 0 || col_end < col_begin || col_end > n_samp || alloc_cols < n_samp)
     return fail(c, ICIKT_E_INVALID, "prepare: bad column range");
   // rec is interleaved in blocks of two columns: a column range is contiguous memory only on even boundaries
-  if ((col_begin & 1) || ((col_end & 1) && col_end != n_samp))
+  // (an EMPTY range is fine wherever it sits: a rank beyond the last column of an odd-width matrix has [n_samp, n_samp))
+  if (col_begin < col_end && ((col_begin & 1) || ((col_end & 1) && col_end != n_samp)))
     return fail(c, ICIKT_E_INVALID, "prepare: a column range must start on an even column and end on one (or at n_samp)");
   return ICIKT_SUCCESS;
 }

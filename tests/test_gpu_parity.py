@@ -445,18 +445,19 @@ def test_int32_wrap_regime_matches_oracle(hip_ctx):
         _check(hip_ctx, X, perspective=p, flags=1)
 
 
-def test_sharded_prepass_matches_full(hip_ctx):
+@pytest.mark.parametrize("S,world", [(10, 4), (5, 4), (3, 3)])
+def test_sharded_prepass_matches_full(hip_ctx, S, world):
     """icikt_prepare_cols_dev over column ranges (what ranks do before the all-gather) fills the same
-    prepared state as one full icikt_prepare_dev."""
+    prepared state as one full icikt_prepare_dev.  (5, 4) and (3, 3): the last rank's range is EMPTY and starts at an
+    odd column -- it used to be refused, which sent every rank back to the replicated pre-pass.)"""
     import torch
     rng = np.random.default_rng(59)
-    n, S = 900, 10
+    n = 900
     X = np.asfortranarray(rng.standard_normal((n, S)))
     X[rng.random(X.shape) < 0.1] = np.nan
-    X[:, 3] = np.round(X[:, 3] * 2)
+    X[:, S - 1] = np.round(X[:, S - 1] * 2)
     full, _, _ = hip_ctx.pairs(X, perspective="global", want_counts=False)
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
-    world = 4
     cols_per = 2 * -(-S // (2 * world))  # even: the rec table interleaves column pairs
     alloc = cols_per * world
     for r in range(world):  # one context plays all ranks in turn: the slices land in the same arrays

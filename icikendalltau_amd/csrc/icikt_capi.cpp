@@ -151,6 +151,9 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     pl.opts &= ~1;
     pl.half_items = 0;
   }
+  // bit 2: two long-column pairs of a whole-wave kernel take the singleton region in the half layout (one pair per
+  // 32-lane half, 32-row sub-steps, the half-wave in-step chain)
+  if (np == 2 && pl.half_items == 0 && ov.hyb != 0) pl.opts |= 4;
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
   if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items));  // seen + prefix slots
@@ -1627,6 +1630,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "pend") ov.pend = (val[0] == 'g') ? 1 : 0;
     else if (key == "wpb") ov.wpb = atoi(val.c_str());
     else if (key == "half") ov.half = (val[0] == '1') ? 1 : 0;
+    else if (key == "hyb") ov.hyb = (val[0] == '1') ? 1 : 0;
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());

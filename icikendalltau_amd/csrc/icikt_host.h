@@ -112,7 +112,7 @@ struct icikt_ctx {
 
   // launch-plan overrides of the pair kernel (icikt_debug_set_plan; -1 = the library's choice)
   struct PlanOverride {
-    int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1, grid_cap = -1;
+    int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1, grid_cap = -1, hyb = -1;
     bool has_tgmax = false;
     int tgmax = 0;
     bool verbose = false;

@@ -1778,6 +1778,60 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint32_t rk_prev[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) rk_prev[k] = 0u;
+      if (NP == 2 && HI == 0 && pack2 && (opts & 4)) {
+        // Two long-column pairs in the HALF LAYOUT (round 3): lanes 0..31 take pair 0, lanes 32..63 pair 1, a 64-row step
+        // is two 32-row sub-steps whose rows meet through `seen` -- the in-step pairs are then the half-wave chain
+        // (half_step_count: 15 + 8 distances for both sub-steps and both pairs, ~57 instructions) instead of one packed
+        // whole-wave chain per pair (~105 for two steps of ONE pair), and every LDS instruction of a sub-step serves both
+        // pairs.  The count structure stays the two-level one; only its exchange changes: a half has 32 lanes for the 64
+        // owner bins, so a lane reads-and-clears TWO bins (one 64-bit exchange) and adds their exclusive sums to two lb
+        // entries (one 64-bit add).  Positions above 2^15 are compared halved, as in the packed whole-wave chain.
+        const bool hiH = lane >= 32u;
+        const uint32_t l32 = lane & 31u;
+        const TwoLevel TH = tl_view(hiH ? S[NP - 1].L.seen : S[0].L.seen, hiH ? S[NP - 1].L.spre : S[0].L.spre);
+        unsigned long long* const hist2 = reinterpret_cast<unsigned long long*>(TH.hist) + l32;
+        unsigned long long* const lb2 = reinterpret_cast<unsigned long long*>(TH.lb) + l32;
+        uint32_t dh = 0u;
+        do {
+          uint32_t rk[NP];
+          if (rk_ok) {
+            take_rk(rk);
+          } else {
+            const uint2 rv = gload_rec2(rec_blk, r0);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) rk[k] = comp[k] ? rv.y : rv.x;
+          }
+          pos += 64;
+          advance64();
+          const auto sw = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t r = sub ? sw[1] : sw[0];
+            const uint32_t cnt = tl_query(TH, r >> 16, IT, magic);
+            wave_lds_fence();
+            seen_insert(TH.seen, r & 0xFFFFu);
+            tl_update_rows(TH, r & 0xFFFFu);
+            wave_lds_fence();
+            const unsigned long long hh = atomicExch(hist2, 0ull);
+            if (sub == 0) {   // the chain of the whole step: registers only, between the issue of the atomics and the wait for them
+              uint32_t ka = sw[0], kb = sw[1];
+              if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
+                ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
+                kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+              }
+              dh += half_step_count(ka, kb, lane, partner_addr);
+            }
+            dh += cnt;
+            const uint32_t h0 = (uint32_t)hh, h1 = (uint32_t)(hh >> 32), hs = h0 + h1;
+            const uint32_t below0 = half_incl_scan(hs) - hs, below1 = below0 + h0;
+            if ((below0 | below1) != 0u) atomicAdd(lb2, (unsigned long long)below0 | ((unsigned long long)below1 << 32));
+            wave_lds_fence();
+          }
+          ICIKT_ST_MARK(0, 64)
+        } while (pos + 64 <= hot_until);
+        S[0].dis += hiH ? 0u : dh;
+        S[NP - 1].dis += hiH ? dh : 0u;
+      } else
       if (HI == 0 && pack2) {
         // One pair per wave (or two, one after the other) with the packed two-step chain.  A step's LDS work is two
         // dependent round trips -- the query's reads, then the histogram exchange behind the insertions' atomics -- and at

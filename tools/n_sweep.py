@@ -6,7 +6,9 @@ from icikendalltau_amd import _lib
 from bench import make_matrix
 
 ns = [int(a) for a in sys.argv[1:]] or [2000, 5000, 10000, 16000, 17000, 25000, 26000, 40000, 65535]
-variants = [dict(), dict(np="1"), dict(np="1", pend="g"), dict(np="1", pend="l"), dict(np="2", pend="g"), dict(np="2", pend="g", wpb="1"), dict(np="2", pend="g", wpb="3")]
+variants = [dict(), dict(np="1"), dict(np="2"), dict(np="2", wpb="1"), dict(np="2", wpb="3"), dict(np="2", hyb="1"), dict(np="2", hyb="1", wpb="3"), dict(np="2", hyb="1", wpb="1")]
+if os.environ.get("VARIANTS"):
+    variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in os.environ["VARIANTS"].split(";")]
 ctx = _lib.Context(0)
 for n in ns:
     S = 512
@@ -27,6 +29,6 @@ for n in ns:
             ts.append(ctx.kernel_ms(_lib.K_PAIRS)[0])
         o = out.cpu().numpy()
         if ref is None: ref = o.copy()
-        tag = "default" if not v else "np" + v["np"] + v.get("pend", "") + ("w" + v["wpb"] if "wpb" in v else "")
+        tag = "default" if not v else ",".join(f"{k}={x}" for k, x in v.items())
         line.append(f"{tag} {P / (min(ts) / 1e3):.3e}{'' if np.array_equal(o, ref, equal_nan=True) else ' DIFF'}")
     print("  ".join(line), flush=True)

@@ -71,7 +71,9 @@ def hot_loop_mix(want):
     #  one that runs on columns without odd-positioned tie groups, i.e. on every benchmark workload)
     loops = [x for x in hot_loops(want, verbose=True) if x[2].get("global", 0) > 0]
     packed = [x for x in loops if any("v_perm_b32" in l for l in x[3])]
-    a, b, cnt, _ = (packed or loops)[0]
+    # two long-column pairs per wave: the singleton region runs in the half layout (the loop with v_permlane32_swap)
+    swapped = [x for x in packed if any("permlane32_swap" in l for l in x[3])] if "Li2ELi0E" in want else []
+    a, b, cnt, _ = (swapped or packed or loops)[0]
     return {"kernel": want, "full": cnt.get("vF", 0), "half": cnt.get("vH", 0), "permlane": cnt.get("v8", 0),
             "ds": cnt.get("ds", 0), "global": cnt.get("global", 0), "salu_and_waits": cnt.get("s", 0)}
 

@@ -978,6 +978,49 @@ __device__ __forceinline__ uint32_t half_partner_addr(uint32_t lane) {
   const uint32_t p = lane & 15u, h = lane & 32u;
   return ((lane & 16u) ? (h + p) : (h + 16u + ((p + 15u) & 15u))) * 4u;
 }
+// (in three parts for the long-column kernels, which spread the chain over the LDS waits of a step's two sub-steps: the
+//  operands with the partners' offers -- one ds_bpermute --, the in-row sums, the sums between the rows)
+struct HalfChain { uint32_t A, B, offer, xa; };
+__device__ __forceinline__ HalfChain half_step_prep(uint32_t sw0, uint32_t sw1, uint32_t lane, uint32_t partner_addr) {
+  HalfChain h;
+  const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
+  const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
+  h.A = 0x7FFF7FFFu - Q; h.B = LO;
+  h.offer = (lane & 16u) ? h.B : h.A;
+  h.xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)h.offer);
+  return h;
+}
+__device__ __forceinline__ uint32_t half_step_part_a(const HalfChain& h, uint32_t acc) {
+  const uint32_t A = h.A, B = h.B, xa = h.xa, offer = h.offer;
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u;
+  uint32_t v1, t1, t2;
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PSHR2(3, 4) ICIKT_PSHR2(5, 6) ICIKT_PSHR2(7, 8) ICIKT_PSHR2(9, 10) ICIKT_PSHR2(11, 12)
+               ICIKT_PSHR2(13, 14)
+               "v_add_u32_dpp %1, %3, %4 row_shr:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_e32 %2, %7, %8\n\t" ICIKT_PACC
+               : "=&v"(v1), "=&v"(t1), "=&v"(t2)
+               : "v"(A), "v"(B), "s"(M8), "s"(SEL), "v"(xa), "v"(offer));
+  return bcnt_acc(v1, acc);
+}
+__device__ __forceinline__ uint32_t half_step_part_b(const HalfChain& h, uint32_t acc) {
+  const uint32_t xa = h.xa, offer = h.offer;
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
+  uint32_t v2, t1, t2;
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+               ICIKT_PROR2(3, 4) ICIKT_PROR2(5, 6)
+               "v_add_u32_dpp %1, %3, %4 row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+               "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %7, %0\n\t"
+               : "=&v"(v2), "=&v"(t1), "=&v"(t2)
+               : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
+  return bcnt_acc(v2, acc);
+}
 __device__ __forceinline__ uint32_t half_step_count(uint32_t sw0, uint32_t sw1, uint32_t lane, uint32_t partner_addr) {
   const uint32_t Q = __builtin_amdgcn_perm(sw1, sw0, 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16
   const uint32_t LO = __builtin_amdgcn_perm(sw1, sw0, 0x07060302u);   // lo likewise
@@ -1804,6 +1847,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           pos += 64;
           advance64();
           const auto sw = __builtin_amdgcn_permlane32_swap(rk[0], rk[NP - 1], false, false);
+          HalfChain hc;
+          {
+            uint32_t ka = sw[0], kb = sw[1];
+            if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
+              ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
+              kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
+            }
+            hc = half_step_prep(ka, kb, lane, partner_addr);   // (its ds_bpermute queues with the first query's reads)
+          }
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub) {
             const uint32_t r = sub ? sw[1] : sw[0];
@@ -1813,14 +1865,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             tl_update_rows(TH, r & 0xFFFFu);
             wave_lds_fence();
             const unsigned long long hh = atomicExch(hist2, 0ull);
-            if (sub == 0) {   // the chain of the whole step: registers only, between the issue of the atomics and the wait for them
-              uint32_t ka = sw[0], kb = sw[1];
-              if (halved) {   // q | lo << 16  ->  q >> 1 | (lo + 1) >> 1 << 16
-                ka = (((ka + 0x10000u) >> 1) & 0x7FFF0000u) | ((ka >> 1) & 0x7FFFu);
-                kb = (((kb + 0x10000u) >> 1) & 0x7FFF0000u) | ((kb >> 1) & 0x7FFFu);
-              }
-              dh += half_step_count(ka, kb, lane, partner_addr);
-            }
+            // the chain of the whole step, registers only, in two parts: each between the issue of a sub-step's atomics and
+            // the wait for its exchange
+            if (sub == 0) dh = half_step_part_a(hc, dh);
+            else dh = half_step_part_b(hc, dh);
             dh += cnt;
             const uint32_t h0 = (uint32_t)hh, h1 = (uint32_t)(hh >> 32), hs = h0 + h1;
             const uint32_t below0 = half_incl_scan(hs) - hs, below1 = below0 + h0;

@@ -19,7 +19,10 @@ for n in ns:
     out = torch.empty((P, 4), dtype=torch.float64, device="cuda")
     ctx.prepare_dev(dX.data_ptr(), n, S, n, _lib.FLAG_TIMING); ctx.sync()
     line = [f"n={n:6d} K0/col {ctx.kernel_ms(_lib.K_PREPARE)[0] / S * 1e3:6.1f} us"]
-    ctx.run_dev(1, 0, False, 0, out.data_ptr()); ctx.sync()  # warm-up (clocks, first-touch)
+    import time
+    t_w = time.time()
+    while time.time() - t_w < 1.0:  # warm-up (clocks, first-touch): the first variant used to read 5-15 % low
+        ctx.run_dev(1, 0, False, 0, out.data_ptr()); ctx.sync()
     ref = None
     for v in variants:
         ctx.debug_set_plan(v)

@@ -108,13 +108,14 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // CU's LDS (n <~ 60 000), else one.  The two share the streamed column and the rec block, so one 8-byte gather per row
   // serves both: the pair kernel of long columns was bound by the L2's request rate (64 requests per wave and gather; the
   // block never sits in an L1), not by instruction issue (round 3: a quarter fewer vector instructions changed nothing
-  // at n = 50 000).  Measured (tools/n_sweep.py, 512 columns, one pair -> two pairs per wave): n = 20 000 1.32e7 -> 1.68e7
-  // pairs/s, 30 000 8.2e6 -> 1.12e7, 36 000 6.7e6 -> 9.4e6, 50 000 4.9e6 -> 5.8e6, 60 000 4.1e6 -> 4.9e6; at 65 535 the two
-  // pairs' LDS state leaves 4-6 waves per CU and one pair per wave wins (3.7e6 vs 2.7e6).
+  // at n = 50 000).  Measured (tools/n_sweep.py, 512 columns, one pair -> two pairs per wave -> their singleton region in
+  // the half layout): n = 20 000 1.24e7 -> 1.69e7 -> 1.98e7 pairs/s, 30 000 8.0e6 -> 1.13e7 -> 1.33e7, 36 000 6.6e6 -> 9.4e6
+  // -> 1.11e7, 50 000 4.9e6 -> 5.8e6 -> 7.2e6, 60 000 4.1e6 -> 4.9e6 -> 6.0e6, 65 535 3.7e6 -> 3.9e6 -> 4.6e6.
   // No kernel keeps a second bitset for open tie groups any more (`pend`, in LDS or in per-wave global slots with a
   // persistent grid: rounds 1-2): the plan keys pend / gridmult / gridcap of icikt_debug_set_plan are accepted and ignored.
-  // 18 337 .. 30 656 rows: BOTH families fit.  Continuous columns run 11-14 % faster on the whole wave (n = 20 000:
-  // 1.74e7 vs 1.55e7 pairs/s; 30 000: 1.00e7 vs 0.88e7: the half-wave prefix rebuild costs 11 .. 15 words per lane there),
+  // 18 337 .. 30 656 rows: BOTH families fit.  Continuous columns run 25-50 % faster in the long-column kernel (n = 20 000:
+  // 1.98e7 vs 1.55e7 pairs/s; 30 000: 1.33e7 vs 0.88e7: the half-wave prefix rebuild costs 11 .. 15 words per lane there,
+  // the long-column kernel takes singleton rows in the half layout over the two-level counts: bit 2 of `opts` below),
   // tied columns 1.4-2.1x faster in the half-wave kernels (their MIXED steps use the packed chains and the pre-pass's
   // masks; n = 30 000, ~15 000 / 3 000 / 600 distinct values: 1.48 / 1.95 / 1.74 ms vs 2.46 / 4.12 / 2.83): `tied` (the
   // prepared columns average more than eight tie groups: matrix_tied below) chooses.

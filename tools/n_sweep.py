@@ -1,4 +1,6 @@
-"""K1 throughput against column length for the default plan and for forced plans (development aid)."""
+"""K1 throughput against column length for the default plan and for forced plans (development aid): one pair per wave;
+two pairs on the whole wave (half=0: also where the half-wave kernels are the default) with the singleton region in the
+half layout (the default) and with the previous whole-wave loop (hyb=0); workgroups of 1 / 3 waves instead of 4."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -6,7 +8,7 @@ from icikendalltau_amd import _lib
 from bench import make_matrix
 
 ns = [int(a) for a in sys.argv[1:]] or [2000, 5000, 10000, 16000, 17000, 25000, 26000, 40000, 65535]
-variants = [dict(), dict(np="1"), dict(np="2"), dict(np="2", wpb="1"), dict(np="2", wpb="3"), dict(np="2", hyb="1"), dict(np="2", hyb="1", wpb="3"), dict(np="2", hyb="1", wpb="1")]
+variants = [dict(), dict(np="1"), dict(half="0", np="2"), dict(half="0", np="2", hyb="0"), dict(half="0", np="2", wpb="1"), dict(half="0", np="2", wpb="3")]
 if os.environ.get("VARIANTS"):
     variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in os.environ["VARIANTS"].split(";")]
 ctx = _lib.Context(0)

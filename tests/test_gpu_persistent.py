@@ -92,6 +92,33 @@ def test_two_pairs_per_wave_long_columns(plan_ctx, n):
     assert np.array_equal(two[0], one[0], equal_nan=True) and np.array_equal(two[1], one[1])
 
 
+@pytest.mark.parametrize("n", [20000, 32767, 32768, 32769, 41000, 65535])
+def test_long_column_half_layout_loop(plan_ctx, n):
+    """The singleton region of k1_pairs<2, 0> in the half layout (one pair per 32-lane half, 32-row sub-steps over the
+    two-level counts, a lane exchanging two histogram bins; positions above 2^15 compared halved) against the previous
+    whole-wave loop (plan key hyb=0) and against the oracle: mostly continuous columns -- long singleton regions, with
+    odd and even step counts in front of the fill group -- plus a tied and a half-missing column whose tie steps carry on
+    from the state the loop leaves; a capped grid makes every wave run several tasks."""
+    rng = np.random.default_rng(n)
+    S = 11
+    X = np.asfortranarray(rng.standard_normal((n, S)))
+    for c in range(S):
+        k = int(rng.integers(1, 400)) + 64 * (c & 1)
+        X[np.argsort(X[:, c], kind="stable")[:k], c] = np.nan          # left-censored: the fill group closes the walk
+    X[:, 3] = np.round(X[:, 3] * 40)
+    X[rng.random(n) < 0.5, 6] = np.nan
+    # (half=0: up to 30 656 rows the tied column would otherwise send the matrix to the half-wave kernels)
+    plan_ctx.debug_set_plan({"np": 2, "half": 0, "gridcap": 4})
+    _all_pairs_vs_oracle(plan_ctx, X)
+    plan_ctx.debug_set_plan({"np": 2, "half": 0})
+    new = plan_ctx.pairs(X, perspective="local")
+    plan_ctx.debug_set_plan({"np": 2, "half": 0, "hyb": 0})
+    old = plan_ctx.pairs(X, perspective="local")
+    assert np.array_equal(new[0], old[0], equal_nan=True) and np.array_equal(new[1], old[1])
+    plan_ctx.debug_set_plan({"np": 2, "half": 0, "hyb": 0, "gridcap": 4})
+    _all_pairs_vs_oracle(plan_ctx, X)                                  # the previous loop stays covered
+
+
 @pytest.mark.parametrize("n", [18337, 22529, 26624, 30656])
 def test_half_wave_kernels_11_to_15_words(plan_ctx, n):
     """18 337 .. 30 656 rows: both kernel families fit -- the half-wave kernels with 11, 13 and 15 words per lane (the

@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- all-pairs ICI-Kendall-tau throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config c3|c4|c5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
     python bench.py --gpus N --launcher inlib     one process, N GPUs behind ONE C call (icikt_pairs_multi_f64)
+
+`python bench.py --gpus N` runs AS TYPED for N = 1, 2, 4, 8: with N > 1 and no WORLD_SIZE in the environment this
+process -- before it imports torch or touches a GPU -- starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never an
+exec), relays its one JSON line and exits with its status.  Started under torch.distributed.run directly (WORLD_SIZE set,
+as the driver does for N > 1) it is a rank.  The timed region is the same at every N, so the N = 1 line equals BENCH.
 
 Default workload = BASELINE.md c4, the configuration the metric is quoted on: synthetic 10 000 features x
 1 024 samples, numpy default_rng(4).standard_normal, per column the 1 000 smallest values missing
@@ -12,6 +17,8 @@ perspective = "global": 523 776 column pairs, each a pair of length-10 000 vecto
 --config c3: 10 000 x 256, 500 smallest missing (32 640 pairs).  --config c5: 50 000 x 2 048, 1 000 smallest
 missing, 2 096 128 pairs in BOTH perspectives ("local" is the epilogue over the same pair counts), plus the
 include_only subset (first 64 names: 128 992 pairs) and pairwise_completeness on that subset, timed beside it.
+--config c2: the yeast matrix of the reference (data/yeast_missing.rda as the fixture tests/golden/yeast_missing.npz:
+6 887 x 96, zeros -> missing), perspective = "global", all 4 560 pairs; the CPU leg runs ALL of them (no sampling).
 
 One "step" = one full pass of the hot path over the matrix, input already resident in HBM:
   K0 per-column pre-pass (N > 1: each rank sorts S/N columns, then one RCCL all-gather of the prepared state;
@@ -19,6 +26,9 @@ One "step" = one full pass of the hot path over the matrix, input already reside
   contiguous block of the combn-ordered pair list (the reference's `core` chunks, R/kendalltau.R:250-255) -> K2
   epilogue -> (N > 1) RCCL gather of the P/N x 4 results to rank 0.
 value = pairs of the whole job / wall time (max over ranks); total work is fixed, so scaling = strong.
+Beside it, timed the same way (K steps, mean): `pcie_inclusive` -- the host-buffer entry icikt_pairs_f64, i.e. the metric
+as SURVEY.md section 8(d) words it (H2D of the matrix, kernels, D2H of the results) -- and `full_matrix_wall_ms` -- the
+icikt_matrix_f64 call that returns the five S x S matrices of ici_kendalltau().
 Exit status is non-zero when the results disagree with the oracle sample (a wrong line is not a bench line).
 """
 from __future__ import annotations
@@ -26,6 +36,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,12 +45,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+# (torch is imported inside main(): the self-launching parent must not load it)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ATOL = 1e-10
 
 CONFIGS = {
+    "c2": dict(fixture="yeast_missing.npz", n_feat=6887, n_samp=96, n_na=0, seed=0, steps=50, warmup=10, cpu_sample=4560, pre_warm=30),
     "c3": dict(n_feat=10000, n_samp=256, n_na=500, seed=3, steps=20, warmup=5, cpu_sample=6000, pre_warm=8),
     "c4": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, steps=20, warmup=5, cpu_sample=12000, pre_warm=5),
     "c5": dict(n_feat=50000, n_samp=2048, n_na=1000, seed=5, steps=3, warmup=1, cpu_sample=1200),
@@ -54,6 +66,73 @@ def make_matrix(n_feat: int, n_samp: int, n_na: int, seed: int) -> np.ndarray:
         idx = np.argpartition(X, n_na, axis=0)[:n_na]
         np.put_along_axis(X, idx, np.nan, axis=0)
     return X
+
+
+def workload_matrix(config: str, cfg: dict) -> np.ndarray:
+    """The matrix of a configuration as the pair entries take it (column-major float64, NaN = missing).  c2 is the
+    reference's own yeast data (a committed fixture decoded from data/yeast_missing.rda by tests/golden/make_golden.py),
+    zeros -> missing as global_na = c(NA, Inf, 0) makes them (R/utils.R:1-23)."""
+    if CONFIGS[config].get("fixture"):
+        if any(cfg[k] != CONFIGS[config][k] for k in ("n_feat", "n_samp", "n_na", "seed")):
+            raise SystemExit(f"--config {config} is a fixed data set: --n-feat / --n-samp / --n-na / --seed do not apply")
+        z = np.load(os.path.join(ROOT, "tests", "golden", CONFIGS[config]["fixture"]))
+        X = np.asfortranarray(z["X"].astype(np.float64))
+        X[(X == 0) | ~np.isfinite(X)] = np.nan
+        return X
+    return make_matrix(cfg["n_feat"], cfg["n_samp"], cfg["n_na"], cfg["seed"])
+
+
+# ---- self-launch: `python bench.py --gpus N` as typed ----------------------------------------------------------------
+def should_spawn(gpus: int, launcher: str, env) -> bool:
+    """True when this process is the PARENT of a torch.distributed run: no WORLD_SIZE yet, and either several GPUs are
+    asked for or the one-rank rehearsal of the distributed sequence (ICIKT_BENCH_FORCE_DIST=1)."""
+    if launcher != "torchrun" or env.get("WORLD_SIZE"):
+        return False
+    return gpus > 1 or env.get("ICIKT_BENCH_FORCE_DIST") == "1"
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def child_command(argv, gpus: int, port: int):
+    """The command line of the child: one rank per GPU of ONE node over torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def spawn_ranks(argv, gpus: int) -> int:
+    """Parent: start the ranks as a child process, relay the JSON line (everything else the ranks print goes to stderr)
+    and return the child's exit status.  Nothing here imports torch or touches a GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = child_command(argv, gpus, free_port())
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        try:
+            d = json.loads(line)
+            d["launched_by"] = {"parent": "bench.py (self-launch)", "cmd": " ".join(cmd[1:9]) + " bench.py ...",
+                                "child_wall_s": time.perf_counter() - t0, "child_rc": rc}
+            line = json.dumps(d)
+        except Exception:
+            pass
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 3   # no line is not a result
+    return rc
 
 
 def host_cores() -> int:
@@ -80,7 +159,8 @@ def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, perspective="gl
     n, S = X.shape
     rng = np.random.default_rng(seed)
     iu, ju = np.triu_indices(S, k=1)
-    sel = rng.choice(P_total, size=min(sample_pairs, P_total), replace=False)
+    # (every pair, in order, when the sample covers the list: c2 runs all 4 560 pairs of the yeast matrix)
+    sel = np.arange(P_total) if sample_pairs >= P_total else rng.choice(P_total, size=sample_pairs, replace=False)
     pi, pj = iu[sel].astype(np.int32), ju[sel].astype(np.int32)
     cores = host_cores()
     chunks = np.array_split(np.arange(len(sel)), cores * 4)
@@ -95,7 +175,7 @@ def cpu_baseline(X: np.ndarray, P_total: int, sample_pairs: int, perspective="gl
     out = np.concatenate([r[0] for r in res])
     cnt = np.concatenate([r[1] for r in res])
     return {"value": len(sel) / dt, "unit": "column-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{len(sel)} random pairs of the same {n}x{S} matrix, {dt:.2f} s wall on {cores} threads "
+            "sample": f"{'ALL ' if len(sel) == P_total else ''}{len(sel)} {'' if len(sel) == P_total else 'random '}pairs of the same {n}x{S} matrix, {dt:.2f} s wall on {cores} threads "
                       f"({dt * cores / len(sel) * 1e3:.2f} core-ms per pair)",
             "note": "CPU restatement in C (oracle/), NOT the reference's Rcpp path (R is absent from the image); it "
                     "copies less than Rcpp sugar does, so per pair it is about 3x faster than the reference's own "
@@ -175,25 +255,34 @@ def _pmc_pass(config: str, counters, outdir: str, timeout_s: int):
         if ln.startswith("{") and "k1_ms_per_launch" in ln:
             info = json.loads(ln)
     agg = collections.defaultdict(list)
+    names = collections.Counter()
     for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if "k1_pairs" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    names[r["Kernel_Name"]] += 1
     if not agg:
         raise RuntimeError("no k1_pairs dispatch in the counter output")
+    info["kernel_names"] = dict(names)
     return {c: sum(v) / len(v) for c, v in agg.items()}, info   # one row per dispatch and counter: the mean per dispatch
 
 
-K1_KERNEL_OF = {"c3": "k1_pairsILi2ELi5E", "c4": "k1_pairsILi2ELi5E", "c5": "k1_pairsILi2ELi0E"}   # plan_k1's choice
+def k1_instance_of(kernel_name: str):
+    """'k1_pairsILi<NP>ELi<HI>E' (the mangled substring tools/valu_mix.py looks for) of a dispatch row's kernel name,
+    demangled ('k1_pairs<2, 5>') or not; None if it is not one."""
+    import re
+    m = re.search(r"k1_pairs<\s*(\d+)\s*,\s*(\d+)\s*>", kernel_name) or re.search(r"k1_pairsILi(\d+)ELi(\d+)E", kernel_name)
+    return f"k1_pairsILi{m.group(1)}ELi{m.group(2)}E" if m else None
 
 
-def static_valu_mix(config: str):
-    """Full-rate / half-rate vector instructions in the hot loop of the workload's pair kernel, from the compiler's
-    assembly of THIS source (tools/valu_mix.py; ~7 s of hipcc)."""
+def static_valu_mix(kernel: str):
+    """Full-rate / half-rate vector instructions in the hot loop of pair kernel instance `kernel` (as the DISPATCH ROWS
+    of the counter pass name it: no table of "the plan's choice" to go stale), from the compiler's assembly of THIS
+    source (tools/valu_mix.py; ~7 s of hipcc)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import valu_mix
-    return valu_mix.hot_loop_mix(K1_KERNEL_OF[config])
+    return valu_mix.hot_loop_mix(kernel)
 
 
 def collect_pmc(config: str, timeout_s: int = 240):
@@ -208,8 +297,18 @@ def collect_pmc(config: str, timeout_s: int = 240):
         if name == "sq":
             rec["k1_ms_in_pmc_pass"] = info.get("k1_ms_per_launch")
             rec["pairs_per_launch"] = info.get("pairs_per_launch")
+            # the pair-kernel instance that RAN, from the dispatch rows of the counter output
+            inst = {k1_instance_of(k): v for k, v in (info.get("kernel_names") or {}).items()}
+            inst.pop(None, None)
+            if inst:
+                rec["k1_kernel"] = max(inst, key=inst.get)
+                if len(inst) > 1:
+                    rec["k1_kernel_note"] = f"several instances were dispatched: {inst}"
     try:
-        rec["valu_mix_hot_loop"] = static_valu_mix(config)
+        if not rec.get("k1_kernel"):
+            raise RuntimeError("the counter rows name no k1_pairs instance")
+        rec["valu_mix_hot_loop"] = static_valu_mix(rec["k1_kernel"])
+        assert rec["valu_mix_hot_loop"]["kernel"] == rec["k1_kernel"]
     except Exception as e:  # noqa: BLE001
         rec["valu_mix_note"] = f"static mix unavailable ({e!r})"[:200]
     return rec
@@ -293,6 +392,11 @@ def build_roofline(pmc, pmc_source, pmc_note, k1_avg_s, P_local, n):
         roof["issue_cycles_per_instruction_floor"] = cyc
         roof["peak"] = N_SIMD * clock / cyc / 1e9
         roof["frac"] = roof["achieved"] / roof["peak"]                      # == insts x floor cycles / (SIMDs x launch cycles)
+        roof["frac_kind"] = ("MIX-RELATIVE: against the issue floor of THIS kernel's hot-loop instruction mix (h from the "
+                             "compiler's assembly of the instance the dispatch rows name, %s); the two fixed-denominator "
+                             "fractions beside it need no model: frac_of_2_cycle_slots (the guide's full-rate issue, a true "
+                             "upper bound) and frac_of_4_cycle_slots (every instruction in a DPP-stream slot; can exceed 1)"
+                             % (pmc.get("k1_kernel") or "?"))
         roof["frac_of_4_cycle_slots"] = insts * 4.0 / (N_SIMD * cycles)     # every instruction in a 4-cycle slot: > 1 = some full-rate forms did overlap
         roof["frac_of_2_cycle_slots"] = insts * 2.0 / (N_SIMD * cycles)     # against the SIMD's best case (full-rate forms only)
         roof["issue_note"] = ("peak = SIMDs x clock / (4 h + 2 (1 - h)) with h the share of half-rate forms in the hot loop "
@@ -324,8 +428,24 @@ def build_roofline(pmc, pmc_source, pmc_note, k1_avg_s, P_local, n):
         if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
             roof["l1_hit_rate"] = 1.0 - req / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] if pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] > req else 0.0
     roof["pmc"] = {k: pmc[k] for k in sorted(pmc) if k[:3] in ("SQ_", "GRB", "FET", "WRI", "TCC", "TCP") or
-                   k in ("src_hash", "taken", "k1_ms_in_pmc_pass", "valu_mix_hot_loop", "valu_mix_note")}
+                   k in ("src_hash", "taken", "k1_ms_in_pmc_pass", "valu_mix_hot_loop", "valu_mix_note", "k1_kernel", "k1_kernel_note")}
+    if pmc.get("k1_kernel"):
+        roof["kernel"] = pmc["k1_kernel"]
     return roof
+
+
+def workload_text(config, cfg, P_total, both):
+    n, S = cfg["n_feat"], cfg["n_samp"]
+    if CONFIGS[config].get("fixture"):
+        return (f"{config}: yeast_missing (the reference's data/yeast_missing.rda), {n} features x {S} samples, zeros -> missing, "
+                f"perspective=global, {P_total} column pairs")
+    return (f"{config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
+            f"perspective={'global + local' if both else 'global'}, {P_total} column pairs")
+
+
+def spread(rows, keys):
+    """{key: {"max": .., "min": ..}} over the ranks' rows (a list of dicts)."""
+    return {k: {"max": max(r[k] for r in rows), "min": min(r[k] for r in rows)} for k in keys}
 
 
 def run_inlib(args, cfg):
@@ -333,7 +453,7 @@ def run_inlib(args, cfg):
     boundary hands over HOST buffers, so this rate is PCIe-inclusive by construction."""
     from icikendalltau_amd import _lib
     n, S = cfg["n_feat"], cfg["n_samp"]
-    X = make_matrix(n, S, cfg["n_na"], cfg["seed"])
+    X = workload_matrix(args.config, cfg)
     P_total = S * (S - 1) // 2
     # (RCCL prints a version banner on stdout when its first communicator is made: keep stdout to the one JSON line)
     sys.stdout.flush()
@@ -355,17 +475,20 @@ def run_inlib(args, cfg):
     elapsed = time.perf_counter() - t0
     m.pairs(X, perspective="global", want_counts=False, flags=_lib.FLAG_TIMING)
     phases = m.phase_ms()
+    ranks = m.rank_phase_ms()[:max(1, m.ranks_used)]
     line = {
         "metric": "column-pairs/s (+ full-matrix wall time) at 10k feat x 1k samp",
         "value": P_total * args.steps / elapsed, "unit": "column-pairs/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32 rank/popcount counting + f64 epilogue",
-        "data": "synthetic", "launcher": "inlib",
-        "config": {"workload": f"{args.config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
-                               f"perspective=global, {P_total} column pairs, HOST buffers in and out "
+        "data": "synthetic" if not CONFIGS[args.config].get("fixture") else "reference fixture (yeast_missing)", "launcher": "inlib",
+        "config": {"workload": workload_text(args.config, cfg, P_total, False) + ", HOST buffers in and out "
                                "(icikt_pairs_multi_f64: PCIe-inclusive)",
                    "pairs": P_total, "n_feat": n, "n_samp": S, "exchange": "rccl" if m.uses_rccl else "copy"},
+        "rccl_ranks": m.comm_ranks,          # ncclCommCount of the handle's communicator (0: device copies, no communicator)
+        "ranks_used": m.ranks_used,
         "phase_ms_synced": phases,
+        "rank_phase_ms": spread(ranks, _lib.MULTI_PHASES + ("wait",)),
     }
     if args.cpu_sample > 0:
         _b, sel, ref_out, ref_cnt = cpu_baseline(X, P_total, min(args.cpu_sample, 2000))
@@ -375,13 +498,19 @@ def run_inlib(args, cfg):
     return 0 if line.get("check", {}).get("ok", True) else 1
 
 
-def main():
+PHASES = ("k0", "exchange", "k1", "gather")   # per step and rank: pre-pass of the rank's columns | all-gather + rebuild | pair kernel + epilogue | result gather
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
-    ap.add_argument("--launcher", choices=("torchrun", "inlib"), default="torchrun")
+    ap.add_argument("--launcher", choices=("torchrun", "inlib"), default="torchrun",
+                    help="torchrun: one process per GPU over torch.distributed (self-launched when WORLD_SIZE is unset); "
+                         "inlib: one process, N GPUs behind one C call")
     ap.add_argument("--n-feat", type=int, default=None)
     ap.add_argument("--n-samp", type=int, default=None)
     ap.add_argument("--n-na", type=int, default=None)
@@ -392,7 +521,14 @@ def main():
                     help="roofline counters of the pair kernel: taken now by child rocprofv3 --pmc runs (N = 1; falls back "
                          "to the committed record of the same source), from the committed record only, or not at all")
     ap.add_argument("--save-pmc", action="store_true", help="write the live counters to profiles/k1_pmc_records.json")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    # `python bench.py --gpus N` as typed: this process is the parent of the ranks (no torch, no GPU in it)
+    if should_spawn(args.gpus, args.launcher, os.environ):
+        return spawn_ranks(argv, args.gpus)
+
+    import torch
     cfg = dict(CONFIGS[args.config])
     for k in ("n_feat", "n_samp", "n_na", "seed", "steps", "warmup", "cpu_sample"):
         v = getattr(args, k)
@@ -401,17 +537,13 @@ def main():
     args.steps, args.warmup, args.cpu_sample = cfg["steps"], cfg["warmup"], cfg["cpu_sample"]
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     if args.launcher == "inlib":
-        raise SystemExit(run_inlib(args, cfg))
+        return run_inlib(args, cfg)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node "
-                             f"{args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ... "
-                             "(or --launcher inlib for one process driving all GPUs)")
-        args.gpus = world
+        args.gpus = world   # started under torch.distributed.run with another rank count: the launcher's count holds
     # ICIKT_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: every rank uses the visible device
     # and the collectives go through host memory.  The driver's N > 1 runs use nccl (= RCCL over xGMI).
     backend = os.environ.get("ICIKT_BENCH_BACKEND", "nccl")
@@ -436,7 +568,7 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n, S = cfg["n_feat"], cfg["n_samp"]
-    X = make_matrix(n, S, cfg["n_na"], cfg["seed"])
+    X = workload_matrix(args.config, cfg)
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, n) row-major == n x S column-major
     P_total = S * (S - 1) // 2
     begin, end, n_each = sharding.pair_block(P_total, rank, world)  # ceiling(n_todo / ncore), R/kendalltau.R:250
@@ -463,22 +595,39 @@ def main():
                 prep_mode = sp.mode
     ctx.set_pairs_combn(S, begin, end)
 
-    def step():
+    # per-rank phase times: events on the stream everything of a step is launched on (torch's current stream: the
+    # library runs on it -- set_stream above -- and the collectives synchronise with it), five per step
+    ev_pool = []
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def step(timed=False):
         nonlocal gathered
+        evs = [mark()] if timed else None
         if sp is None:
             ctx.prepare_dev(dX.data_ptr(), n, S, n, flags)
+            if timed:
+                evs += [mark(), mark()]          # k0 | (no exchange)
         else:
-            sp.run(flags)
+            sp.run(flags, on_phase=(lambda _name: evs.append(mark())) if timed else None)   # "k0", "exchange"
         if P_local > 0:
             ctx.run_dev(_lib.PERSPECTIVE["global"], _lib.ALTERNATIVE["two.sided"], False, flags, out_local.data_ptr())
             if both:  # the second perspective is the epilogue over the same pair counts
                 ctx.run_dev(_lib.PERSPECTIVE["local"], _lib.ALTERNATIVE["two.sided"], False,
                             flags | _lib.FLAG_REUSE_COUNTS, out_second.data_ptr())
+        if timed:
+            evs.append(mark())                   # k1 (+ epilogue)
         if distributed:
             # every rank's P/N x 4 results to rank 0 (RCCL over xGMI)
             gathered = sharding.gather_blocks(dist, out_local, n_each, dev, via_host, to_all=False)
             if both:
                 sharding.gather_blocks(dist, out_second, n_each, dev, via_host, to_all=False)
+        if timed:
+            evs.append(mark())                   # gather
+            ev_pool.append(evs)
 
     def fence():
         if distributed:
@@ -495,13 +644,21 @@ def main():
     ctx.reset_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # this rank's phases, ms per step (the events are complete: fence() synchronised)
+    my_phase = [sum(evs[i].elapsed_time(evs[i + 1]) for evs in ev_pool) / max(1, len(ev_pool)) for i in range(4)]
+    rank_rows = [dict(zip(PHASES, my_phase))]
+    if distributed:
+        pt = torch.tensor(my_phase, dtype=torch.float64, device="cpu" if via_host else dev)
+        parts = [torch.empty_like(pt) for _ in range(world)]
+        dist.all_gather(parts, pt)
+        rank_rows = [dict(zip(PHASES, [float(v) for v in q.cpu()])) for q in parts]
 
     k_ms = {name: ctx.kernel_ms(k) for name, k in (("prepare", _lib.K_PREPARE), ("pairs", _lib.K_PAIRS),
                                                     ("epilogue", _lib.K_EPILOGUE))}
@@ -538,16 +695,21 @@ def main():
             pmc_note = "counters are kept for the standard single-GPU workloads only"
         roof = build_roofline(pmc, pmc_source, pmc_note, k1_avg_s, P_local, n)
         roof["kernel_launches_per_step"] = k1_n / args.steps
-        wl = (f"{args.config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
-              f"perspective={'global + local' if both else 'global'}, {P_total} column pairs")
         line = {
             "metric": "column-pairs/s (+ full-matrix wall time) at 10k feat x 1k samp",
             "value": value, "unit": "column-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int32 rank/popcount counting + f64 epilogue", "data": "synthetic",
-            "config": {"workload": wl, "pairs": P_total, "n_feat": n, "n_samp": S,
+            "dtype": "int32 rank/popcount counting + f64 epilogue",
+            "data": "synthetic" if not CONFIGS[args.config].get("fixture") else "reference fixture (yeast_missing)",
+            "config": {"workload": workload_text(args.config, cfg, P_total, both), "pairs": P_total, "n_feat": n, "n_samp": S,
                        "sharding": f"combn-order blocks over {world} rank(s)", "pre_pass": prep_mode},
-            "full_matrix_wall_ms": ms_per_step,
+            "value_definition": "matrix resident in HBM when the timed region starts; K0 + (N > 1: all-gather + rebuild) + K1 + K2 "
+                                "+ (N > 1: gather to rank 0); barrier + synchronize on both sides, max over ranks",
+            # the communicator as the backend reports it (nccl = RCCL); null when the run had no process group
+            "rccl_ranks": (dist.get_world_size() if (distributed and backend == "nccl") else None),
+            "backend": (backend if distributed else None),
+            # per rank and step, from events on the launch stream: max and min over the ranks
+            "rank_phase_ms": spread(rank_rows, PHASES),
             "roofline": roof,
             # accumulated event time of each kernel id / steps (the pre-pass id covers K0 and, at N > 1, the two
             # rebuild launches of a step, not the all-gather between them)
@@ -578,17 +740,21 @@ def main():
         if distributed:
             # the assembled result: rank blocks concatenated in combn order (no NaN may be left in real pairs)
             full = sharding.assemble(gathered, P_total, n_each).cpu().numpy()
-            line["check"] = {"assembled_pairs": int(full.shape[0]), "nan_rows": int(np.isnan(full[:, 0]).sum())}
-            line["check"]["ok"] = full.shape[0] == P_total and line["check"]["nan_rows"] == 0
+            chk = {"assembled_pairs": int(full.shape[0]), "nan_rows": int(np.isnan(full[:, 0]).sum())}
+            chk["ok"] = full.shape[0] == P_total and chk["nan_rows"] == 0
             if args.cpu_sample > 0:
                 from oracle import oracle as O
                 rng = np.random.default_rng(1)
                 sel = rng.choice(P_total, size=min(2000, P_total), replace=False)
                 iu, ju = np.triu_indices(S, k=1)
                 ref, _c, _r = O.ici_pairs(X, iu[sel], ju[sel], "global", want_counts=False)
-                line["check"].update(pairs_checked_against_oracle=int(len(sel)),
-                                     max_abs_diff=float(np.nanmax(np.abs(full[sel] - ref))))
-                line["check"]["ok"] = line["check"]["ok"] and line["check"]["max_abs_diff"] <= ATOL
+                chk.update(pairs_checked_against_oracle=int(len(sel)), max_abs_diff=float(np.nanmax(np.abs(full[sel] - ref))))
+                chk["ok"] = chk["ok"] and chk["max_abs_diff"] <= ATOL
+            if "check" in line:   # (one rank over a process group: both checks hold)
+                chk["ok"] = chk["ok"] and line["check"]["ok"]
+                line["check"].update(chk)
+            else:
+                line["check"] = chk
         if not distributed and not args.no_extras:
             extras(line, args, cfg, X, ctx, dev)
         status = 0 if line.get("check", {}).get("ok", True) else 1
@@ -603,43 +769,61 @@ def main():
 
 
 def extras(line, args, cfg, X, ctx, dev):
-    """N = 1 only, outside the timed region: the figures SURVEY.md section 8(d) asks for beside the metric."""
+    """N = 1 only, after the resident timed region: the figures SURVEY.md section 8(d) asks for beside the metric, each
+    over K steps (mean, not a best-of)."""
+    import torch
     from icikendalltau_amd import _lib, api
     n, S = X.shape
     P_total = S * (S - 1) // 2
     ctx.use_own_stream()
-    # (1) PCIe-inclusive: the host-buffer entry the R glue binds (H2D of the matrix in column chunks overlapped with
-    #     K0, kernels, D2H of the results), best of 5
+    L = _lib.lib()
+    # (1) PCIe-inclusive -- the metric as section 8(d) words it: the host-buffer entry the R glue binds (pageable host
+    #     matrix in: H2D in column chunks overlapped with K0 and the pair kernel; D2H of the results into pageable host
+    #     arrays), `steps` calls after `warmup`, wall clock around the loop, mean
     out4 = np.empty((P_total, 4))
     rsn = np.zeros(P_total, np.int32)
-    ts = []
-    L = _lib.lib()
-    for _ in range(1 if args.config == "c5" else 5):
-        t0 = time.perf_counter()
+
+    def host_call():
         rc = L.icikt_pairs_f64(ctx._h, X.ctypes.data, n, S, n, None, None, 0, 1, 0, 0, 0, out4.ctypes.data, None, rsn.ctypes.data)
-        ts.append(time.perf_counter() - t0)
         assert rc == 0, L.icikt_last_error(ctx._h)
-    line["pcie_inclusive"] = {"value": P_total / min(ts), "unit": "column-pairs/s", "ms": min(ts) * 1e3,
-                              "entry": "icikt_pairs_f64 (pageable host matrix in, host results out)",
+
+    for _ in range(max(1, args.warmup)):
+        host_call()
+    ts = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        host_call()          # (synchronous: the results are in the caller's arrays when it returns)
+        ts.append(time.perf_counter() - t0)
+    mean = sum(ts) / len(ts)
+    line["pcie_inclusive"] = {"value": P_total / mean, "unit": "column-pairs/s", "ms_per_step": mean * 1e3, "steps": len(ts),
+                              "warmup": max(1, args.warmup), "ms_min": min(ts) * 1e3, "ms_max": max(ts) * 1e3,
+                              "entry": "icikt_pairs_f64 (pageable host matrix in, host results out; one perspective)",
                               "h2d_bytes": int(X.nbytes), "d2h_bytes": int(out4.nbytes + rsn.nbytes)}
-    # (2) the whole ici_kendalltau() equivalent: masking, pair list, the call above, scaling, five S x S matrices
+    # (2) the five S x S matrices of ici_kendalltau() behind ONE library call (icikt_matrix_f64: exclusion rule in the
+    #     pre-pass, pair kernels, scale_and_reshape on the device, one D2H of 5 S^2 doubles + keep): mean over the steps
+    reps = min(args.steps, 5)
+    ctx.matrix(X, (float("nan"),))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.matrix(X, (float("nan"),))
+    line["full_matrix_wall_ms"] = (time.perf_counter() - t0) / reps * 1e3
+    line["full_matrix_note"] = f"icikt_matrix_f64, host buffers in and out, mean of {reps} calls; d2h {5 * S * S * 8 + n * S} bytes"
+    # (3) the whole ici_kendalltau() equivalent of the Python front-end: argument checks, the call above, data frames
     if args.config != "c5":
         names = [f"s{i}" for i in range(S)]
         eng = api.HipEngine(device=dev.index)
         ts, rt = [], []
         for _ in range(3):   # the first call also creates the engine's context and workspaces
             t0 = time.perf_counter()
-            res = api.ici_kendalltau(X, perspective="global", colnames=names, engine=eng)
+            res = api.ici_kendalltau(X, global_na=(float("nan"),), perspective="global", colnames=names, engine=eng)
             ts.append(time.perf_counter() - t0)
             rt.append(res["run_time"])
-        # ici_kendalltau(): argument checks, then ONE library call (icikt_matrix_f64: exclusion rule in the pre-pass, pair
-        # kernels, scale_and_reshape on the device, one D2H of the five S x S matrices + keep), data frames around them
         line["e2e_ici_kendalltau_ms"] = min(ts) * 1e3
         line["e2e_first_call_ms"] = ts[0] * 1e3
         line["e2e_run_time_field_ms"] = min(rt) * 1e3          # the run_time field: the library call alone
-        line["e2e_vs_pcie_inclusive"] = line["e2e_ici_kendalltau_ms"] / line["pcie_inclusive"]["ms"]
+        line["e2e_vs_pcie_inclusive"] = line["e2e_ici_kendalltau_ms"] / line["pcie_inclusive"]["ms_per_step"]
     else:
-        # (3) BASELINE config 5's subset legs: include_only = the first 64 names (pairs with s1 OR s2 among them) in
+        # (4) BASELINE config 5's subset legs: include_only = the first 64 names (pairs with s1 OR s2 among them) in
         #     both perspectives, and pairwise_completeness (self pairs included) on the same subset
         names = [f"s{i}" for i in range(S)]
         pi, pj, _core = api.setup_comparisons(names, include_only=names[:64], diag_good=True, ncore=1)
@@ -653,17 +837,19 @@ def extras(line, args, cfg, X, ctx, dev):
         ctx.run_dev(_lib.PERSPECTIVE["local"], 0, False, _lib.FLAG_REUSE_COUNTS, sub.data_ptr())
         ctx.sync()
         t_sub = time.perf_counter() - t0
+        del dX
         pc_i, pc_j, _c = api.setup_comparisons(names, include_only=names[:64], diag_good=False, ncore=1)
+        ctx.missingness(X, pc_i, pc_j)
         t0 = time.perf_counter()
         miss = ctx.missingness(X, pc_i, pc_j)
         t_pc = time.perf_counter() - t0
         line["include_only_subset"] = {"pairs": int(len(pi)), "both_perspectives_ms": t_sub * 1e3,
                                        "pairs_per_s": len(pi) / t_sub,
                                        "pairwise_completeness_pairs": int(len(pc_i)), "pairwise_completeness_ms": t_pc * 1e3,
-                                       "pairwise_completeness_note": "host-buffer entry: includes H2D of the matrix",
+                                       "pairwise_completeness_note": "host-buffer entry icikt_missingness_f64: H2D of the matrix "
+                                                                     "in chunks, a mask-only pre-pass per chunk (no sort), popcounts",
                                        "missingness_checksum": int(miss.sum())}
-        del dX
-    # (4) single-core latency of the CPU restatement beside the reference's README table
+    # (5) single-core latency of the CPU restatement beside the reference's README table
     line["cpu_single_core_us"] = cpu_single_core_us()
 
 

@@ -27,8 +27,10 @@ ALT_OTHER = 3
 FLAG_EXACT_INT64 = 1
 FLAG_TIMING = 2
 FLAG_REUSE_COUNTS = 4
+FLAG_HOST_PINNED = 8     # the caller has page-locked the matrix and the result arrays of the call (pinned_empty)
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
+MASK_VALS = 32                # distinct finite global_na values of the device-side exclusion rule (icikt_device.h)
 MAX_FEATURES = 65535          # the tuned kernels
 MAX_FEATURES_WIDE = 262144    # the plain 32-bit path (exact integer arithmetic)
 PREP_ARRAYS = 5  # order, rec, hirow, meta (bitsets + stats per column), tgroups
@@ -49,7 +51,7 @@ EXPORTS = (
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
     "icikt_matrix_f64", "icikt_matrix_multi_f64", "icikt_multi_rank_phase_ms", "icikt_multi_ranks_used",
-    "icikt_debug_step_stats",
+    "icikt_debug_step_stats", "icikt_multi_comm_ranks",
 )
 
 
@@ -142,6 +144,7 @@ def lib():
     L.icikt_multi_last_error.restype = ctypes.c_char_p
     L.icikt_multi_n_gpu.argtypes = [c_vp]
     L.icikt_multi_uses_rccl.argtypes = [c_vp]
+    L.icikt_multi_comm_ranks.argtypes = [c_vp]
     L.icikt_pairs_multi_f64.argtypes = L.icikt_pairs_f64.argtypes
     L.icikt_multi_phase_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double)]
     L.icikt_multi_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
@@ -167,6 +170,17 @@ def device_count() -> int:
 
 def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def pinned_empty(shape, dtype=np.float64, order="C"):
+    """A numpy array in PAGE-LOCKED host memory (hipHostMalloc through torch's pinned allocator; the array keeps the
+    tensor alive).  Host entries called with FLAG_HOST_PINNED copy from / into such arrays directly."""
+    import torch
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape)) if shape else 1
+    t = torch.empty(max(n, 1) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
+    a = t.numpy()[:n * np.dtype(dtype).itemsize].view(dtype).reshape(shape, order=order)
+    return a
 
 
 def _matrix_call(fn, handle, chk, X, global_na, pi, pj, perspective, alternative, continuity, flags, scale_max,
@@ -321,9 +335,13 @@ class Context:
             pi_a = np.ascontiguousarray(pi, dtype=np.int32)
             pj_a = np.ascontiguousarray(pj, dtype=np.int32)
             P = pi_a.shape[0]
-        out = np.empty((P, 4), dtype=np.float64)
-        cnt = np.zeros((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
-        rsn = np.zeros(P, dtype=np.int32)
+        alloc = pinned_empty if (flags & FLAG_HOST_PINNED) else np.empty   # (X is the caller's: pinned by the caller)
+        out = alloc((P, 4), dtype=np.float64)
+        cnt = alloc((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
+        rsn = alloc(P, dtype=np.int32)
+        if cnt is not None:
+            cnt[...] = 0
+        rsn[...] = 0
         alt = ALTERNATIVE.get(alternative, ALT_OTHER)
         self._chk(lib().icikt_pairs_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a), P,
                                         PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, _ptr(out),
@@ -413,6 +431,11 @@ class MultiContext:
     def uses_rccl(self) -> bool:
         return bool(lib().icikt_multi_uses_rccl(self._h))
 
+    @property
+    def comm_ranks(self) -> int:
+        """Ranks of the RCCL communicator as RCCL reports them (0: device copies, no communicator)."""
+        return int(lib().icikt_multi_comm_ranks(self._h))
+
     def _chk(self, rc: int, what: str):
         if rc != SUCCESS:
             msg = lib().icikt_multi_last_error(self._h)
@@ -463,9 +486,13 @@ class MultiContext:
             pi_a = np.ascontiguousarray(pi, dtype=np.int32)
             pj_a = np.ascontiguousarray(pj, dtype=np.int32)
             P = pi_a.shape[0]
-        out = np.empty((P, 4), dtype=np.float64)
-        cnt = np.zeros((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
-        rsn = np.zeros(P, dtype=np.int32)
+        alloc = pinned_empty if (flags & FLAG_HOST_PINNED) else np.empty   # (X is the caller's: pinned by the caller)
+        out = alloc((P, 4), dtype=np.float64)
+        cnt = alloc((P, len(CNT_FIELDS)), dtype=np.int64) if want_counts else None
+        rsn = alloc(P, dtype=np.int32)
+        if cnt is not None:
+            cnt[...] = 0
+        rsn[...] = 0
         alt = ALTERNATIVE.get(alternative, ALT_OTHER)
         self._chk(lib().icikt_pairs_multi_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a), _ptr(pj_a),
                                               P, PERSPECTIVE[perspective], alt, int(bool(continuity)), flags, _ptr(out),

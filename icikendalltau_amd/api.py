@@ -457,7 +457,11 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
         ncore = len(engine.ctx.devices)
     eng = engine or _default_engine()
 
-    if return_matrix and not check_timing and world == 1 and hasattr(eng, "matrix"):
+    # the device-side exclusion rule holds up to MASK_VALS distinct finite values; the reference loops over any number
+    # (R/utils.R:16-20): a longer list takes the host-masking route below
+    n_finite = len({float(v) for v in np.atleast_1d(np.asarray([] if global_na is None else global_na, dtype=np.float64))
+                    if math.isfinite(v)})
+    if return_matrix and not check_timing and world == 1 and hasattr(eng, "matrix") and n_finite <= _lib.MASK_VALS:
         # One library call does everything below the argument checks on the device (icikt_matrix_f64): the exclusion
         # rule of setup_missing_matrix inside the pre-pass (no masked copy of the matrix on the host), the pair
         # kernels, scale_and_reshape, one copy of the five matrices back.  All pairs of the upper triangle need no
@@ -518,7 +522,7 @@ def ici_kendalltau(data_matrix, global_na=(float("nan"), float("inf"), 0), persp
     # scale_and_reshape
     if scale_max:
         have = _na_rm(taumax)                                           # max(taumax, na.rm = TRUE)
-        max_cor = have.max() if have.size else np.nan
+        max_cor = have.max() if have.size else -np.inf                  # max(numeric(0)) is -Inf in R (and in k_assemble)
         cor = raw / max_cor
     else:
         cor = raw.copy()

@@ -550,6 +550,22 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   return ICIKT_SUCCESS;
 }
 
+int mask_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp) {
+  c->prepared = false;
+  c->raw_valid = false;
+  PrepView pv{};
+  pv.n = (int)n_feat;
+  pv.n_pad = std::max(64, (int)((n_feat + 63) / 64 * 64));
+  pv.W = (int)((n_feat + 63) / 64);
+  pv.Wp = pv.W + 1;
+  pv.n_samp = (int)n_samp;
+  pv.mstride = pv.Wp;                      // the missing-row bitset is all a column's record holds here
+  HIPCHK(c, c->meta.reserve((size_t)std::max<int64_t>(n_samp, 1) * (size_t)pv.mstride));
+  pv.meta = c->meta.p;
+  c->pv = pv;
+  return ICIKT_SUCCESS;
+}
+
 int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end, hipStream_t stream) {
   const PrepView& pv = c->pv;
   if (!stream) stream = c->stream;
@@ -619,6 +635,7 @@ int icikt_prepare_cols_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_
   if (rc) return rc;
   rc = prepare_alloc(c, n_feat, n_samp, alloc_cols, col_end - col_begin);
   if (rc) return rc;
+  const icikt::host::PinnedScope pinned_scope(c, flags);
   rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, col_begin, col_end, flags);
   if (rc) return rc;
   c->prepared = true;
@@ -809,37 +826,6 @@ int icikt_reset_timers(icikt_ctx* c) {
 namespace icikt {
 namespace host {
 
-// true when the byte at p lies in host memory that is page-locked already (hipHostRegister or hipHostMalloc by the caller)
-static bool pinned_already(const void* p) {
-  hipPointerAttribute_t a{};
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-    (void)hipGetLastError();   // plain malloc memory: "invalid value" on this runtime
-    return false;
-  }
-  return a.type == hipMemoryTypeHost;
-}
-
-// every probe of the range (both ends and one per MB) lies in memory that is page-locked already
-static bool range_pinned_already(const void* p, size_t bytes) {
-  bool all = pinned_already(p) && pinned_already(static_cast<const char*>(p) + bytes - 1);
-  for (size_t off = (size_t)1 << 20; all && off < bytes; off += (size_t)1 << 20)
-    all = pinned_already(static_cast<const char*>(p) + off);
-  return all;
-}
-
-HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags) {
-  if (c->force_reg_fail) return HostLock::Refused;
-  // A range the caller has page-locked itself is used as it is.  (Asked first: this runtime ACCEPTS a second
-  // hipHostRegister of a registered range, and the hipHostUnregister that ends it takes the caller's registration
-  // away with it -- seen as "pointer does not correspond to a registered memory region" on the caller's own
-  // unregister.)
-  if (range_pinned_already(p, bytes)) return HostLock::Already;
-  if (hipHostRegister(const_cast<void*>(p), bytes, flags) == hipSuccess) return HostLock::Locked;
-  (void)hipGetLastError();
-  // refused for any other reason: the bytes go through the library's own pinned buffers
-  return HostLock::Refused;
-}
-
 // Host-side copies into / out of the library's pinned buffers, on a few threads: one core moves ~10 GB/s, the c4
 // matrix is 82 MB and PCIe takes it in 1.8 ms.  The threads belong to the context (started on first use, parked on a
 // condition variable between copies: creating and joining seven threads per chunk cost ~0.2 ms a time, a millisecond of
@@ -952,18 +938,23 @@ int ensure_bounce(icikt_ctx* c, size_t need) {
 
 // H2D of columns [col_begin, col_end) + K0 over them.  The copies run on the context's copy stream in column
 // chunks and K0 of a chunk waits only for its own chunk (an event per chunk), so the pre-pass of chunk i runs
-// while chunk i + 1 crosses PCIe.  The source is the caller's (pageable) matrix:
-//   mode 1 (default)  the source range is page-locked for the duration of the call (hipHostRegister): the copies
-//                     are true DMA from the caller's memory, no staging copy.  Refused because the caller has
-//                     page-locked it already: the same copies; refused for any other reason: mode 2
-//   mode 2            staged by this library through a pinned double buffer (a host memcpy per chunk)
-//   mode 3            the matrix is page-locked already (by the multi-device driver, once for all devices)
-//   mode 0            pageable copies through the runtime's own staging path: only for matrices below kLockMin
-//                     bytes, never selected for larger ones (icikt_host.h)
+// while chunk i + 1 crosses PCIe.  How the caller's matrix is read:
+//   staged (default)  through the library's pinned double buffer (a threaded host memcpy per chunk): the GPU never
+//                     touches the caller's pages, and the library never page-locks them
+//   pinned            ICIKT_FLAG_HOST_PINNED on the call: the caller has page-locked the matrix itself; the copies are
+//                     DMA straight out of it
+//   small             matrices below kLockMin bytes take the runtime's own staging path
+// prepass: kPrepassFull = K0; kPrepassMask = missing-row bitsets only (pairwise_completeness); kPrepassNone = the
+// columns are only copied (icikt_pairs_complete_f64 sorts masked copies, not the columns).
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister, bool pipelined,
-                       const std::function<int(size_t, int64_t)>* on_chunk) {
-  if (deferred_unregister) *deferred_unregister = nullptr;
+                       int64_t col_end, uint32_t flags, bool pipelined, const std::function<int(size_t, int64_t)>* on_chunk,
+                       int prepass) {
+  // what runs over the columns of a chunk once they are on the device
+  auto chunk_prepass = [&](int64_t c0, int64_t c1, hipStream_t st) -> int {
+    if (prepass == kPrepassFull) return prepare_launch(c, c->d_X.p, n_feat, c0, c1, st);
+    if (prepass == kPrepassMask) HIPCHK(c, icikt::launch_k0_mask(c->pv, c->d_X.p, n_feat, (int)c0, (int)(c1 - c0), st ? st : c->stream));
+    return ICIKT_SUCCESS;
+  };
   c->chunk_col_end.clear();
   const size_t nel = (size_t)std::max<int64_t>(n_feat * n_samp, 1);
   HIPCHK(c, c->d_X.reserve(nel));
@@ -979,18 +970,10 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
     // pre-pass launches the last pair-kernel launch waits for (c4: ten chunks of 104 columns finished their pre-pass
     // 1.4 ms after the last copy, four chunks of 256 right behind it)
     if (pipelined) chunk = std::max<int64_t>(chunk, std::min<int64_t>(c->prop.multiProcessorCount, (n_samp / 4) & ~(int64_t)1));
-    chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
+    if (prepass == kPrepassFull) chunk = std::min<int64_t>(chunk, std::max(1, c->sort_chunk));
     const double* src0 = X + col_begin * ld;
     const size_t span = ((size_t)(ncols - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
-    // (default: staged -- the library does not page-lock the caller's memory unless told to: icikt_host.h)
-    int mode = (span < kLockMin) ? 0 : (c->h2d_mode < 0 ? 2 : c->h2d_mode);
-    if (mode == 2 && c->h2d_mode < 0 && !c->force_reg_fail && range_pinned_already(src0, span)) mode = 3;   // page-locked by the caller: copied as it is
-    bool registered = false;
-    if (mode == 1) {
-      const HostLock lk = lock_host(c, src0, span, hipHostRegisterDefault);
-      registered = lk == HostLock::Locked;
-      if (lk == HostLock::Refused) mode = 2;   // never a copy from pageable memory of this size
-    }
+    const int mode = (span < kLockMin) ? 0 : (c->host_pinned ? 3 : 2);
     if (mode == 2) {
       rc = ensure_bounce(c, 2 * (size_t)chunk * col_bytes);
       if (rc) return rc;
@@ -1019,7 +1002,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
       if (pipelined) {
         // the chunk's pre-pass on the pre-pass stream; an event of its own tells the pair kernel's stream when
         if (e == hipSuccess) e = hipStreamWaitEvent(c->prep_stream, ev, 0);
-        if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc, c->prep_stream);
+        if (e == hipSuccess) rc = chunk_prepass(c0, c0 + nc, c->prep_stream);
         if ((size_t)k >= c->ev_chunk.size()) {
           hipEvent_t ne = nullptr;
           if (e == hipSuccess) e = hipEventCreateWithFlags(&ne, hipEventDisableTiming);
@@ -1031,23 +1014,18 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
         if (e == hipSuccess && rc == 0 && on_chunk) rc = (*on_chunk)((size_t)k, c0 + nc);
       } else {
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
-        if (e == hipSuccess) rc = prepare_launch(c, c->d_X.p, n_feat, c0, c0 + nc);
+        if (e == hipSuccess) rc = chunk_prepass(c0, c0 + nc, nullptr);
       }
     }
     if (pipelined && (e != hipSuccess || rc)) (void)hipStreamSynchronize(c->prep_stream);
-    if (registered && deferred_unregister && e == hipSuccess && rc == 0) {
-      // the caller goes on with host work while the copies run, and ends the registration itself
-      // (finish_upload) once it has waited for them
-      *deferred_unregister = src0;
-    } else if (registered || mode == 0 || mode == 2 || e != hipSuccess || rc) {
-      // the caller's buffer must stay page-locked (and alive) until the last copy has read it; the staging buffer
-      // of mode 2 serves the later transfers of the call as their bounce buffer
-      (void)hipStreamSynchronize(c->copy_stream);
-      if (registered) (void)hipHostUnregister(const_cast<double*>(src0));
-    }
+    // The staging buffer serves the later transfers of the call as their bounce buffer, so its last copy is waited for
+    // here.  A matrix the caller has page-locked is read in place: the pipelined callers go on with host work (the task
+    // list) and wait for the copy stream themselves before they return (finish_upload) -- no entry point returns while
+    // a copy still reads the caller's memory.
+    if (!(pipelined && mode == 3) || e != hipSuccess || rc) (void)hipStreamSynchronize(c->copy_stream);
     if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D of the matrix: ") + hipGetErrorString(e));
     if (rc) return rc;
-  } else if (ncols > 0) {
+  } else if (ncols > 0 && prepass == kPrepassFull) {
     rc = prepare_launch(c, c->d_X.p, n_feat, col_begin, col_end);  // n_feat == 0: statistics of empty columns
     if (rc) return rc;
   }
@@ -1071,14 +1049,13 @@ void prebuild_units(icikt_ctx* c) {
 // launch per chunk behind that chunk's pre-pass event.  The pairs among the columns that have arrived are counted
 // while the rest of the matrix still crosses PCIe: the available work grows with the square of the arrived columns,
 // so after the first millisecond of a c4-sized call the GPU never waits for the link again.
-int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags,
-                         const void** deferred_unregister) {
+int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags) {
   const size_t col_bytes = (size_t)n_feat * sizeof(double);
   const size_t span = (n_samp > 0 && n_feat > 0) ? ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double) : 0;
-  const bool can = !c->pv.wide && n_feat > 0 && c->n_pairs > 0 && c->h2d_mode != 3;
+  const bool can = !c->pv.wide && n_feat > 0 && c->n_pairs > 0;
   const bool want = c->pipe_mode < 0 ? (span >= ((size_t)24 << 20)) : (c->pipe_mode == 1 && (size_t)n_samp * col_bytes > ((size_t)8 << 20));
   if (!(can && want)) {
-    int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags, deferred_unregister, false);
+    int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags);
     if (rc) return rc;
     c->prepared = true;
     prebuild_units(c);   // host work under the copies; icikt_run_dev uploads the list
@@ -1138,7 +1115,7 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
       return launch_pair_tasks(c, pl, (int)first, (int)cnt);
     };
     rc = timer_begin(c, ICIKT_K_PAIRS, flags);
-    if (rc == 0) rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true, &on_chunk);
+    if (rc == 0) rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, true, &on_chunk);
     if (rc) { (void)hipStreamSynchronize(c->prep_stream); return rc; }
     c->prepared = true;
     nchunks = c->chunk_col_end.size();
@@ -1147,7 +1124,7 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
     c->units_dirty = true;
     t_enq = t_built = t_up = ms_since();
   } else {
-  rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, deferred_unregister, true, nullptr);
+  rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags & ~ICIKT_FLAG_TIMING, true, nullptr);
   if (rc) return rc;
   c->prepared = true;
   t_enq = ms_since();
@@ -1218,11 +1195,9 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
 
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
-  const HostLock lk = bytes < kLockMin ? HostLock::Already
-                     : (c->h2d_mode == 1 ? lock_host(c, src, bytes, hipHostRegisterDefault)
-                        : ((!c->force_reg_fail && range_pinned_already(src, bytes)) ? HostLock::Already : HostLock::Refused));
-  if (lk == HostLock::Refused) {
-    // through the library's pinned bounce buffer, a chunk at a time
+  if (bytes >= kLockMin) {
+    // through the library's pinned bounce buffer, a chunk at a time (pair and task lists: the library's own vectors
+    // or the caller's index arrays -- ICIKT_FLAG_HOST_PINNED speaks of the matrix and the result arrays only)
     const size_t cap = (size_t)8 << 20;
     int rc = ensure_bounce(c, std::min(bytes, cap));
     if (rc) return rc;
@@ -1238,7 +1213,6 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   }
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
   const hipError_t es = hipStreamSynchronize(c->stream);       // the host range must outlive the copy
-  if (lk == HostLock::Locked) (void)hipHostUnregister(const_cast<void*>(src));
   if (e == hipSuccess) e = es;
   if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("H2D copy: ") + hipGetErrorString(e));
   return ICIKT_SUCCESS;
@@ -1246,26 +1220,21 @@ int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
 
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ICIKT_SUCCESS;
-  if (bytes >= kLockMin) {
-    const HostLock lk = c->h2d_mode == 1 ? lock_host(c, dst, bytes, hipHostRegisterDefault)
-                        : ((!c->force_reg_fail && range_pinned_already(dst, bytes)) ? HostLock::Already : HostLock::Refused);
-    if (lk == HostLock::Locked) c->locked_out.push_back(dst);
-    if (lk == HostLock::Refused) {
-      // into a pinned buffer of the library's (kept from call to call: slot = position among the call's downloads);
-      // finish_downloads() moves it to the caller's array
-      const size_t slot = c->bounced_out.size();
-      if (slot >= c->out_pinned.size()) c->out_pinned.resize(slot + 1);
-      auto& ps = c->out_pinned[slot];
-      if (ps.bytes < bytes) {
-        if (ps.p) (void)hipHostFree(ps.p);
-        ps.p = nullptr; ps.bytes = 0;
-        HIPCHK(c, hipHostMalloc(&ps.p, bytes, hipHostMallocDefault));
-        ps.bytes = bytes;
-      }
-      c->bounced_out.push_back(icikt_ctx::Bounce{ps.p, dst, bytes});
-      HIPCHK(c, hipMemcpyAsync(ps.p, src, bytes, hipMemcpyDeviceToHost, c->stream));
-      return ICIKT_SUCCESS;
+  if (bytes >= kLockMin && !c->host_pinned) {
+    // into a pinned buffer of the library's (kept from call to call: slot = position among the call's downloads);
+    // finish_downloads() moves it to the caller's array
+    const size_t slot = c->bounced_out.size();
+    if (slot >= c->out_pinned.size()) c->out_pinned.resize(slot + 1);
+    auto& ps = c->out_pinned[slot];
+    if (ps.bytes < bytes) {
+      if (ps.p) (void)hipHostFree(ps.p);
+      ps.p = nullptr; ps.bytes = 0;
+      HIPCHK(c, hipHostMalloc(&ps.p, bytes, hipHostMallocDefault));
+      ps.bytes = bytes;
     }
+    c->bounced_out.push_back(icikt_ctx::Bounce{ps.p, dst, bytes});
+    HIPCHK(c, hipMemcpyAsync(ps.p, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return ICIKT_SUCCESS;
   }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   return ICIKT_SUCCESS;
@@ -1273,8 +1242,6 @@ int download(icikt_ctx* c, void* dst, const void* src, size_t bytes) {
 
 // (the stream has been synchronised; `ok` = it ended without an error, i.e. the bounced bytes are the results)
 void finish_downloads(icikt_ctx* c, bool ok) {
-  for (void* p : c->locked_out) (void)hipHostUnregister(p);
-  c->locked_out.clear();
   for (auto& b : c->bounced_out)
     if (ok) par_memcpy(c, b.dst, b.pinned, b.bytes);
   c->bounced_out.clear();
@@ -1322,16 +1289,12 @@ int icikt_pairs_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sam
   if (rc) return rc;
   // The copies and the pre-pass are only ENQUEUED here; the host builds the pair kernel's task list while the matrix
   // crosses PCIe (it used to wait for the copies first and build the list afterwards, with the GPU idle: 1.2 ms of
-  // 14.3 on c4), and ends the page-locking of the caller's matrix after the final synchronisation.
-  const void* registered_src = nullptr;
-  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags, &registered_src);
+  // 14.3 on c4).  Nothing may still read the caller's matrix when the call returns: finish_upload.
+  const icikt::host::PinnedScope pinned_scope(c, flags);
+  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags);
   auto finish_upload = [&]() {
     (void)hipStreamSynchronize(c->prep_stream);
-    if (registered_src) {
-      (void)hipStreamSynchronize(c->copy_stream);
-      (void)hipHostUnregister(const_cast<void*>(registered_src));
-      registered_src = nullptr;
-    }
+    (void)hipStreamSynchronize(c->copy_stream);
   };
   if (rc) { finish_upload(); return rc; }
   const int64_t P = c->n_pairs;
@@ -1382,7 +1345,7 @@ int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt
       for (int q = 0; q < ms->n_vals; ++q) dup = dup || ms->vals[q] == v;
       if (dup) continue;
       if (ms->n_vals == icikt::ICIKT_MASK_VALS)
-        return fail(c, ICIKT_E_INVALID, "matrix: more than 6 finite values in global_na");
+        return fail(c, ICIKT_E_INVALID, "matrix: more than 32 distinct finite values in global_na (mask the matrix on the host and pass NaN)");
       ms->vals[ms->n_vals++] = v;
     }
   }
@@ -1433,19 +1396,15 @@ int icikt_matrix_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_sa
   HIPCHK(c, c->d_red.reserve(8));
   HIPCHK(c, c->d_out4.reserve(std::max<size_t>(P, 1) * 4));
   HIPCHK(c, c->d_reasons.reserve(std::max<size_t>(P, 1)));
-  const void* registered_src = nullptr;
+  const icikt::host::PinnedScope pinned_scope(c, flags);
   c->k0_mask = &ms;
   c->k0_keep = keep_bytes ? c->d_keep.p : nullptr;
-  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags, &registered_src);
+  rc = icikt::host::upload_prepare_pairs(c, X, n_feat, n_samp, ld, flags);
   c->k0_mask = nullptr;
   c->k0_keep = nullptr;
   auto finish_upload = [&]() {
     (void)hipStreamSynchronize(c->prep_stream);
-    if (registered_src) {
-      (void)hipStreamSynchronize(c->copy_stream);
-      (void)hipHostUnregister(const_cast<void*>(registered_src));
-      registered_src = nullptr;
-    }
+    (void)hipStreamSynchronize(c->copy_stream);
   };
   if (rc) { finish_upload(); return rc; }
   unsigned long long red[8] = {};
@@ -1495,6 +1454,7 @@ int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int6
   // the matrix and the pair list, once
   rc = icikt_set_pairs(c, pi, pj, n_pairs);
   if (rc) return rc;
+  const icikt::host::PinnedScope pinned_scope(c, flags);
   DevBuf<int32_t> all_pi, all_pj;  // the caller's list stays on the device while d_pi / d_pj hold a chunk's (2k, 2k+1)
   HIPCHK(c, all_pi.reserve((size_t)n_pairs));
   HIPCHK(c, all_pj.reserve((size_t)n_pairs));
@@ -1502,11 +1462,9 @@ int icikt_pairs_complete_f64(icikt_ctx* c, const double* X, int64_t n_feat, int6
     HIPCHK(c, hipMemcpyAsync(all_pi.p, c->d_pi.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(all_pj.p, c->d_pj.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     int r = ICIKT_SUCCESS;
-    if (n_feat > 0) {  // H2D of the matrix; none of its own columns is sorted, only the masked pair columns are
-      const size_t nel = (size_t)n_feat * (size_t)n_samp;
-      HIPCHK(c, c->d_X.reserve(nel));
-      HIPCHK(c, hipMemcpy2DAsync(c->d_X.p, (size_t)n_feat * sizeof(double), X, (size_t)ld * sizeof(double),
-                                 (size_t)n_feat * sizeof(double), (size_t)n_samp, hipMemcpyHostToDevice, c->stream));
+    if (n_feat > 0) {  // H2D of the matrix (staged like every other matrix upload); none of its own columns is sorted, only the masked pair columns are
+      r = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, 0u, false, nullptr, icikt::host::kPrepassNone);
+      if (r) return r;
     }
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_pairs, ((int64_t)3 << 29) / std::max<int64_t>(16 * n_feat, 16)));
     HIPCHK(c, c->d_Xp.reserve((size_t)std::max<int64_t>(2 * chunk * n_feat, 1)));
@@ -1566,8 +1524,9 @@ int icikt_pair_f64(icikt_ctx* c, const double* x, const double* y, int64_t n, in
     memcpy(xy.data() + n, y, (size_t)n * sizeof(double));
   }
   const int32_t pi = 0, pj = 1;
-  return icikt_pairs_f64(c, xy.data(), n, 2, n, &pi, &pj, 1, perspective, alternative, continuity, flags, out4,
-                         counts, reason);
+  // (the two vectors travel in a vector of this function's: whatever the caller says about ITS memory does not hold for it)
+  return icikt_pairs_f64(c, xy.data(), n, 2, n, &pi, &pj, 1, perspective, alternative, continuity,
+                         flags & ~ICIKT_FLAG_HOST_PINNED, out4, counts, reason);
 }
 
 int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld,
@@ -1585,11 +1544,14 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
   if (rc) return rc;
   rc = icikt_set_pairs(c, pi, pj, n_pairs);
   if (rc) return rc;
-  rc = prepare_alloc(c, n_feat, n_samp, n_samp, n_samp);
+  // The mask-only pre-pass (k0_mask): one streaming pass over each column chunk as it arrives, no sort -- the
+  // reference's missing_either (R/kendalltau.R:626-629) is sum(in_x | in_y) and nothing more.
+  rc = icikt::host::mask_alloc(c, n_feat, n_samp);
   if (rc) return rc;
-  rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, 0);
-  if (rc) return rc;
-  c->prepared = true;
+  if (n_feat > 0) {
+    rc = icikt::host::upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, 0u, false, nullptr, icikt::host::kPrepassMask);
+    if (rc) return rc;
+  }
   auto body = [&]() -> int {
     HIPCHK(c, c->d_counts.reserve((size_t)n_pairs));
     HIPCHK(c, icikt::launch_missingness(c->pv, c->d_pi.p, c->d_pj.p, n_pairs, c->d_counts.p, c->stream));
@@ -1607,14 +1569,13 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 // path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
 // wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), gridmult (persistent grid as a
 // multiple of the resident waves, always), gridcap (persistent grid: at most this many workgroups),
-// h2d (register | stage: how a host matrix of 256 KB or more is read), regfail (0 | 1: behave as if every
-// hipHostRegister were refused -- the transfers then go through the library's pinned buffers),
-// verbose (0 | 1: print the plan to stderr).
+// pipe (0 | 1: the host entries' chunk pipeline off / on whenever possible), verbose (0 | 1: print the plan to stderr).
+// (The keys h2d and regfail of rounds 2-3 are gone with the mode they steered: the library no longer page-locks
+// caller memory, icikt_host.h.)
 int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   if (!c) return ICIKT_E_INVALID;
   icikt_ctx::PlanOverride ov;
-  int h2d = -1, pipe = -1;
-  bool regfail = false;
+  int pipe = -1;
   std::string sp = spec ? spec : "";
   size_t pos = 0;
   while (pos < sp.size()) {
@@ -1636,15 +1597,10 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());
-    else if (key == "regfail") regfail = (val[0] == '1');
     else if (key == "pipe") pipe = (val[0] == '1') ? 1 : 0;
-    else if (key == "h2d") h2d = (val == "register") ? 1 : (val == "stage") ? 2 : -2;
     else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
-    if (h2d == -2) return fail(c, ICIKT_E_INVALID, "debug_set_plan: h2d must be register or stage");
   }
   c->plan_ov = ov;
-  c->h2d_mode = h2d;
-  c->force_reg_fail = regfail;
   c->pipe_mode = pipe;
   c->raw_valid = false;
   c->wpb = 0;  // tasks are rebuilt for the new plan

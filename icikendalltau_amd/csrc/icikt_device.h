@@ -38,7 +38,8 @@ __host__ __device__ inline uint32_t tprog_n0(uint32_t e) { return (e >> 10) & 63
 // R/kendalltau.R:119-121) before the pre-pass.  The pre-pass applies it while it reads the matrix, so the masked copy
 // `exclude_data` never exists.  A NaN in the data is missing for ici_kt whether or not NaN is in global_na
 // (Rcpp is_na, src/kendallc.cpp:181), but counts as excluded (n_good, keep) only when it is.
-constexpr int ICIKT_MASK_VALS = 6;
+constexpr int ICIKT_MASK_VALS = 32;   // distinct finite global_na values the device rule holds (the struct travels as a kernel
+                                      // argument); a longer list is masked by the host front-end before the call (api.py, icikt_mi355x.R)
 struct MaskSpec {
   int mask_nan;                  // global_na holds NA
   int mask_inf;                  // global_na holds Inf: is.infinite(), both signs
@@ -47,7 +48,7 @@ struct MaskSpec {
 };
 __host__ __device__ inline bool mask_excluded(const MaskSpec& ms, double v) {
   bool ex = (ms.mask_nan && v != v) || (ms.mask_inf && (v - v != 0.0) && v == v);   // v - v: NaN for +-Inf, 0 otherwise
-  for (int k = 0; k < ICIKT_MASK_VALS; ++k) ex = ex || (k < ms.n_vals && v == ms.vals[k]);
+  for (int k = 0; k < ms.n_vals; ++k) ex = ex || (v == ms.vals[k]);   // (n_vals <= ICIKT_MASK_VALS, wave-uniform)
   return ex;
 }
 
@@ -171,6 +172,8 @@ hipError_t k1_blocks_per_cu(int np, int half_items, int wpb, size_t lds_bytes, i
 hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, const PairRaw* raw,
                      int64_t n_pairs, int perspective, int alternative, int continuity, int exact64,
                      double* out4, int64_t* counts, int32_t* reasons, hipStream_t s);
+// the mask-only pre-pass of pairwise_completeness: missing-row bitsets (NaN = missing) of columns [col_begin, col_begin + ncols)
+hipError_t launch_k0_mask(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s);
 hipError_t launch_missingness(const PrepView& pv, const int32_t* pi, const int32_t* pj, int64_t n_pairs,
                               int64_t* missing, hipStream_t s);
 hipError_t launch_mask_pairs(const double* dX, int64_t ld, int n, const int32_t* pi, const int32_t* pj, int64_t first,

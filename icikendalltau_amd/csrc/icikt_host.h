@@ -73,11 +73,8 @@ struct icikt_ctx {
   void* pinned_tasks = nullptr;   // pinned staging of the task list the pipelined host path generates chunk by chunk
   size_t pinned_tasks_bytes = 0;
   bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
-  // result buffers of the caller that were page-locked for a D2H copy (icikt::host::download): released by
-  // finish_downloads() once the stream has been synchronised
-  std::vector<void*> locked_out;
-  // ... and result copies that could not be page-locked in place: a pinned bounce allocation per copy, moved to the
-  // caller's array (and freed) by finish_downloads()
+  // result copies of 256 KB or more cross a pinned buffer of the library's (one per array of a call, kept from call
+  // to call) and are moved to the caller's array by finish_downloads()
   struct Bounce { void* pinned; void* dst; size_t bytes; };
   struct PinnedSlot { void* p = nullptr; size_t bytes = 0; };
   std::vector<PinnedSlot> out_pinned;   // result downloads: one pinned buffer per array of a call, kept from call to call
@@ -93,10 +90,10 @@ struct icikt_ctx {
   std::vector<int64_t> chunk_col_end;      // columns [.., chunk_col_end[k]) have arrived with chunk k (this call)
   int pipe_mode = -1;                      // -1: the library's choice; 0 / 1: off / on whenever possible (debug plan)
   hipEvent_t ev_copy[4] = {};
-  void* pinned = nullptr;   // pinned staging area (h2d mode "stage", and every transfer whose page-locking was refused)
+  void* pinned = nullptr;   // pinned staging area: the matrix in column chunks (two halves), pair / task lists in 8 MB pieces
   size_t pinned_bytes = 0;
-  int h2d_mode = -1;        // -1: library default (= 2); 1 register the caller's buffers, 2 stage through pinned buffers, 3 page-locked by the caller
-  bool force_reg_fail = false;  // test hook (icikt_debug_set_plan "regfail=1"): behave as if every hipHostRegister failed
+  bool host_pinned = false; // for the duration of a host entry called with ICIKT_FLAG_HOST_PINNED: the caller has page-locked
+                            // the matrix and the result arrays, they are copied from / into directly (PinnedScope)
   DevBuf<double> d_X, d_out4, d_Xp;  // d_Xp: masked column pairs of icikt_pairs_complete_f64
   // full-matrix entry (icikt_matrix_f64): the exclusion rule the pre-pass applies while it reads the matrix and the
   // optional keep bytes it writes (both only for the duration of that call), the assembled matrices, the reduction
@@ -150,48 +147,56 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
 int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin, int64_t col_end, hipStream_t stream = nullptr);
 // Host matrix -> device (columns [col_begin, col_end) only) overlapped with K0 by column chunks; the device copy
 // keeps the full n_feat x n_samp layout (leading dimension n_feat) in c->d_X.  prepare_alloc() must have run.
-// deferred_unregister (optional): when the source was page-locked for the call, do not wait for the copies; the
-// caller synchronises c->copy_stream and calls hipHostUnregister(*deferred_unregister) itself.
 // pipelined: the pre-pass launches go to c->prep_stream, one event per chunk in c->ev_chunk / c->chunk_col_end; the
-// caller makes c->stream wait for them (per chunk, or for the last one).
+// caller makes c->stream wait for them (per chunk, or for the last one), and synchronises c->copy_stream before it
+// returns to ITS caller.  prepass: what runs over a chunk once it has arrived -- the full pre-pass (K0), the
+// mask-only one of pairwise_completeness (k0_mask: meta alone must be allocated, mask_alloc), or nothing.
+enum { kPrepassNone = 0, kPrepassFull = 1, kPrepassMask = 2 };
+// Allocate c->pv for the missing-row bitsets alone (meta; no order / rec / sort scratch).  Leaves the context unprepared.
+int mask_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp);
 int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, int64_t col_begin,
-                       int64_t col_end, uint32_t flags, const void** deferred_unregister = nullptr, bool pipelined = false,
-                       const std::function<int(size_t, int64_t)>* on_chunk = nullptr);   // pipelined: called per chunk (index, columns arrived)
+                       int64_t col_end, uint32_t flags, bool pipelined = false,
+                       const std::function<int(size_t, int64_t)>* on_chunk = nullptr,   // pipelined: called per chunk (index, columns arrived)
+                       int prepass = kPrepassFull);
 // H2D + pre-pass + pair kernel of the host entries: pipelined by chunks when the matrix has several, else in sequence.
 // Leaves the pair kernel's counts in c->d_raw (raw_valid): the caller runs the epilogue (icikt_run_dev with
 // ICIKT_FLAG_REUSE_COUNTS).
-int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags,
-                         const void** deferred_unregister);
+int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_samp, int64_t ld, uint32_t flags);
 // global_na values (NaN = NA, +-Inf = Inf, anything else compared with ==) -> the pre-pass's exclusion rule
 int make_mask_spec(icikt_ctx* c, const double* global_na, int n_global_na, icikt::MaskSpec* ms);
 // Build the pair kernel's task list on the host now (prepare_alloc and a pair list must be in place).
 void prebuild_units(icikt_ctx* c);
-// Host <-> device copies of the caller's (pageable) memory.  HIP pins pageable memory on the fly for copies of 1 MB and
-// more; that path faulted intermittently in round 2 (a GPU memory-access fault at a host heap address, under load:
-// DESIGN.md section 6), and so -- once in a dozen full test runs of round 3 -- did copies from and to ranges the library
-// had page-locked itself for the call (hipHostRegister / hipHostUnregister per call on heap memory that Python frees and
-// reuses).  The library therefore moves every transfer of kLockMin bytes or more through its OWN pinned buffers
-// (hipHostMalloc, kept from call to call), with the host-side copies spread over a few threads:
-//   * the matrix: double-buffered column chunks (mode 2 "stage"), each chunk's pre-pass and pair-kernel launches enqueued
-//     before the host stages the next chunk;
-//   * pair lists: a bounce buffer in chunks (upload_sync); results: one pinned buffer per array (download /
+// Host <-> device copies of the caller's memory.  THE LIBRARY NEVER PAGE-LOCKS CALLER MEMORY (no hipHostRegister /
+// hipHostUnregister anywhere in it, since round 4) and never hands pageable memory of 256 KB or more to an asynchronous
+// copy: rounds 2 and 3 each saw one GPU memory-access fault at a host heap address inside a host entry, with
+// per-call registrations of heap ranges that Python frees and reuses; DESIGN.md section 6 lists what a reading of
+// that code found (registrations of neighbouring, non-page-aligned heap ranges set up and torn down independently
+// while copies from a neighbour were in flight) and why the mode was deleted rather than repaired.
+//   * the matrix: double-buffered column chunks through the library's pinned buffer (hipHostMalloc, kept from call to
+//     call), host-side copies on a few threads, each chunk's pre-pass and pair-kernel launches enqueued before the
+//     host stages the next chunk;
+//   * pair lists: a bounce buffer in 8 MB pieces (upload_sync); results: one pinned buffer per array (download /
 //     finish_downloads);
-//   * memory the CALLER has page-locked (hipPointerGetAttributes) is used as it is;
-//   * icikt_debug_set_plan("h2d=register") page-locks the caller's ranges for the call instead (the round-2 / early
-//     round-3 default; c4: 11.1 ms against 11.4-11.6 ms staged) -- kept for measurement.
-// Smaller copies take the runtime's staging path, which does not touch the caller's pages from the GPU.
+//   * ICIKT_FLAG_HOST_PINNED: the caller states that the matrix and the result arrays of THIS call lie in memory it
+//     has page-locked itself (hipHostMalloc / hipHostRegister): they are copied from and into directly.  The library
+//     does not probe the caller's memory (hipPointerGetAttributes logs an error for every pageable pointer).
+// Copies below kLockMin take the runtime's staging path, which does not touch the caller's pages from the GPU.
 constexpr size_t kLockMin = (size_t)256 << 10;
-enum class HostLock { Locked /* by this call: unregister afterwards */, Already /* pinned by the caller */, Refused };
-HostLock lock_host(icikt_ctx* c, const void* p, size_t bytes, unsigned flags);
+struct PinnedScope {
+  icikt_ctx* c;
+  PinnedScope(icikt_ctx* ctx, uint32_t flags) : c(ctx) { c->host_pinned = (flags & ICIKT_FLAG_HOST_PINNED) != 0; }
+  ~PinnedScope() { c->host_pinned = false; }
+  PinnedScope(const PinnedScope&) = delete;
+  PinnedScope& operator=(const PinnedScope&) = delete;
+};
 // grow c->pinned to at least `need` bytes (no copy may be in flight from or into it)
 int ensure_bounce(icikt_ctx* c, size_t need);
 void destroy_copy_pool(void* pool);
 // H2D on c->stream, complete (and the host range released) on return
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes);
-// after the stream that carries download() copies has been synchronised: end the page-locking of their targets and
-// deliver the bounced ones
+// after the stream that carries download() copies has been synchronised: deliver the bounced ones
 void finish_downloads(icikt_ctx* c, bool ok = true);
-// D2H of a result array into a pageable host buffer on c->stream (not synchronised; finish_downloads afterwards)
+// D2H of a result array into the caller's buffer on c->stream (not synchronised; finish_downloads afterwards)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 
 }  // namespace host

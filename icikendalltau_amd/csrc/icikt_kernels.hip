@@ -2830,6 +2830,26 @@ k2_epilogue(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restri
 // ------------------------------------------------------------------------------------------------
 // pairwise missingness (pairwise_completeness, R/kendalltau.R:611-629): popcount of mask OR
 // ------------------------------------------------------------------------------------------------
+// The mask-only pre-pass: the missing-row bitset of a column and nothing else -- no sort, no statistics.  The
+// reference's missing_either (R/kendalltau.R:626-629) never sorts either; the full pre-pass cost 13 ms of sorting per
+// c5 matrix here for bitsets that one streaming pass delivers.  One workgroup per (column, slab of 64 words).
+constexpr int KM_WORDS = 64;   // words (= waves' 64-row steps) per workgroup: 4 096 rows, 32 KB of the column
+__global__ void __launch_bounds__(256)
+k0_mask(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin) {
+  const int c = col_begin + (int)blockIdx.x;
+  const double* col = X + (int64_t)c * ld;
+  unsigned long long* mask = pv.col_mask(c);
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const int w0 = (int)blockIdx.y * KM_WORDS;
+  for (int w = w0 + wave; w < min(w0 + KM_WORDS, pv.W); w += 4) {
+    const int i = w * 64 + lane;
+    const double v = (i < pv.n) ? col[i] : 0.0;
+    const unsigned long long b = __ballot(v != v);
+    if (lane == 0) mask[w] = b;
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) mask[pv.W] = 0ull;
+}
+
 __global__ void __launch_bounds__(256)
 k_missingness(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restrict__ pj, int64_t n_pairs,
               int64_t* __restrict__ missing) {
@@ -3313,6 +3333,14 @@ hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStr
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k0_expand, dim3(ncols), dim3(64 * KX_WAVES), lds, s, pv, col_begin, ncols, staged);
+  return hipGetLastError();
+}
+
+hipError_t launch_k0_mask(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, hipStream_t s) {
+  if (ncols <= 0) return hipSuccess;
+  (void)hipGetLastError();
+  const unsigned slabs = (unsigned)std::max(1, (pv.W + KM_WORDS - 1) / KM_WORDS);
+  hipLaunchKernelGGL(k0_mask, dim3((unsigned)ncols, slabs), dim3(256), 0, s, pv, dX, ld, col_begin);
   return hipGetLastError();
 }
 

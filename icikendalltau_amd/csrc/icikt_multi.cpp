@@ -346,7 +346,7 @@ void rank_main(Call& a, int r) {
     RANKCHK_HIP(es);
   };
   phase_c();
-  if (!c->locked_out.empty() || !c->bounced_out.empty()) {   // phase C left early: nothing may still write the caller's arrays
+  if (!c->bounced_out.empty()) {   // phase C left early: nothing may still write the caller's arrays
     (void)hipStreamSynchronize(c->stream);
     icikt::host::finish_downloads(c, false);
   }
@@ -423,6 +423,11 @@ void icikt_multi_destroy(icikt_multi* m) {
 const char* icikt_multi_last_error(const icikt_multi* m) { return m ? m->err.c_str() : "null handle"; }
 int icikt_multi_n_gpu(const icikt_multi* m) { return m ? m->n : 0; }
 int icikt_multi_uses_rccl(const icikt_multi* m) { return (m && m->rccl) ? 1 : 0; }
+int icikt_multi_comm_ranks(const icikt_multi* m) {
+  if (!m || !m->rccl || m->comms.empty() || !m->comms[0]) return 0;
+  int n = 0;
+  return ncclCommCount(m->comms[0], &n) == ncclSuccess ? n : -1;
+}
 
 int icikt_multi_phase_ms(const icikt_multi* m, double* ms) {
   if (!m || !ms) return ICIKT_E_INVALID;
@@ -481,15 +486,12 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   // state of the tuned kernels, which wide columns do not have.
   if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0 || n_feat > ICIKT_MAX_FEATURES) {
     icikt_ctx* c = m->ctx[0];
-    const int saved = c->h2d_mode;
-    c->h2d_mode = -1;
     const double t0 = now_ms();
     const int rc = mx ? icikt_matrix_f64(c, X, n_feat, n_samp, ld, mx->global_na, mx->n_global_na, pi, pj, n_pairs, perspective,
                                          alternative, continuity, flags, mx->scale_max, mx->diag_good, mx->out5, mx->keep,
                                          mx->reason_counts)
                       : icikt_pairs_f64(c, X, n_feat, n_samp, ld, pi, pj, n_pairs, perspective, alternative, continuity, flags,
                                         out4, counts, reasons);
-    c->h2d_mode = saved;
     if (rc) return mfail(m, rc, icikt_last_error(c));
     m->ranks_used = 1;   // the caller can tell (icikt_multi_ranks_used); the whole call is booked as the pairs phase
     m->phase_ms[ICIKT_MULTI_PHASE_PAIRS] = m->rank_ms[ICIKT_MULTI_PHASE_PAIRS] = now_ms() - t0;
@@ -529,22 +531,10 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   a.order_base.assign((size_t)G, nullptr); a.meta_base.assign((size_t)G, nullptr);
   a.out4_dev.assign((size_t)G, nullptr); a.counts_dev.assign((size_t)G, nullptr); a.reasons_dev.assign((size_t)G, nullptr);
 
-  // Default: every rank stages its columns through its own pinned buffer (icikt_host.h: the library does not page-lock
-  // the caller's memory unless told to).  h2d=register: the caller's matrix is page-locked once and every rank DMAs its
-  // columns straight out of it; refused (and not because the caller has page-locked it already): staged again --
-  // never an asynchronous copy from pageable memory
-  const size_t span = ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double);
-  bool registered = false;
-  int rank_mode = m->ctx[0]->h2d_mode;
-  if (rank_mode < 0) rank_mode = 2;
-  if (rank_mode == 3 || rank_mode == 1) {
-    (void)hipSetDevice(m->devices[0]);
-    const icikt::host::HostLock lk = icikt::host::lock_host(m->ctx[0], X, span, hipHostRegisterPortable);
-    registered = lk == icikt::host::HostLock::Locked;
-    rank_mode = (lk == icikt::host::HostLock::Refused) ? 2 : 3;
-  }
-  std::vector<int> saved_modes;
-  for (icikt_ctx* c : m->ctx) { saved_modes.push_back(c->h2d_mode); c->h2d_mode = rank_mode; }
+  // Every rank stages its columns through its own pinned buffer (icikt_host.h: the library never page-locks the caller's
+  // memory); with ICIKT_FLAG_HOST_PINNED the caller has page-locked the matrix and the result arrays (portably, for
+  // several devices: hipHostMallocPortable / hipHostRegisterPortable) and every rank DMAs its columns straight out of it.
+  for (icikt_ctx* c : m->ctx) c->host_pinned = (flags & ICIKT_FLAG_HOST_PINNED) != 0;
 
   std::vector<std::thread> th;
   bool started = true;
@@ -560,11 +550,7 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   }
   if (started) rank_main(a, 0);  // the calling thread is rank 0
   for (auto& t : th) t.join();
-  for (size_t r = 0; r < m->ctx.size(); ++r) m->ctx[r]->h2d_mode = saved_modes[r];
-  if (registered) {
-    (void)hipSetDevice(m->devices[0]);
-    (void)hipHostUnregister(const_cast<double*>(X));
-  }
+  for (icikt_ctx* c : m->ctx) c->host_pinned = false;
   m->ranks_used = G;
   for (int r = 0; r < G; ++r)
     for (int k = 0; k < ICIKT_MULTI_PHASES; ++k)

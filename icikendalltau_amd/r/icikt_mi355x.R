@@ -104,10 +104,27 @@ ici_kendalltau_gpu = function(data_matrix, global_na = c(NA, Inf, 0), perspectiv
     cmp = do.call(rbind, setup_comparisons(samples, include_only, diag_good, 1L))
     pi = match(cmp[, 1], samples); pj = match(cmp[, 2], samples)
   }
+  # the device-side exclusion rule holds up to 32 distinct finite global_na values (the reference loops over any number,
+  # R/utils.R:16-20): a longer list is applied here, by the reference's own setup_missing_matrix, and NA handed over.
+  # keep = t(!exclude_loc) (R/kendalltau.R:417) then comes from this mask: the masked matrix would count data NaN in.
+  exclude_loc = NULL
+  if (length(unique(global_na[is.finite(global_na)])) > 32L) {
+    exclude_loc = setup_missing_matrix(data_matrix, global_na)
+    data_matrix[exclude_loc] = NA
+    global_na = NA_real_          # every excluded cell is NA now; cells that were NaN without NA in global_na are
+  }                               # put right below (n_good, keep)
   t1 = Sys.time()
   res = .Call("icikt_R_matrix", data_matrix, as.double(global_na), pi, pj, perspective, alternative, continuity,
               scale_max, diag_good, as.integer(device), as.integer(n_gpu))
   t2 = Sys.time()
+  if (!is.null(exclude_loc)) {    # n_good = colSums(!exclude_loc) of the CALLER's rule (R/kendalltau.R:375-386)
+    res$keep = t(!exclude_loc)
+    if (diag_good) {
+      n_good = colSums(!exclude_loc)
+      diag(res$raw) = diag(res$cor) = n_good / max(n_good)
+      diag(res$completeness) = n_good / nrow(exclude_loc)
+    }
+  }
   for (code in 2:4) for (k in seq_len(res$reason_counts[code + 1])) warning(.icikt_warn[[as.character(code)]], call. = FALSE)
   out = res[c("cor", "raw", "pvalue", "taumax", "completeness")]
   for (nm in names(out)) dimnames(out[[nm]]) = list(samples, samples)

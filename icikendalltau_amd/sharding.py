@@ -126,14 +126,20 @@ class ShardedPrepass:
                 self.dist.all_gather(parts, mine.cpu())
                 full.copy_(torch.cat(parts))
 
-    def run(self, flags: int = 0):
-        """K0 on this rank's columns, exchange, rebuild of rec / hirow / tgroups for the columns received."""
+    def run(self, flags: int = 0, on_phase=None):
+        """K0 on this rank's columns, exchange, rebuild of rec / hirow / tgroups for the columns received.
+        on_phase(name): called after "k0" and after "exchange" (all-gather + rebuild) have been enqueued -- bench.py
+        records an event on the launch stream there (per-rank phase times)."""
         self.prepare_local(self.c0, self.c1, self.alloc_cols, flags)
+        if on_phase is not None:
+            on_phase("k0")
         self.exchange()
         if self.c0 > 0:
             self.ctx.expand_cols_dev(0, min(self.c0, self.n_samp), flags)
         if self.c1 < self.n_samp:
             self.ctx.expand_cols_dev(self.c1, self.n_samp, flags)
+        if on_phase is not None:
+            on_phase("exchange")
 
 
 def gather_blocks(dist, out_local, n_each: int, device, via_host: bool, to_all: bool):

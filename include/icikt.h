@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICIKT_VERSION 300 /* 0.3.0: icikt_matrix_f64 (device-side full-matrix assembly), per-rank phase times */
+#define ICIKT_VERSION 400 /* 0.4.0: ICIKT_FLAG_HOST_PINNED (no page-locking of caller memory by the library), mask-only missingness pre-pass */
 
 /* status codes */
 #define ICIKT_SUCCESS 0
@@ -71,6 +71,13 @@ extern "C" {
                                      list, keep its integer counts and run the epilogue only -- "local" is derived
                                      from the same counts as "global", so the second perspective (or another
                                      alternative / continuity) costs microseconds */
+
+#define ICIKT_FLAG_HOST_PINNED 8u  /* host entries: the caller states that the matrix and the result arrays of this call
+                                     lie in memory it has page-locked itself (hipHostMalloc / hipHostRegister); they are
+                                     then copied from and into directly.  Without it (default) every transfer of 256 KB
+                                     or more crosses the library's own pinned buffers: the library never page-locks
+                                     and never probes caller memory.  Setting it for pageable memory is a caller error
+                                     with the consequences of an asynchronous copy from pageable memory. */
 
 /* per-pair reason codes; the host wrapper raises the reference's warnings from them */
 #define ICIKT_OK 0
@@ -187,7 +194,8 @@ int icikt_pair_f64(icikt_ctx *ctx, const double *x, const double *y, int64_t n, 
  * ici_kendalltau() below its argument checks (R/kendalltau.R:117-176), with NOTHING left to the host:
  *   setup_missing_matrix (R/utils.R:1-23)     global_na is applied by the pre-pass while it reads X: a cell is
  *                                             excluded if it is NaN and global_na holds a NaN, infinite and global_na
- *                                             holds an Inf, or == any other global_na value (at most 6 of those).  The
+ *                                             holds an Inf, or == any other global_na value (at most 32 distinct ones:
+ *                                             ICIKT_E_INVALID beyond; the front-ends mask such a matrix themselves).  The
  *                                             masked copy `exclude_data` (R/kendalltau.R:119-121) never exists.  A
  *                                             NaN in X is missing for ici_kt whatever global_na says (Rcpp is_na,
  *                                             src/kendallc.cpp:181) but counts as excluded only under the rule, as in R.
@@ -227,6 +235,9 @@ void icikt_multi_destroy(icikt_multi *m);
 const char *icikt_multi_last_error(const icikt_multi *m);
 int icikt_multi_n_gpu(const icikt_multi *m);
 int icikt_multi_uses_rccl(const icikt_multi *m);
+/* Ranks of the handle's RCCL communicator as RCCL reports them (ncclCommCount); 0 when the handle exchanges by device
+ * copies and has no communicator, -1 on an RCCL error. */
+int icikt_multi_comm_ranks(const icikt_multi *m);
 int icikt_pairs_multi_f64(icikt_multi *m, const double *X, int64_t n_feat, int64_t n_samp, int64_t ld,
                           const int32_t *pi, const int32_t *pj, int64_t n_pairs, int perspective,
                           int alternative, int continuity, uint32_t flags, double *out4, int64_t *counts,
@@ -278,9 +289,8 @@ int icikt_selftest(icikt_ctx *ctx);
  * the pair kernel's launch plan and of the host path's H2D mode on this context; NULL or "" restores the library's
  * choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g: open-group bitset in LDS | global memory), wpb (waves
  * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), gridmult / gridcap (persistent grid
- * of the long-column kernel: a multiple of the resident workgroups / at most this many), h2d (register | stage: how
- * a host matrix of 256 KB or more is read), regfail (0 | 1: behave as if page-locking the caller's memory were refused),
- * verbose (0 | 1: print the chosen plan to stderr). */
+ * of the long-column kernel: a multiple of the resident workgroups / at most this many), pipe (0 | 1: the host entries'
+ * chunk pipeline), verbose (0 | 1: print the chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
 /* Development hook: per step kind of the pair kernel (hot loop, hot step in the main loop, MIXED, GROUP, general,
  * closed-form tail, set-up) the steps taken, their rows and the wave cycles spent, as out24 = [steps x 8 | rows x 8 |

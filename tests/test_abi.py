@@ -24,7 +24,7 @@ def test_header_functions_are_exported():
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/icikt.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert L.icikt_version() == 300
+    assert L.icikt_version() == 400
 
 
 def test_constants_match_header():
@@ -64,3 +64,22 @@ def test_product_package_does_not_import_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".c", ".R")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in text.lower() or fn == "api.py" and "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_library_never_page_locks_or_probes_caller_memory():
+    """By construction: the library's sources call neither hipHostRegister / hipHostUnregister (a
+    per-call registration of caller heap ranges was the common factor of the two GPU memory-access faults of rounds 2
+    and 3) nor hipPointerGetAttributes (probing pageable pointers floods the runtime's error log).  Comments may name
+    them; code may not."""
+    csrc = os.path.join(ROOT, "icikendalltau_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        code = []
+        for ln in open(os.path.join(csrc, fn), errors="ignore"):
+            code.append(ln.split("//", 1)[0])
+        text = re.sub(r"/\*.*?\*/", "", "".join(code), flags=re.S)
+        for sym in ("hipHostRegister", "hipHostUnregister", "hipPointerGetAttributes", "hipHostGetDevicePointer"):
+            assert sym not in text, f"{fn} calls {sym}"
+    from icikendalltau_amd import _lib
+    assert _lib.FLAG_HOST_PINNED == 8
+    src = open(os.path.join(ROOT, "include", "icikt.h")).read()
+    assert re.search(r"#define\s+ICIKT_FLAG_HOST_PINNED\s+8u", src)

@@ -26,16 +26,30 @@ def _torchrun(script_args, env_extra, timeout):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+def _bench_as_typed(args, env_extra, timeout):
+    """`python bench.py --gpus N ...` as the driver types it for N = 1: no torch.distributed.run on the command line, no
+    WORLD_SIZE in the environment -- bench.py starts its ranks itself (bench.spawn_ranks) and relays their line."""
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
 @pytest.mark.timeout(900)
 def test_bench_sequence_two_ranks_gloo(tmp_path):
-    res = _torchrun(["bench.py", "--gpus", "2", "--config", "c3", "--steps", "2", "--warmup", "1"],
-                    {"ICIKT_BENCH_BACKEND": "gloo"}, 840)
+    res = _bench_as_typed(["--gpus", "2", "--config", "c3", "--steps", "2", "--warmup", "1"], {"ICIKT_BENCH_BACKEND": "gloo"}, 840)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # ONE JSON line on stdout, whatever the ranks printed
+    line = json.loads(lines[0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_gloo2_c3.json"), "w") as f:
         json.dump(line, f)
     assert line["n_gpus"] == 2 and line["config"]["pre_pass"] == "sharded+allgather"
+    assert line["launched_by"]["child_rc"] == 0 and "--nproc-per-node 2" in line["launched_by"]["cmd"]
+    assert line["backend"] == "gloo" and line["rccl_ranks"] is None
+    assert set(line["rank_phase_ms"]) == {"k0", "exchange", "k1", "gather"}
+    assert all(v["max"] >= v["min"] >= 0 for v in line["rank_phase_ms"].values()) and line["rank_phase_ms"]["k1"]["min"] > 0
     assert line["check"]["ok"] and line["check"]["assembled_pairs"] == 32640 and line["check"]["nan_rows"] == 0
     assert line["check"]["max_abs_diff"] <= 1e-10
 
@@ -44,17 +58,13 @@ def test_bench_sequence_two_ranks_gloo(tmp_path):
 def test_bench_sequence_one_rank_rccl(tmp_path):
     """The same sequence over the real nccl (= RCCL) backend with a process group of ONE rank: zero-copy torch views of
     the library's device arrays go through all_gather_into_tensor and gather on the GPU (the two-rank rehearsal
-    above moves them through host memory)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICIKT_BENCH_FORCE_DIST="1")
-    env.pop("RANK", None)
-    env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1", "--config", "c3", "--steps", "2",
-           "--warmup", "1"]
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    above moves them through host memory).  Self-launched too: `python bench.py --gpus 1` with ICIKT_BENCH_FORCE_DIST=1."""
+    res = _bench_as_typed(["--gpus", "1", "--config", "c3", "--steps", "2", "--warmup", "1"], {"ICIKT_BENCH_FORCE_DIST": "1"}, 840)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["pre_pass"] == "sharded+allgather"
+    assert line["backend"] == "nccl" and line["rccl_ranks"] == 1
+    assert line["launched_by"]["child_rc"] == 0
     assert line["check"]["ok"] and line["check"]["assembled_pairs"] == 32640 and line["check"]["nan_rows"] == 0
     assert line["check"]["max_abs_diff"] <= 1e-10
 

@@ -2,7 +2,7 @@
 applied inside the pre-pass, the pair kernels, and scale_and_reshape (R/kendalltau.R:357-421) on the device, against
  (a) the host assembly of the same pair results (api.ici_kendalltau's pair-list path: bit for bit), and
  (b) the whole front-end run on the oracle engine (1e-10, the north_star tolerance).
-Also: the transfers when page-locking the caller's memory is refused (the library's own pinned buffers), and the
+Also: the staged transfers (the library's own pinned buffers) and caller-pinned memory (ICIKT_FLAG_HOST_PINNED), and the
 per-rank figures of the multi-device driver."""
 import warnings
 
@@ -82,6 +82,32 @@ def test_matrix_entry_equals_host_assembly_and_oracle(hip_ctx, kw):
     _same(fast, host, exact=True)
     _same(fast, orac, exact=False)
     assert fast["run_time"] > 0
+
+
+@pytest.mark.parametrize("n_vals", [7, 32, 33, 50])
+def test_matrix_entry_many_global_na_values(hip_ctx, n_vals):
+    """The reference loops over ANY number of global_na values (R/utils.R:16-20).  The device rule of icikt_matrix_f64
+    holds _lib.MASK_VALS = 32 distinct finite ones (round 3: six, and a seventh made ici_kendalltau() raise); a longer
+    list is masked by the front-end (setup_missing_matrix) and takes the pair-list route.  Both equal the oracle
+    front-end, and the C entry refuses the 33rd value with ICIKT_E_INVALID instead of ignoring it."""
+    from icikendalltau_amd import _lib, api
+    from tests.oracle_engine import OracleEngine
+    rng = np.random.default_rng(n_vals)
+    n, S = 900, 8
+    X = np.asfortranarray(rng.integers(0, 80, size=(n, S)).astype(float))
+    X[rng.random((n, S)) < 0.02] = np.nan
+    gna = [float("nan"), float("inf")] + [float(v) for v in range(n_vals)] + [3.0, 3.0]     # duplicates do not count
+    names = [f"s{i}" for i in range(S)]
+    fast = api.ici_kendalltau(X, global_na=gna, colnames=names, engine=api.HipEngine())
+    orac = api.ici_kendalltau(X, global_na=gna, colnames=names, engine=OracleEngine())
+    _same(fast, orac, exact=False)
+    assert np.array_equal(np.asarray(fast["keep"]).T, ~(np.isnan(X) | (X < n_vals)))
+    if n_vals > _lib.MASK_VALS:
+        with pytest.raises(_lib.IciktError, match="more than 32 distinct finite values"):
+            hip_ctx.matrix(X, gna)
+    else:
+        out5, keep, _rc = hip_ctx.matrix(X, gna)
+        assert np.array_equal(out5[1], np.asarray(fast["raw"]), equal_nan=True)
 
 
 def test_matrix_entry_degenerate_columns_and_warnings(hip_ctx):
@@ -175,54 +201,85 @@ def test_matrix_multi_equals_single(hip_ctx, devices):
         m.close()
 
 
-def test_transfers_when_page_locking_is_refused(plan_ctx):
-    """icikt_debug_set_plan("regfail=1") makes the library behave as if every hipHostRegister were refused: the
-    matrix (21 MB), the pair and task lists and the result arrays then go through the library's own pinned buffers
-    (staging double buffer, bounce chunks, a pinned allocation per result array) -- never an asynchronous copy from
-    or into pageable memory.  Same bytes out as on the default path; both host entries and the multi-device one."""
+def test_transfers_staged_and_caller_pinned(plan_ctx):
+    """The library never page-locks caller memory (no hipHostRegister in it since round 4): the matrix (21 MB), the pair
+    and task lists and the result arrays cross its own pinned buffers (staging double buffer, bounce pieces, one pinned
+    buffer per result array).  A caller that HAS page-locked its matrix and result arrays says so with
+    ICIKT_FLAG_HOST_PINNED and they are copied from / into directly: hipHostMalloc memory (torch's pinned allocator) and
+    a numpy array the caller registered itself (and can still unregister afterwards).  Same bytes on every route; both
+    host entries and the multi-device one."""
+    import ctypes
     from icikendalltau_amd import _lib
+    L = _lib.lib()
     rng = np.random.default_rng(5)
     n, S = 9000, 300
     X = np.asfortranarray(rng.standard_normal((n, S)))
     X[rng.random((n, S)) < 0.05] = np.nan
-    plan_ctx.debug_set_plan(None)
+    plan_ctx.debug_set_plan({"pipe": 0})
     ref = plan_ctx.pairs(X, perspective="global")
     ref5 = plan_ctx.matrix(X, (float("nan"),))
-    plan_ctx.debug_set_plan({"regfail": 1})
+    plan_ctx.debug_set_plan(None)
     got = plan_ctx.pairs(X, perspective="global")
     got5 = plan_ctx.matrix(X, (float("nan"),))
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref5, got5))
-    plan_ctx.debug_set_plan({"h2d": "stage"})
-    got = plan_ctx.pairs(X, perspective="global")
-    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
-    # a caller that has page-locked its matrix itself: the library finds the range pinned, copies straight from it and
-    # leaves the caller's registration alone (the caller's own unregister must still succeed afterwards)
+    # (1) everything in hipHostMalloc memory
+    Xp = _lib.pinned_empty((n, S), order="F")
+    Xp[...] = X
+    assert Xp.flags.f_contiguous
+    for plan in ({"pipe": 0}, {"pipe": 1}):
+        plan_ctx.debug_set_plan(plan)
+        got = plan_ctx.pairs(Xp, perspective="global", flags=_lib.FLAG_HOST_PINNED)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got)), plan
+    out5 = _lib.pinned_empty((5, S, S))
+    keep = _lib.pinned_empty((S, n), dtype=np.uint8)
+    rc5 = np.zeros(5, dtype=np.int64)
+    gna = np.array([np.nan])
+    rc = L.icikt_matrix_f64(plan_ctx._h, Xp.ctypes.data, n, S, n, gna.ctypes.data, 1, None, None, 0, 1, 0, 0,
+                            _lib.FLAG_HOST_PINNED, 1, 1, out5.ctypes.data, keep.ctypes.data, rc5.ctypes.data)
+    assert rc == 0, L.icikt_last_error(plan_ctx._h)
+    assert np.array_equal(out5, ref5[0], equal_nan=True) and np.array_equal(keep.view(np.bool_), ref5[1])
+    # (2) a matrix the caller registered itself; results staged (no flag: the library does not look at the memory)
     import torch
     cudart = torch.cuda.cudart()
     plan_ctx.debug_set_plan(None)
     assert int(cudart.cudaHostRegister(X.ctypes.data, X.nbytes, 0)) == 0
     try:
         got = plan_ctx.pairs(X, perspective="global")
+        P = S * (S - 1) // 2
+        out = _lib.pinned_empty((P, 4))
+        rsn = _lib.pinned_empty(P, dtype=np.int32)
+        rc = L.icikt_pairs_f64(plan_ctx._h, X.ctypes.data, n, S, n, None, None, 0, 1, 0, 0, _lib.FLAG_HOST_PINNED,
+                               out.ctypes.data, None, rsn.ctypes.data)
+        assert rc == 0, L.icikt_last_error(plan_ctx._h)
     finally:
         rc_unreg = int(cudart.cudaHostUnregister(X.ctypes.data))
     assert rc_unreg == 0
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    assert np.array_equal(out, ref[0], equal_nan=True) and np.array_equal(rsn, ref[2])
+    # (3) the single-pair entry copies its two vectors itself: the flag must not reach that copy
+    o1, c1, r1 = plan_ctx.pair(X[:, 0], X[:, 1], "global", flags=_lib.FLAG_HOST_PINNED)
+    assert np.array_equal(o1, ref[0][0], equal_nan=True)
     m = _lib.MultiContext([0, 0])
     try:
-        m.debug_set_plan({"regfail": 1})
         got = m.pairs(X, perspective="global")
         assert m.ranks_used == 2
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+        got = m.pairs(Xp, perspective="global", flags=_lib.FLAG_HOST_PINNED)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
     finally:
         m.close()
+    with pytest.raises(_lib.IciktError, match="unknown key"):
+        plan_ctx.debug_set_plan("h2d=register")      # removed with the mode (DESIGN.md section 6)
+    with pytest.raises(_lib.IciktError, match="unknown key"):
+        plan_ctx.debug_set_plan("regfail=1")
 
 
 def test_pipelined_host_path(plan_ctx):
     """The host entries pipeline a matrix of several 8 MB chunks: the pre-pass of a chunk runs as it arrives and the pair
     kernel is launched once per chunk, over the tasks whose last column lies in it (icikt::host::upload_prepare_pairs).
     Same bytes out as the one-launch path: all pairs, an unsorted explicit list with both orientations and self pairs,
-    the matrix entry, with the staged and the bounced transfers, and on long columns (persistent pair kernel)."""
+    the matrix entry, and on long columns (persistent pair kernel)."""
     rng = np.random.default_rng(12)
     n, S = 9000, 300                                     # three chunks of 116 columns
     X = np.asfortranarray(rng.standard_normal((n, S)))
@@ -236,7 +293,7 @@ def test_pipelined_host_path(plan_ctx):
     ref_all = plan_ctx.pairs(X, perspective="global")
     ref_lst = plan_ctx.pairs(X, qi, qj, "local")
     ref_mat = plan_ctx.matrix(X, (float("nan"),))
-    for plan in ({"pipe": 1}, {"pipe": 1, "h2d": "stage"}, {"pipe": 1, "regfail": 1}, {"pipe": 1, "np": 1}):
+    for plan in ({"pipe": 1}, {"pipe": 1, "np": 1}):
         plan_ctx.debug_set_plan(plan)
         got = plan_ctx.pairs(X, perspective="global")
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref_all, got)), plan

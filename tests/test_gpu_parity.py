@@ -616,35 +616,33 @@ def test_joint_tie_counting_modes(plan_ctx, tgmax):
         _check(hip_ctx, X, perspective=p)
 
 
-@pytest.mark.parametrize("mode", ["register", "stage", ""])
+@pytest.mark.parametrize("mode", ["staged", "pinned"])
 def test_host_upload_modes(plan_ctx, mode):
-    """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; the two ways of
-    reading the caller's pageable matrix (and the library's default) give the same results, also with a leading
-    dimension larger than n_feat and for a matrix of several chunks.  (There is no mode that hands pageable memory of
-    this size to a copy: tests/test_gpu_matrix.py::test_transfers_when_page_locking_is_refused.)"""
-    import ctypes
+    """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; staged through the library's
+    pinned buffers (default) or, with ICIKT_FLAG_HOST_PINNED, straight out of memory the caller has page-locked -- the
+    same results, also with a leading dimension larger than n_feat and for a matrix of several chunks.  (There is no
+    mode that hands pageable memory of this size to a copy, and none that page-locks it:
+    tests/test_gpu_matrix.py::test_transfers_staged_and_caller_pinned.)"""
     from icikendalltau_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(5)
     n, S, ld = 9000, 300, 9016                       # 300 columns x 70 KB: three 8 MB chunks
-    buf = np.full((S, ld), 7.0)                      # row-major (S, ld) == column-major ld x S
+    alloc = _lib.pinned_empty if mode == "pinned" else np.empty
+    buf = alloc((S, ld))                             # row-major (S, ld) == column-major ld x S
+    buf[...] = 7.0
     buf[:, :n] = rng.standard_normal((S, n))
     buf[:, :n][rng.random((S, n)) < 0.05] = np.nan
     X = np.asfortranarray(buf[:, :n].T)              # compact copy for the reference run
     plan_ctx.debug_set_plan(None)
     ref = plan_ctx.pairs(X, perspective="global", want_counts=False)
-    plan_ctx.debug_set_plan({"h2d": mode})
     P = S * (S - 1) // 2
-    out = np.empty((P, 4))
-    rsn = np.zeros(P, np.int32)
-    rc = L.icikt_pairs_f64(plan_ctx._h, buf.ctypes.data, n, S, ld, None, None, 0, 1, 0, 0, 0, out.ctypes.data, None,
-                           rsn.ctypes.data)
+    out = alloc((P, 4))
+    rsn = alloc(P, dtype=np.int32)
+    rsn[...] = 0
+    rc = L.icikt_pairs_f64(plan_ctx._h, buf.ctypes.data, n, S, ld, None, None, 0, 1, 0, 0,
+                           _lib.FLAG_HOST_PINNED if mode == "pinned" else 0, out.ctypes.data, None, rsn.ctypes.data)
     assert rc == 0, L.icikt_last_error(plan_ctx._h)
     assert np.array_equal(out, ref[0]) and np.array_equal(rsn, ref[2])
-    with pytest.raises(_lib.IciktError, match="h2d"):
-        plan_ctx.debug_set_plan("h2d=bogus")
-    with pytest.raises(_lib.IciktError, match="h2d"):
-        plan_ctx.debug_set_plan("h2d=plain")     # removed: it was an asynchronous copy from pageable memory
     with pytest.raises(_lib.IciktError, match="unknown key"):
         plan_ctx.debug_set_plan("nope=1")
 

@@ -164,6 +164,41 @@ def test_scaling_skips_na_pairs_wherever_they_sit():
     assert np.array_equal(cor[ok], raw[ok] / best) and np.all(np.isnan(cor[~ok]))
 
 
+def test_all_pairs_degenerate_scales_by_minus_inf():
+    """max(taumax, na.rm = TRUE) over no value at all is -Inf in R (max(numeric(0)), R/kendalltau.R:368-373), so
+    cor = raw / -Inf: NA pairs stay NA.  The device assembly (k_assemble) does the same; the host assembly used NaN."""
+    X = np.tile(np.array([1.0, 2.0, 3.0])[None, :], (20, 1))       # every column constant: every pair is NA
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = api.ici_kendalltau(X, global_na=[np.nan], colnames=_names(3), return_matrix=False, engine=ENG)["cor"]
+    assert np.all(np.isnan(r["cor"].to_numpy()[:3])) and np.all(r["cor"].to_numpy()[3:] == 1.0)
+
+
+def test_many_global_na_values_take_the_host_masking_route():
+    """The reference loops over ANY number of global_na values (R/utils.R:16-20).  The device-side rule of the one-call
+    matrix entry holds _lib.MASK_VALS distinct finite ones; a longer list must not fail: the front-end masks the matrix
+    itself (setup_missing_matrix) and runs the pair-list route.  `_Matrixless` has a `matrix` method that must not be
+    reached with the long list."""
+    from icikendalltau_amd import _lib
+    rng = np.random.default_rng(21)
+    X = rng.integers(0, 60, size=(80, 5)).astype(float)
+    gna = [float("nan")] + [float(v) for v in range(40)]           # 40 distinct finite values
+
+    class _Matrixless(type(ENG)):
+        def matrix(self, *a, **k):
+            raise AssertionError("the device rule cannot hold this list")
+
+    eng = _Matrixless()
+    assert len(gna) - 1 > _lib.MASK_VALS
+    r = api.ici_kendalltau(X, global_na=gna, colnames=_names(5), engine=eng)
+    Xm = X.copy()
+    Xm[X < 40] = np.nan
+    ref = api.ici_kendalltau(Xm, global_na=[np.nan], colnames=_names(5), engine=ENG)
+    for k in ("cor", "raw", "pvalue", "taumax", "completeness"):
+        assert np.array_equal(r[k].to_numpy(), ref[k].to_numpy(), equal_nan=True), k
+    assert np.array_equal(r["keep"], ref["keep"])
+
+
 def test_setup_comparisons_order_and_cores():
     pi, pj, core = api.setup_comparisons(_names(5), ncore=3)
     assert list(zip(pi, pj))[:5] == [(0, 1), (0, 2), (0, 3), (0, 4), (1, 2)]  # utils::combn order
@@ -251,3 +286,30 @@ def test_ici_kt_report_output(capsys):
     with pytest.warns(RuntimeWarning):
         api.ici_kt(x, np.ones(10), "global", output="full", engine=OracleEngine())
     assert capsys.readouterr().out == ""
+
+
+def test_bench_self_launch_command_line():
+    """`python bench.py --gpus N` as typed (no WORLD_SIZE): the parent starts torch.distributed.run with one rank per GPU
+    of one node, rendezvous on 127.0.0.1, and hands its own arguments on -- and does so without importing torch."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.child_command(["--gpus", "8", "--steps", "3", "--warmup", "1"], 8, 29611)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:10] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29611"]
+    assert cmd[10].endswith("bench.py") and cmd[11:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert bench.should_spawn(8, "torchrun", {}) and bench.should_spawn(2, "torchrun", {"RANK": ""})
+    assert not bench.should_spawn(1, "torchrun", {})                       # N = 1: this process IS the run
+    assert not bench.should_spawn(8, "torchrun", {"WORLD_SIZE": "8"})      # already a rank (the driver's own launch)
+    assert not bench.should_spawn(8, "inlib", {})                          # one process drives all GPUs
+    assert bench.should_spawn(1, "torchrun", {"ICIKT_BENCH_FORCE_DIST": "1"})
+    p = bench.free_port()
+    assert 1024 < p < 65536
+    # importing bench (what the parent has done when it spawns) must not have loaded torch
+    code = "import sys, bench; assert 'torch' not in sys.modules, 'bench imported torch at module level'"
+    r = subprocess.run([sys.executable, "-c", code], cwd=bench.ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # and a parent whose child fails relays the failure: a command that cannot start ranks (no such GPU count is checked
+    # by torchrun itself; here the child is made to fail at once through an invalid argument)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "nope"], cwd=bench.ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid choice" in r.stderr

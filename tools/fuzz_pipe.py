@@ -2,8 +2,8 @@
 random leading dimension, random tie structures and missingness per column, all pairs or an unsorted pair list with both
 orientations and self pairs, through icikt_pairs_f64 / icikt_matrix_f64
   (a) in one piece (plan key pipe=0: one copy, one pre-pass, one pair-kernel launch) and
-  (b) pipelined by chunks (pipe=1) with a random transfer mode (staged / registered / refused registration) and a
-      random pairs-per-wave override;
+  (b) pipelined by chunks (pipe=1), staged through the library's pinned buffers or -- matrix and result arrays in
+      hipHostMalloc memory, ICIKT_FLAG_HOST_PINNED -- copied directly, with a random pairs-per-wave override;
 the two must give the same bytes (results, counts, reasons; the five matrices and `keep`).  The one-piece path is what
 tools/fuzz_gpu.py checks against the oracle.
 
@@ -23,26 +23,34 @@ import fuzz_gpu
 from icikendalltau_amd import _lib
 
 
-def call_pairs(ctx, buf, n, S, ld, pi, pj, persp, want_counts):
+def call_pairs(ctx, buf, n, S, ld, pi, pj, persp, want_counts, pinned=False):
     L = _lib.lib()
     P = S * (S - 1) // 2 if pi is None else len(pi)
-    out = np.empty((P, 4))
-    cnt = np.zeros((P, len(_lib.CNT_FIELDS)), dtype=np.int64) if want_counts else None
-    rsn = np.zeros(P, dtype=np.int32)
+    alloc = _lib.pinned_empty if pinned else np.empty
+    out = alloc((P, 4))
+    cnt = alloc((P, len(_lib.CNT_FIELDS)), dtype=np.int64) if want_counts else None
+    rsn = alloc(P, dtype=np.int32)
+    if cnt is not None:
+        cnt[...] = 0
+    rsn[...] = 0
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-    rc = L.icikt_pairs_f64(ctx._h, p(buf), n, S, ld, p(pi), p(pj), P, persp, 0, 0, 0, p(out), p(cnt), p(rsn))
+    rc = L.icikt_pairs_f64(ctx._h, p(buf), n, S, ld, p(pi), p(pj), P, persp, 0, 0, _lib.FLAG_HOST_PINNED if pinned else 0,
+                           p(out), p(cnt), p(rsn))
     assert rc == 0, (rc, ctx.last_error() if hasattr(ctx, "last_error") else "")
     return out, cnt, rsn
 
 
-def call_matrix(ctx, buf, n, S, ld, gna, pi, pj, persp, scale_max, diag_good):
+def call_matrix(ctx, buf, n, S, ld, gna, pi, pj, persp, scale_max, diag_good, pinned=False):
     L = _lib.lib()
     P = 0 if pi is None else len(pi)
-    out5 = np.empty((5, S, S))
-    keep = np.zeros((S, n), dtype=np.uint8)
+    alloc = _lib.pinned_empty if pinned else np.empty
+    out5 = alloc((5, S, S))
+    keep = alloc((S, n), dtype=np.uint8)
+    keep[...] = 0
     rc5 = np.zeros(5, dtype=np.int64)
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-    rc = L.icikt_matrix_f64(ctx._h, p(buf), n, S, ld, p(gna), len(gna), p(pi), p(pj), P, persp, 0, 0, 0, int(scale_max),
+    rc = L.icikt_matrix_f64(ctx._h, p(buf), n, S, ld, p(gna), len(gna), p(pi), p(pj), P, persp, 0, 0,
+                            _lib.FLAG_HOST_PINNED if pinned else 0, int(scale_max),
                             int(diag_good), p(out5), p(keep), p(rc5))
     assert rc == 0, rc
     return out5, keep, rc5
@@ -70,20 +78,24 @@ def one_case(ctx, rng, case):
         pi = rng.integers(0, S, m).astype(np.int32)
         pj = rng.integers(0, S, m).astype(np.int32)
     what = "matrix" if rng.random() < 0.3 else "pairs"
-    plan = {"pipe": 1, "h2d": str(rng.choice(["", "stage", "register"])), "np": str(rng.choice(["", "1", "2"]))}
-    if rng.random() < 0.15:
-        plan["regfail"] = 1
+    plan = {"pipe": 1, "np": str(rng.choice(["", "1", "2"]))}
+    pinned = bool(rng.random() < 0.35)
     plan = {k: v for k, v in plan.items() if v != ""}
-    desc = f"case {case}: n={n} S={S} ld={ld} {what} persp={persp} list={None if pi is None else len(pi)} plan={plan}"
+    desc = f"case {case}: n={n} S={S} ld={ld} {what} persp={persp} list={None if pi is None else len(pi)} plan={plan} pinned={pinned}"
     gna = np.array([np.nan, np.inf, 0.0])
     sm, dg = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
     res = []
-    for pl in ({"pipe": 0}, plan):
+    pbuf = None
+    if pinned:
+        pbuf = _lib.pinned_empty(buf.shape)
+        pbuf[...] = buf
+    for pl, pin in (({"pipe": 0}, False), (plan, pinned)):
         ctx.debug_set_plan(pl)
+        src = pbuf if pin else buf
         if what == "pairs":
-            res.append(call_pairs(ctx, buf, n, S, ld, pi, pj, persp, want_counts=True))
+            res.append(call_pairs(ctx, src, n, S, ld, pi, pj, persp, want_counts=True, pinned=pin))
         else:
-            res.append(call_matrix(ctx, buf, n, S, ld, gna, pi, pj, persp, sm, dg))
+            res.append(call_matrix(ctx, src, n, S, ld, gna, pi, pj, persp, sm, dg, pinned=pin))
     ctx.debug_set_plan(None)
     for a, b in zip(*res):
         if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):

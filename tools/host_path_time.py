@@ -1,4 +1,4 @@
-"""PCIe-inclusive timing of the host-buffer entries (development aid): icikt_pairs_f64 with each H2D mode, and
+"""PCIe-inclusive timing of the host-buffer entries (development aid): icikt_pairs_f64 staged (default) and from caller-pinned memory (ICIKT_FLAG_HOST_PINNED), and
 icikt_pairs_multi_f64 on the devices given (default: one rank over RCCL, then two ranks on device 0 with copies)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,15 +12,17 @@ X = make_matrix(n, S, na, seed)
 P = S * (S - 1) // 2
 ctx = _lib.Context(0)
 ref = None
-for mode in ("register", "stage", ""):
-    ctx.debug_set_plan({"h2d": mode})
+Xp = _lib.pinned_empty(X.shape, order="F")
+Xp[...] = X
+for mode in ("staged", "pinned"):
     ts = []
     for _ in range(4):
         t0 = time.perf_counter()
-        out, _c, rsn = ctx.pairs(X, perspective="global", want_counts=False)
+        out, _c, rsn = ctx.pairs(Xp if mode == "pinned" else X, perspective="global", want_counts=False,
+                                 flags=_lib.FLAG_HOST_PINNED if mode == "pinned" else 0)
         ts.append(time.perf_counter() - t0)
     if ref is None: ref = out
-    print(f"{cfg} icikt_pairs_f64 h2d={mode or 'default':8s} best {min(ts)*1e3:7.2f} ms  -> {P/min(ts):.3e} pairs/s (PCIe-inclusive)"
+    print(f"{cfg} icikt_pairs_f64 {mode:8s} best {min(ts)*1e3:7.2f} ms  -> {P/min(ts):.3e} pairs/s (PCIe-inclusive)"
           f"  {'same' if np.array_equal(out, ref) else 'DIFF'}", flush=True)
 for devices, ex in (([0], "rccl"), ([0, 0], "copy"), ([0, 0, 0, 0], "copy")):
     m = _lib.MultiContext(devices, exchange=ex)

@@ -163,8 +163,9 @@ def test_matrix_c_abi_contract(hip_ctx):
     assert L.icikt_matrix_f64(*args(out=None)) == -1
     assert L.icikt_matrix_f64(*args(ld=49)) == -1
     assert L.icikt_matrix_f64(*args(persp=7)) == -1
-    many = np.arange(1.0, 9.0)
-    assert L.icikt_matrix_f64(*args(gna=many.ctypes.data, ngna=8)) == -1 and b"global_na" in L.icikt_last_error(hip_ctx._h)
+    many = np.arange(1.0, 35.0)                          # 34 distinct finite values: one more than the device rule holds
+    assert L.icikt_matrix_f64(*args(gna=many.ctypes.data, ngna=32)) == 0
+    assert L.icikt_matrix_f64(*args(gna=many.ctypes.data, ngna=34)) == -1 and b"global_na" in L.icikt_last_error(hip_ctx._h)
     assert L.icikt_matrix_f64(*args(gna=None, ngna=0)) == 0
 
 

@@ -138,6 +138,9 @@ __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/
 // K0: per-column pre-pass
 // ------------------------------------------------------------------------------------------------
 constexpr int K0_THREADS = 1024;
+#ifndef ICIKT_K0_MIN_WAVES
+#define ICIKT_K0_MIN_WAVES 4   // waves per SIMD the pre-pass is compiled for: 4 = one 1 024-thread workgroup per CU (<= 128 VGPRs)
+#endif
 constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB)
 
 __device__ __forceinline__ unsigned long long sortable_key(double v) {
@@ -147,21 +150,16 @@ __device__ __forceinline__ unsigned long long sortable_key(double v) {
   return (b < 0) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// block-wide reductions through LDS scratch (K0_THREADS entries)
+// Block-wide reductions: inside a wave by shuffles, across the waves through one small LDS table -- one or two workgroup
+// barriers per BATCH of values.  (Rounds 1-3 ran a 1 024-entry LDS tree per value: 12 barriers each, 14 values per
+// column: 170 of a column's ~450 barriers, in a kernel whose time IS its barriers.)
+constexpr int K0_WAVES = K0_THREADS / 64;
 template <typename T, typename Op>
-__device__ T block_reduce(T v, T* scratch, Op op) {
-  const int tid = threadIdx.x;
-  scratch[tid] = v;
-  __syncthreads();
-  for (int s = K0_THREADS / 2; s > 0; s >>= 1) {
-    if (tid < s) scratch[tid] = op(scratch[tid], scratch[tid + s]);
-    __syncthreads();
-  }
-  T r = scratch[0];
-  __syncthreads();
-  return r;
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+  return v;
 }
-
 // value of lane ^ J for J = 1, 2, 4, 8, 16, 32 without LDS: quad_perm for 1 and 2, row_shl / row_shr 4 with a
 // select, row_ror:8 (inside a 16-lane row rotating by 8 IS xor 8), v_permlane16_swap / v_permlane32_swap of two
 // copies for 16 and 32.  Every DPP runs with all lanes active; the selects come afterwards.
@@ -188,10 +186,18 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
 // 1 and 2 stay inside the thread, distances 4..128 pair it with lane t ^ (j / 4) of its own wave (DPP and
 // permlane exchanges: no LDS, no barrier); only distances >= 256 need the LDS tile and a workgroup barrier.  Of the 78
 // stages of a tile sort 68 run this way.
+// FAST: the element is ONE word, top 48 bits of the sortable key | row (16 bits) -- unique, so a single 64-bit compare
+// orders it and no index travels beside it: five vector instructions per element of a lane stage instead of nine, two
+// registers instead of three, 8 bytes per element through the LDS tile and the scratch instead of 12.  Exact whenever no
+// two values of the column differ ONLY in the low 16 bits of their keys (relative difference below 2^-36): k0_prepare
+// checks the result against the full keys and repeats the column with the three-word elements if it finds an inversion.
+template <bool FAST>
 __device__ __forceinline__ bool kv_gt(unsigned long long ka, uint32_t ia, unsigned long long kb, uint32_t ib) {
+  if constexpr (FAST) return ka > kb;
   return (ka > kb) || (ka == kb && ia > ib);
 }
 // stages j = jmax .. 1 (jmax <= 128) of merge step k; gi = global index of the thread's first element
+template <bool FAST>
 __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint32_t (&ei)[4], int k, int jmax,
                                               int gi, int tid) {
   const uint32_t lane = (uint32_t)tid & 63u;
@@ -202,16 +208,16 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
     const bool want_gt = (((tid & (LX)) == 0) == up48); /* take the partner's when (mine > theirs) == want_gt */ \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
       const uint32_t klo = lane_xor<(LX)>((uint32_t)ek[r], lane), khi = lane_xor<(LX)>((uint32_t)(ek[r] >> 32), lane); \
-      const uint32_t oi = lane_xor<(LX)>(ei[r], lane);                                                   \
+      const uint32_t oi = FAST ? 0u : lane_xor<(LX)>(ei[r], lane);                                       \
       const unsigned long long ok = (unsigned long long)klo | ((unsigned long long)khi << 32);           \
-      if (kv_gt(ek[r], ei[r], ok, oi) == want_gt) { ek[r] = ok; ei[r] = oi; }                            \
+      if (kv_gt<FAST>(ek[r], ei[r], ok, oi) == want_gt) { ek[r] = ok; ei[r] = oi; }                      \
     }                                                                                                    \
   }
   ICIKT_K0_XSTAGE(32) ICIKT_K0_XSTAGE(16) ICIKT_K0_XSTAGE(8) ICIKT_K0_XSTAGE(4) ICIKT_K0_XSTAGE(2) ICIKT_K0_XSTAGE(1)
 #undef ICIKT_K0_XSTAGE
 #define ICIKT_CE(a, b, upv)                                                          \
   {                                                                                  \
-    if (kv_gt(ek[a], ei[a], ek[b], ei[b]) == (upv)) {                                \
+    if (kv_gt<FAST>(ek[a], ei[a], ek[b], ei[b]) == (upv)) {                          \
       const unsigned long long tk = ek[a]; ek[a] = ek[b]; ek[b] = tk;                \
       const uint32_t ti = ei[a]; ei[a] = ei[b]; ei[b] = ti;                          \
     }                                                                                \
@@ -225,6 +231,54 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
     ICIKT_CE(0, 1, up0) ICIKT_CE(2, 3, up2)
   }
 #undef ICIKT_CE
+}
+
+// Compare-exchange stages on an array (the LDS tile, or the column's global scratch), TWO stages per pass and barrier: a
+// thread loads the four elements i0, i0 + j/2, i0 + j, i0 + 3j/2, runs stage j (pairs at distance j) and stage j/2 in
+// registers and stores them back -- half the barriers and half the traffic of one stage per pass.  Stages jmax .. jmin
+// (powers of two) of merge step k over `count` elements; dbase = what is added to an index to find its direction bit.
+template <bool FAST, typename KP, typename IP>
+__device__ __forceinline__ void k0_mem_stages(KP tk, IP ti, int count, int dbase, int k, int jmax, int jmin, int tid) {
+  int j = jmax;
+  while (j >= 2 * jmin) {
+    const int jh = j >> 1;
+    for (int t = tid; t < (count >> 2); t += K0_THREADS) {
+      const int i0 = ((t & ~(jh - 1)) << 2) | (t & (jh - 1));
+      const bool up = ((dbase + i0) & k) == 0;      // the same for the four: bits j/2 and j of i0 are clear, j + j/2 < k
+      unsigned long long ek[4];
+      uint32_t ei[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ek[r] = tk[i0 + r * jh]; ei[r] = FAST ? 0u : ti[i0 + r * jh]; }
+#define ICIKT_CE4(a, b)                                                              \
+      if (kv_gt<FAST>(ek[a], ei[a], ek[b], ei[b]) == up) {                           \
+        const unsigned long long xk = ek[a]; ek[a] = ek[b]; ek[b] = xk;              \
+        const uint32_t xi = ei[a]; ei[a] = ei[b]; ei[b] = xi;                        \
+      }
+      ICIKT_CE4(0, 2) ICIKT_CE4(1, 3) ICIKT_CE4(0, 1) ICIKT_CE4(2, 3)
+#undef ICIKT_CE4
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tk[i0 + r * jh] = ek[r];
+        if (!FAST) ti[i0 + r * jh] = ei[r];
+      }
+    }
+    __syncthreads();
+    j >>= 2;
+  }
+  if (j >= jmin) {   // an odd number of stages: the last one alone
+    for (int t = tid; t < (count >> 1); t += K0_THREADS) {
+      const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      const int l = i | j;
+      const bool up = ((dbase + i) & k) == 0;
+      const unsigned long long ka = tk[i], kb = tk[l];
+      const uint32_t ia = FAST ? 0u : ti[i], ib = FAST ? 0u : ti[l];
+      if (kv_gt<FAST>(ka, ia, kb, ib) == up) {
+        tk[i] = kb; tk[l] = ka;
+        if (!FAST) { ti[i] = ib; ti[l] = ia; }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ---- the tie program of a column (PrepView::tprog, tmask) ---------------------------------------------------------
@@ -391,7 +445,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
 // WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
 // memory (they outgrow the static LDS), no tie-group list and no rec staging.
 template <bool WIDE>
-__global__ void __launch_bounds__(K0_THREADS)
+__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
 k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms,
            uint8_t* __restrict__ keep) {
   __shared__ long long sh_ll[K0_THREADS];
@@ -446,23 +500,29 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     nna += isna ? 1 : 0;
   }
   if (tid == 0) { mask[W] = 0ull; }
-  // plain double min (no NaN among candidates)
+  // plain double min (no NaN among candidates), the missing and the excluded rows: one batch, two barriers
   {
+    tmin = wave_reduce(tmin, [](double a, double b) { return (b < a) ? b : a; });
+    nna = wave_reduce(nna, [](int a, int b) { return a + b; });
+    nexcl = wave_reduce(nexcl, [](int a, int b) { return a + b; });
     double* sh_d = reinterpret_cast<double*>(sh_st_lds);   // (the start-flag bitset of phase 3 lives here later)
-    sh_d[tid] = tmin;
+    if (lane == 0) { sh_d[tid >> 6] = tmin; sh_i[tid >> 6] = nna; sh_i[K0_WAVES + (tid >> 6)] = nexcl; }
     __syncthreads();
-    for (int s = K0_THREADS / 2; s > 0; s >>= 1) {
-      if (tid < s) { double a = sh_d[tid], b = sh_d[tid + s]; sh_d[tid] = (b < a) ? b : a; }
-      __syncthreads();
+    tmin = sh_d[0]; nna = sh_i[0]; nexcl = sh_i[K0_WAVES];
+#pragma unroll
+    for (int w = 1; w < K0_WAVES; ++w) {
+      const double b = sh_d[w];
+      tmin = (b < tmin) ? b : tmin;
+      nna += sh_i[w];
+      nexcl += sh_i[K0_WAVES + w];
     }
-    tmin = sh_d[0];
     __syncthreads();
   }
-  nna = block_reduce<int>(nna, sh_i, [](int a, int b) { return a + b; });
-  nexcl = block_reduce<int>(nexcl, sh_i, [](int a, int b) { return a + b; });
   const double fill = tmin - 0.1;  // kendallc.cpp:214-215, double arithmetic
 
-  // ---- phase 1b: sortable keys ------------------------------------------------------------------
+  // ---- phases 1b + 2: sortable keys, sort.  FAST: one word per element (top 48 key bits | row), see kv_gt ------
+  auto sort_pass = [&](auto fast_tag) {
+  constexpr bool FAST = decltype(fast_tag)::value;
   for (int i = tid; i < npow2; i += K0_THREADS) {
     unsigned long long k = ~0ull;
     uint32_t id = 0xFFFFFFFFu;
@@ -470,10 +530,11 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
       double v = col[i];
       if (v != v || mask_excluded(ms, v)) v = fill;
       k = sortable_key(v);
+      if (FAST) k = (k & ~0xFFFFull) | (unsigned long long)i;    // (n <= 65 535: the row fits the low 16 bits)
       id = (uint32_t)i;
     }
     keys[i] = k;
-    idx[i] = id;
+    if (!FAST) idx[i] = id;
   }
   __syncthreads();
 
@@ -493,74 +554,44 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
         if (tb >= n) continue;  // a tile of padding only (equal keys) is sorted in either direction already
         const int gi = tb + 4 * tid;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ek[r] = keys[gi + r]; ei[r] = idx[gi + r]; }
-        for (int k = 2; k <= 256; k <<= 1) k0_reg_stages(ek, ei, k, k >> 1, gi, tid);
+        for (int r = 0; r < 4; ++r) { ek[r] = keys[gi + r]; ei[r] = FAST ? 0u : idx[gi + r]; }
+        for (int k = 2; k <= 256; k <<= 1) k0_reg_stages<FAST>(ek, ei, k, k >> 1, gi, tid);
         for (int k = 512; k <= T; k <<= 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = ek[r]; sh_ti[4 * tid + r] = ei[r]; }
+          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = ek[r]; if (!FAST) sh_ti[4 * tid + r] = ei[r]; }
           __syncthreads();
-          for (int j = k >> 1; j >= 256; j >>= 1) {
-            for (int t = tid; t < (T >> 1); t += K0_THREADS) {
-              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const int l = i | j;
-              const bool up = (((tb + i) & k) == 0);
-              const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
-              const uint32_t ia = sh_ti[i], ib = sh_ti[l];
-              if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
-            }
-            __syncthreads();
-          }
+          k0_mem_stages<FAST>(sh_tk, sh_ti, T, tb, k, k >> 1, 256, tid);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = sh_ti[4 * tid + r]; }
+          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = FAST ? 0u : sh_ti[4 * tid + r]; }
           __syncthreads();  // the tile is rewritten by the next step's stores
-          k0_reg_stages(ek, ei, k, 128, gi, tid);
+          k0_reg_stages<FAST>(ek, ei, k, 128, gi, tid);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; idx[gi + r] = ei[r]; }
+        for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
       }
       __syncthreads();
       // merges across tiles: distances >= T in global memory, 2048..256 on the LDS tile, the rest in registers
       for (int k = 2 * T; k <= npow2; k <<= 1) {
-        for (int j = k >> 1; j >= T; j >>= 1) {
-          for (int t = tid; t < (npow2 >> 1); t += K0_THREADS) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const int l = i | j;
-            const bool up = ((i & k) == 0);
-            const unsigned long long ka = keys[i], kb = keys[l];
-            const uint32_t ia = idx[i], ib = idx[l];
-            if (kv_gt(ka, ia, kb, ib) == up) { keys[i] = kb; keys[l] = ka; idx[i] = ib; idx[l] = ia; }
-          }
-          __syncthreads();
-        }
+        k0_mem_stages<FAST>(keys, idx, npow2, 0, k, k >> 1, T, tid);   // (global scratch: __syncthreads orders a workgroup's global accesses)
         for (int tile = 0; tile < ntiles; ++tile) {
           const int tb = tile * T;
           const int gi = tb + 4 * tid;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = keys[gi + r]; sh_ti[4 * tid + r] = idx[gi + r]; }
+          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = keys[gi + r]; if (!FAST) sh_ti[4 * tid + r] = idx[gi + r]; }
           __syncthreads();
-          const bool up = ((tb & k) == 0);  // constant inside a tile because k > T
-          for (int j = T >> 1; j >= 256; j >>= 1) {
-            for (int t = tid; t < (T >> 1); t += K0_THREADS) {
-              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const int l = i | j;
-              const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
-              const uint32_t ia = sh_ti[i], ib = sh_ti[l];
-              if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
-            }
-            __syncthreads();
-          }
+          k0_mem_stages<FAST>(sh_tk, sh_ti, T, tb, k, T >> 1, 256, tid);   // (the direction is constant inside a tile: k > T)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = sh_ti[4 * tid + r]; }
+          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = FAST ? 0u : sh_ti[4 * tid + r]; }
           __syncthreads();
-          k0_reg_stages(ek, ei, k, 128, gi, tid);
+          k0_reg_stages<FAST>(ek, ei, k, 128, gi, tid);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; idx[gi + r] = ei[r]; }
+          for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
         }
         __syncthreads();
       }
     } else {
       // short columns (npow2 < 4096): one partial tile, every stage on LDS
-      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[i]; sh_ti[i] = idx[i]; }
+      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[i]; if (!FAST) sh_ti[i] = idx[i]; }
       __syncthreads();
       for (int k = 2; k <= T; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -569,15 +600,39 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
             const int l = i | j;
             const bool up = ((i & k) == 0);
             const unsigned long long ka = sh_tk[i], kb = sh_tk[l];
-            const uint32_t ia = sh_ti[i], ib = sh_ti[l];
-            if (kv_gt(ka, ia, kb, ib) == up) { sh_tk[i] = kb; sh_tk[l] = ka; sh_ti[i] = ib; sh_ti[l] = ia; }
+            const uint32_t ia = FAST ? 0u : sh_ti[i], ib = FAST ? 0u : sh_ti[l];
+            if (kv_gt<FAST>(ka, ia, kb, ib) == up) {
+              sh_tk[i] = kb; sh_tk[l] = ka;
+              if (!FAST) { sh_ti[i] = ib; sh_ti[l] = ia; }
+            }
           }
           __syncthreads();
         }
       }
-      for (int i = tid; i < T; i += K0_THREADS) { keys[i] = sh_tk[i]; idx[i] = sh_ti[i]; }
+      for (int i = tid; i < T; i += K0_THREADS) { keys[i] = sh_tk[i]; if (!FAST) idx[i] = sh_ti[i]; }
       __syncthreads();
     }
+  }
+  };   // sort_pass
+  if constexpr (WIDE) {
+    sort_pass(std::false_type{});
+  } else {
+    // One-word elements first.  Then the words become what phase 3 reads -- the FULL key and the row of every position
+    // (one gather of the column per position) -- and the order is checked against the full keys: an inversion means two
+    // values of the column share the top 48 bits of their keys and differ below them; the column is then sorted again
+    // with three-word elements (full key, row).  Equal full keys are in row order either way: the row is part of the word.
+    sort_pass(std::true_type{});
+    for (int k = tid; k < n; k += K0_THREADS) {
+      const uint32_t row = (uint32_t)keys[k] & 0xFFFFu;
+      double v = col[row];
+      if (v != v || mask_excluded(ms, v)) v = fill;
+      keys[k] = sortable_key(v);
+      idx[k] = row;
+    }
+    __syncthreads();
+    int inv = 0;
+    for (int k = tid + 1; k < n; k += K0_THREADS) inv |= (keys[k - 1] > keys[k]) ? 1 : 0;
+    if (__syncthreads_or(inv)) sort_pass(std::false_type{});
   }
 
   // ---- phase 3: tie groups in ascending order -----------------------------------------------------
@@ -711,17 +766,13 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   if (!WIDE) {
     const int nw = (n + 63) >> 6;                  // <= 1024 words, one per thread
     const int cnt = (tid < nw) ? (int)__popcll(sh_big[tid]) : 0;
-    sh_i[tid] = cnt;
+    const int incl = (int)wave_incl_scan((uint32_t)cnt);           // inside the wave; the waves' totals through LDS
+    if (lane == 63) sh_i[tid >> 6] = incl;
     __syncthreads();
-    for (int sft = 1; sft < K0_THREADS; sft <<= 1) {
-      const int v = sh_i[tid];
-      const int o = (tid >= sft) ? sh_i[tid - sft] : 0;
-      __syncthreads();
-      sh_i[tid] = v + o;
-      __syncthreads();
-    }
+    int wbase = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wbase += sh_i[w];
     if (tid < nw) {
-      int off = sh_i[tid] - cnt;
+      int off = wbase + incl - cnt;
       unsigned long long m = sh_big[tid];
       while (m != 0ull) {
         const int k = (tid << 6) + (int)__builtin_ctzll(m);
@@ -731,17 +782,38 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     }
     __syncthreads();
   }
-  const int ntg = block_reduce<int>(ntg_local, sh_i, [](int a, int b) { return a + b; });
-  ngroups = block_reduce<int>(ngroups, sh_i, [](int a, int b) { return a + b; });
-  maxgroup = block_reduce<int>(maxgroup, sh_i, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; });
-  tfill = block_reduce<int>(tfill, sh_i, [](int a, int b) { return a > b ? a : b; });
-  oddtie = block_reduce<int>(oddtie, sh_i, [](int a, int b) { return a | b; });
-  s0 = (uint32_t)block_reduce<int>((int)s0, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
-  s1 = (uint32_t)block_reduce<int>((int)s1, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
-  s2 = (uint32_t)block_reduce<int>((int)s2, sh_i, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
-  e0 = block_reduce<long long>(e0, sh_ll, [](long long a, long long b) { return a + b; });
-  e1 = block_reduce<long long>(e1, sh_ll, [](long long a, long long b) { return a + b; });
-  e2 = block_reduce<long long>(e2, sh_ll, [](long long a, long long b) { return a + b; });
+  // the column's statistics: every value reduced inside its wave, the waves' results combined by thread 0 -- one barrier
+  const auto add_i = [](int a, int b) { return a + b; };
+  const auto add_u = [](uint32_t a, uint32_t b) { return a + b; };
+  const auto add_l = [](long long a, long long b) { return a + b; };
+  const int ntg_w = wave_reduce(ntg_local, add_i);
+  ngroups = wave_reduce(ngroups, add_i);
+  maxgroup = (int)wave_reduce((uint32_t)maxgroup, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+  tfill = wave_reduce(tfill, [](int a, int b) { return a > b ? a : b; });
+  oddtie = wave_reduce(oddtie, [](int a, int b) { return a | b; });
+  s0 = wave_reduce(s0, add_u); s1 = wave_reduce(s1, add_u); s2 = wave_reduce(s2, add_u);
+  e0 = wave_reduce(e0, add_l); e1 = wave_reduce(e1, add_l); e2 = wave_reduce(e2, add_l);
+  __syncthreads();   // (sh_i / sh_ll: the list offsets above and the big-group bitset are done with)
+  if (lane == 0) {
+    int* wi = sh_i + (tid >> 6) * 8;
+    wi[0] = ntg_w; wi[1] = ngroups; wi[2] = maxgroup; wi[3] = tfill; wi[4] = oddtie; wi[5] = (int)s0; wi[6] = (int)s1; wi[7] = (int)s2;
+    long long* wl = sh_ll + (tid >> 6) * 3;
+    wl[0] = e0; wl[1] = e1; wl[2] = e2;
+  }
+  __syncthreads();
+  int ntg = 0;
+  if (tid == 0) {
+    ngroups = 0; maxgroup = 0; tfill = 0; oddtie = 0; s0 = s1 = s2 = 0u; e0 = e1 = e2 = 0;
+    for (int w = 0; w < K0_WAVES; ++w) {
+      const int* wi = sh_i + w * 8;
+      ntg += wi[0]; ngroups += wi[1];
+      maxgroup = ((uint32_t)wi[2] > (uint32_t)maxgroup) ? wi[2] : maxgroup;
+      tfill = max(tfill, wi[3]); oddtie |= wi[4];
+      s0 += (uint32_t)wi[5]; s1 += (uint32_t)wi[6]; s2 += (uint32_t)wi[7];
+      const long long* wl = sh_ll + w * 3;
+      e0 += wl[0]; e1 += wl[1]; e2 += wl[2];
+    }
+  }
 
   if (tid == 0) {
     ColStats st;

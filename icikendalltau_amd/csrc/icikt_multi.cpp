@@ -74,6 +74,7 @@ struct icikt_multi {
   std::vector<int> devices;
   std::vector<icikt_ctx*> ctx;
   bool rccl = false;
+  bool rccl_asked = false;                            // exchange = RCCL was asked for by name (a one-rank handle then runs the whole flow)
   std::vector<ncclComm_t> comms;
   std::string err;
   double phase_ms[ICIKT_MULTI_PHASES] = {};          // of the last call: maximum over the ranks
@@ -384,6 +385,7 @@ int icikt_multi_create(const int* devices, int n_gpu, int exchange, icikt_multi*
     return ICIKT_E_INVALID;
   }
   m->rccl = (exchange == ICIKT_MULTI_EXCHANGE_RCCL) || (exchange == ICIKT_MULTI_EXCHANGE_AUTO && distinct);
+  m->rccl_asked = exchange == ICIKT_MULTI_EXCHANGE_RCCL;
   for (int r = 0; r < n_gpu; ++r) {
     icikt_ctx* c = nullptr;
     const int rc = icikt_ctx_create(m->devices[(size_t)r], &c);
@@ -480,11 +482,14 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   }
   const int G = m->n;
   // Too little work to split (fewer than two columns per rank, or a handful of pairs): rank 0's single-device
-  // path, which also owns every argument check.  (One device with enough work runs the full flow below: the
-  // collectives of a one-rank communicator are copies.)
+  // path, which also owns every argument check.  A handle of ONE device takes it too -- it is the pipelined host path
+  // (matrix chunks, pre-pass and pair kernel overlapped: icikt_pairs_f64), so the N = 1 point of an in-library scaling
+  // curve IS the single-device figure (round 3: 14.4 against 12.2 ms on c4, the rank flow uploads, then sorts, then
+  // counts) -- unless RCCL was asked for by name: then the whole rank flow runs on the one-rank communicator (tests).
   // Wide columns (n_feat > ICIKT_MAX_FEATURES) run on rank 0 alone as well: the ranks exchange the 16-bit prepared
   // state of the tuned kernels, which wide columns do not have.
-  if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0 || n_feat > ICIKT_MAX_FEATURES) {
+  if (n_samp < 2 * (int64_t)G || n_pairs < 64 * (int64_t)G || n_feat == 0 || n_feat > ICIKT_MAX_FEATURES ||
+      (G == 1 && !m->rccl_asked)) {
     icikt_ctx* c = m->ctx[0];
     const double t0 = now_ms();
     const int rc = mx ? icikt_matrix_f64(c, X, n_feat, n_samp, ld, mx->global_na, mx->n_global_na, pi, pj, n_pairs, perspective,

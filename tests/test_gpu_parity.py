@@ -51,6 +51,28 @@ def test_random_with_na(hip_ctx, n, perspective):
     _check(hip_ctx, X, perspective=perspective)
 
 
+@pytest.mark.parametrize("n", [700, 5000, 12000, 40000])
+def test_values_that_differ_only_in_their_low_bits(hip_ctx, n):
+    """The pre-pass sorts one-word elements first -- the top 48 bits of a value's sortable key | its row -- and repeats a
+    column with (full key, row) elements when the full keys show an inversion (icikt_kernels.hip: kv_gt, k0_prepare).
+    Columns whose values share their top 48 key bits and differ below them (relative differences under 2^-36) must take
+    that second pass: distinct low bits in random order, with ties among them, beside ordinary columns, negative values
+    (keys complemented), +-0 and missing values; and the boundary case where only SOME neighbours collide."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 8))
+    ulp = 2.0 ** -52
+    k = rng.permutation(n) % 60000
+    X[:, 0] = 1.0 + k * ulp                                   # all top-48 prefixes equal: any order but the rows' is an inversion
+    X[:, 1] = -(3.0 + (rng.integers(0, 5000, n) * 4) * ulp)    # negative, with ties: 5 000 distinct values below the 48 bits
+    X[:, 2] = np.where(rng.random(n) < 0.5, X[:, 2], 7.0 + rng.integers(0, 3, n) * ulp * 8)   # half ordinary, half three close values
+    X[:, 3] = np.round(X[:, 3], 2) + rng.integers(0, 2, n) * 2.0 ** -45                     # pairs of near-equal values around each level
+    X[:, 4] = np.where(rng.random(n) < 0.3, 0.0, rng.integers(-2, 3, n) * 2.0 ** -1070)      # zeros and subnormals: prefixes all equal
+    X[rng.random(X.shape) < 0.05] = np.nan
+    X[::97, 4] = -0.0
+    for p in ("global", "local"):
+        _check(hip_ctx, X, perspective=p)
+
+
 @pytest.mark.parametrize("levels", [2, 3, 7, 50])
 @pytest.mark.parametrize("perspective", ["global", "local"])
 def test_heavy_ties(hip_ctx, levels, perspective):

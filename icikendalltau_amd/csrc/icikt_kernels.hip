@@ -359,22 +359,27 @@ __device__ __forceinline__ uint32_t k0_step_at(const unsigned long long* gf, int
 }
 
 // the same-group flag masks of the rows of the MIXED step that starts at pos (entry e): one lane per row
-__device__ __forceinline__ void k0_step_masks(const unsigned long long* gf, const uint32_t* crossT, int n, int W, int pos,
-                                              uint32_t e, uint2* tmask, uint32_t lane) {
+// (returns the class of the step's largest group, wave-uniform: half_step_flags_near)
+__device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, const uint32_t* crossT, int n, int W, int pos,
+                                                  uint32_t e, uint2* tmask, uint32_t lane) {
   const uint32_t b0 = tprog_n0(e), b1 = tprog_rows(e) - b0;
   const uint32_t sb = lane >> 5, l = lane & 31u;
-  if (l >= (sb ? b1 : b0)) return;
+  const bool vrow = l < (sb ? b1 : b0);          // (every lane of the wave stays: the step's largest group is a wave maximum)
   const int wc = pos >> 6, fb = pos & 63;
   const unsigned long long w0 = gf[min(wc, W)], w1 = gf[min(wc + 1, W)];
   unsigned long long Fe = fb ? ((w0 >> fb) | (w1 << (64 - fb))) : w0;
   const int remaining = n - pos;
   if (remaining < 64) Fe = (Fe & ((1ull << remaining) - 1ull)) | (1ull << remaining);
-  const uint32_t o = sb ? b0 + l : l;                                             // offset of the row in the window (< 64)
+  const uint32_t o = min(sb ? b0 + l : l, 63u);                                   // offset of the row in the window (< 64)
   const unsigned long long upto = Fe & ((o < 63u) ? ((2ull << o) - 1ull) : ~0ull);
-  const uint32_t idx = o - (63u - (uint32_t)__builtin_clzll(upto));               // bit 0 is set: the step starts a group
+  const uint32_t idx = o - (63u - (uint32_t)__builtin_clzll(upto | 1ull));        // bit 0 is set: the step starts a group
   const unsigned long long above = (o < 63u) ? (Fe >> (o + 1u)) : 0ull;
   const uint32_t nxt = (above != 0ull) ? (o + 1u + (uint32_t)__builtin_ctzll(above)) : 64u;   // (offset 64: the step ends there)
   const uint32_t fwd = nxt - 1u - o;
+  // class of the step's largest group: which distances of the pair kernel's second flag chain can hold a pair of one group
+  const int gmax = __builtin_amdgcn_readfirstlane(wave_max_i32(vrow ? (int)(idx + fwd + 1u) : 0));
+  const uint32_t cls = (gmax <= 3) ? 0u : (gmax <= 5) ? 1u : (gmax <= 9) ? 2u : 3u;
+  if (!vrow) return cls;
   const uint32_t p = l & 15u;
   const uint32_t c = min(min(idx, p), 15u);                                       // in-row partners inside my group
   const uint32_t a1 = (1u << ((c + 1u) >> 1)) - 1u, b1m = (1u << (c >> 1)) - 1u;   // vector 1: a / b slots
@@ -384,6 +389,7 @@ __device__ __forceinline__ void k0_step_masks(const unsigned long long* gf, cons
   m.x = ((b1m | (t & 0x80u)) << sh) | (a1 << (16u + sh));
   m.y = ((t & 0x70u) << sh) | (((t >> 8) & 0x70u) << (16u + sh)) | ((t & 0x10000u) ? (0x8000u << (16u * sb)) : 0u);
   tmask[(uint32_t)pos + o] = m;
+  return cls;
 }
 
 // The whole workgroup builds the program, a WINDOW of TPROG_WIN positions at a time: (A) every position's would-be step,
@@ -393,7 +399,7 @@ __device__ __forceinline__ void k0_step_masks(const unsigned long long* gf, cons
 // scratch: E (TPROG_WIN u16) | list of MIXED step positions (TPROG_LIST u16: a MIXED step of complete groups that does
 // not reach 33 rows is followed by a longer group, so a window starts at most TPROG_WIN / 17 of them) | crossT (32 x 64
 // u32); `cnt`: three shared ints (MIXED steps of the window; the chain's position and entry count between windows).
-constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;
+constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;   // (list: TPROG_LIST pairs of u16 -- window offset, entry index)
 __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
                                       int n, int W, uint32_t* prog, uint2* tmask, int tid, int nthreads) {
   const uint32_t lane = (uint32_t)tid & 63u;
@@ -421,7 +427,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
         const uint32_t e = (uint32_t)E[pos - win];
         if (lane == 0u) {
           prog[ne] = e;
-          if (tprog_kind(e) == TPROG_KIND_MIXED) mlist[nm] = (uint16_t)(pos - win);
+          if (tprog_kind(e) == TPROG_KIND_MIXED) { mlist[2 * nm] = (uint16_t)(pos - win); mlist[2 * nm + 1] = (uint16_t)ne; }
         }
         nm += (tprog_kind(e) == TPROG_KIND_MIXED) ? 1 : 0;
         ++ne;
@@ -435,8 +441,11 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     __syncthreads();
     const int nm = cnt[0];
     for (int i = wave; i < nm; i += nwaves) {
-      const int pos = win + (int)mlist[i];
-      k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos - win], tmask, lane);
+      const int pos = win + (int)mlist[2 * i];
+      const uint32_t cls = k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos - win], tmask, lane);
+      // the class of the step's largest group rides in the step's entry (bits 16..17), which the pair kernel holds two
+      // steps ahead; the entry was written by wave 0 before the barrier above
+      if (lane == 0u && cls != 0u) prog[mlist[2 * i + 1]] |= cls << 16;
     }
     __syncthreads();   // (E and the list are rewritten by the next window)
   }
@@ -851,7 +860,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
   __shared__ uint32_t kx_cross[32 * 64];   // k0_tie_program's scratch: cross table, would-be steps, MIXED step list
   __shared__ uint16_t kx_E[TPROG_WIN];
-  __shared__ uint16_t kx_list[TPROG_LIST];
+  __shared__ uint16_t kx_list[2 * TPROG_LIST];
   __shared__ int kx_cnt[3];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
@@ -1157,6 +1166,54 @@ __device__ __forceinline__ void half_step_flags(uint32_t src, uint32_t own, uint
                : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
 }
 
+// The same flags for the NEAR distances only (round 4).  A MIXED step runs the chain twice: [q_earlier < lo_later] at
+// every distance -- rows of different groups are discordant or not wherever they sit in the sub-step -- and the other
+// direction, [q_later < lo_earlier], which only tells JOINT TIES apart and is looked at under the same-group masks
+// alone: pairs at most (largest group of the step) - 1 lanes apart.  The pre-pass knows that size and passes its class
+// with the masks (k0_step_masks): C = 0: groups of <= 3 rows (distances 1, 2), 1: <= 5 (1 .. 4), 2: <= 9 (1 .. 8; between
+// the rows of a half every rotation can hold a pair up to 8 lanes apart).  The flags land where half_step_flags puts
+// them (the remaining shifts of the chain in one), so the masks apply unchanged; the flags of the distances left out are 0
+// and no mask bit of such a step sits there.  10 / 22 / 39 instructions instead of 58.
+template <int C>
+__device__ __forceinline__ void half_step_flags_near(uint32_t src, uint32_t own, uint32_t offer, uint32_t partner_addr,
+                                                     uint32_t& v1, uint32_t& v2) {
+  const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)partner_addr, (int)offer);
+  const uint32_t M8 = 0x80808080u, SEL = 0x07050301u, M16 = 0x80008000u;
+  uint32_t t1, t2;
+#define ICIKT_NEAR_HEAD "s_nop 1\n\t"                                                                          \
+               "v_add_u32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+               "v_add_u32_dpp %2, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+  if constexpr (C == 0) {
+    asm volatile(ICIKT_NEAR_HEAD "v_lshrrev_b32_e32 %0, 7, %0\n\t"
+                 : "=&v"(v1), "=&v"(t1), "=&v"(t2) : "v"(src), "v"(own), "s"(M8), "s"(SEL));
+  } else if constexpr (C == 1) {
+    asm volatile(ICIKT_NEAR_HEAD ICIKT_PSHR2(3, 4) "v_lshrrev_b32_e32 %0, 6, %0\n\t"
+                 : "=&v"(v1), "=&v"(t1), "=&v"(t2) : "v"(src), "v"(own), "s"(M8), "s"(SEL));
+  } else {
+    asm volatile(ICIKT_NEAR_HEAD ICIKT_PSHR2(3, 4) ICIKT_PSHR2(5, 6) ICIKT_PSHR2(7, 8) "v_lshrrev_b32_e32 %0, 4, %0\n\t"
+                 : "=&v"(v1), "=&v"(t1), "=&v"(t2) : "v"(src), "v"(own), "s"(M8), "s"(SEL));
+  }
+#undef ICIKT_NEAR_HEAD
+#define ICIKT_NEAR_HEAD2 "s_nop 1\n\t"                                                                         \
+               "v_add_u32_dpp %1, %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                             \
+               "v_add_u32_dpp %2, %3, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"                             \
+               "v_perm_b32 %1, %1, %2, %6\n\tv_and_b32_e32 %0, %5, %1\n\t"
+  if constexpr (C == 0) {
+    asm volatile(ICIKT_NEAR_HEAD2 "v_lshrrev_b32_e32 %0, 3, %0\n\t"
+                 : "=&v"(v2), "=&v"(t1), "=&v"(t2) : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
+  } else if constexpr (C == 1) {
+    asm volatile(ICIKT_NEAR_HEAD2 ICIKT_PROR2(3, 4) "v_lshrrev_b32_e32 %0, 2, %0\n\t"
+                 : "=&v"(v2), "=&v"(t1), "=&v"(t2) : "v"(xa), "v"(offer), "s"(M8), "s"(SEL));
+  } else {
+    asm volatile(ICIKT_NEAR_HEAD2 ICIKT_PROR2(3, 4) ICIKT_PROR2(5, 6)
+                 "v_add_u32_dpp %1, %3, %4 row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_lshrrev_b32_e32 %0, 1, %0\n\tv_and_or_b32 %0, %1, %7, %0\n\t"
+                 : "=&v"(v2), "=&v"(t1), "=&v"(t2) : "v"(xa), "v"(offer), "s"(M8), "s"(SEL), "s"(M16));
+  }
+#undef ICIKT_NEAR_HEAD2
+}
+
 // ---- one pair on the whole wave: all-pairs of a 64-row step ----------------------------------------
 // Same construction as the half-wave step, for four DPP rows: 15 in-row compares (row_shr) and, for the six
 // row pairs, three rounds in which every row has one partner row (1: 0-1 2-3, 2: 0-2 1-3, 3: 0-3 1-2) and both
@@ -1393,7 +1450,14 @@ __device__ __forceinline__ uint32_t half_pre_index(uint32_t w) {
 template <int HI>
 __device__ __forceinline__ uint32_t prefix_query_half(const unsigned long long* bits, const uint16_t* pre, uint32_t pos) {
   const uint32_t w = pos >> 6;
-  return (uint32_t)pre[half_pre_index<HI>(w)] - (uint32_t)__popcll(bits[w] >> (pos & 63u));
+  // the entry's BYTE address, as the hot step computes it: slot w / HI at 2 * slot-size bytes, entry w % HI at 2 ->
+  // 2 w + (2 slot - 2 HI) (w / HI), with w / HI = (w * (65536 / HI + 1)) >> 16 -- exact for w < 32 HI, HI <= 15 (the
+  // generic form, a division by a constant and a remainder, cost four vector instructions more per query; a GROUP step
+  // in row mode makes eight to sixteen queries)
+  const uint32_t d = (w * (65536u / (uint32_t)HI + 1u)) >> 16;
+  const uint32_t e = (uint32_t)*reinterpret_cast<const uint16_t*>(
+      reinterpret_cast<const unsigned char*>(pre) + 2u * w + (2u * (uint32_t)k1_half_slot<HI>() - 2u * (uint32_t)HI) * d);
+  return e - (uint32_t)__popcll(bits[w] >> (pos & 63u));
 }
 // counts of the HI words a lane holds in registers -> the lane's slot; cw[i] = bits in words 0 .. i of the lane,
 // incl = the half's inclusive scan of cw[HI - 1]
@@ -1517,15 +1581,15 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
 #ifdef ICIKT_STEP_STATS
 __device__ unsigned long long g_step_stats[24];
 #define ICIKT_ST_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(); \
-  unsigned long long st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0, st_c4 = 0, st_c5 = 0, st_c6 = 0; \
-  unsigned st_s0 = 0, st_s1 = 0, st_s2 = 0, st_s3 = 0, st_s4 = 0, st_s5 = 0, st_s6 = 0; \
-  unsigned st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_r4 = 0, st_r5 = 0, st_r6 = 0;
+  unsigned long long st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0, st_c4 = 0, st_c5 = 0, st_c6 = 0, st_c7 = 0; \
+  unsigned st_s0 = 0, st_s1 = 0, st_s2 = 0, st_s3 = 0, st_s4 = 0, st_s5 = 0, st_s6 = 0, st_s7 = 0; \
+  unsigned st_r0 = 0, st_r1 = 0, st_r2 = 0, st_r3 = 0, st_r4 = 0, st_r5 = 0, st_r6 = 0, st_r7 = 0;
 #define ICIKT_ST_MARK(K, ROWS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_c##K += t_ - st_t; st_t = t_; \
   st_s##K += 1u; st_r##K += (unsigned)(ROWS); }
 #define ICIKT_ST_FLUSH1(K) { atomicAdd(&g_step_stats[K], (unsigned long long)st_s##K); atomicAdd(&g_step_stats[8 + K], (unsigned long long)st_r##K); \
   atomicAdd(&g_step_stats[16 + K], st_c##K); }
 #define ICIKT_ST_FLUSH if (lane == 0u) { ICIKT_ST_FLUSH1(0) ICIKT_ST_FLUSH1(1) ICIKT_ST_FLUSH1(2) ICIKT_ST_FLUSH1(3) ICIKT_ST_FLUSH1(4) \
-  ICIKT_ST_FLUSH1(5) ICIKT_ST_FLUSH1(6) }
+  ICIKT_ST_FLUSH1(5) ICIKT_ST_FLUSH1(6) ICIKT_ST_FLUSH1(7) }
 #else
 #define ICIKT_ST_DECL
 #define ICIKT_ST_MARK(K, ROWS)
@@ -1769,6 +1833,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // (wave_allpairs_packed2): inside the hot loop the step itself skips them
   bool defer_allpairs = false;
   uint32_t mix_sg1 = 0u, mix_sg2 = 0u;   // MIXED: the lane's same-group flag masks (both sub-steps); 0 in a plain hot step
+  int mix_cls = 3;                       // MIXED: class of the step's largest group (half_step_flags_near), wave-uniform
   auto hot_step = [&](const uint32_t (&rk)[NP], auto mixed_tag) {
     constexpr bool MIXED = decltype(mixed_tag)::value;
     if constexpr (half_mode) {
@@ -1814,7 +1879,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             const uint32_t A = 0x7FFF7FFFu - Q, B = LO;
             uint32_t f1, f2, g1, g2;
             half_step_flags(A, B, (lane & 16u) ? B : A, partner_addr, f1, f2);      // [q_earlier < lo_later]
-            half_step_flags(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);      // [q_later < lo_earlier]
+            // [q_later < lo_earlier]: looked at inside the groups only -- as far as the step's largest group reaches
+            if (mix_cls == 0) half_step_flags_near<0>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            else if (mix_cls == 1) half_step_flags_near<1>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            else if (mix_cls == 2) half_step_flags_near<2>(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
+            else half_step_flags(B, A, (lane & 16u) ? A : B, partner_addr, g1, g2);
             inpairs = bcnt_acc(f2 & ~mix_sg2, bcnt_acc(f1 & ~mix_sg1, 0u));         // pairs of different groups only
             seg_tie = bcnt_acc(mix_sg2 & ~(f2 | g2), bcnt_acc(mix_sg1 & ~(f1 | g1), seg_tie));   // joint ties inside the groups
           }
@@ -2113,6 +2182,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         const uint32_t o = (lane_t < 32u) ? lane_t : (uint32_t)n0 + lane_t - 32u;
         const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
         tmx = vrow ? tmask_col[(uint32_t)pos + o] : make_uint2(0u, 0u);
+        mix_cls = (int)((e >> 16) & 3u);   // class of the step's largest group (k0_step_masks), carried by the program entry
       }
     } else
     if (pos + 64 <= hot_until) {
@@ -2307,6 +2377,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           const uint32_t b1 = (rowmode && v1) ? Q(h1 + 1u) - c1 : 0u;
           seg_tie2 -= b0 + b1;
         }
+        ICIKT_ST_MARK(4, 0)   // (diagnostic build: a GROUP step up to the end of phase A)
         if (closes) {
           // the group's rows: this step's alone (kept = 0), this and the previous step's, which are still in
           // registers (kept = 1), or more: those are streamed again from the group's first position
@@ -2348,6 +2419,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           wave_lds_fence();
           rebuild_prefix_half<H>(seenH, spreH, l32);
           wave_lds_fence();
+          ICIKT_ST_MARK(7, 0)   // (diagnostic build: a closing GROUP step's list counts before, insertions and rebuild)
           // list mode: C(rows of the group in the listed tie group, 2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

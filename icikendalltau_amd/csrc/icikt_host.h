@@ -75,10 +75,12 @@ struct icikt_ctx {
   bool units_dirty = false;   // h_units has been rebuilt on the host and not uploaded yet
   // result copies of 256 KB or more cross a pinned buffer of the library's (one per array of a call, kept from call
   // to call) and are moved to the caller's array by finish_downloads()
-  struct Bounce { void* pinned; void* dst; size_t bytes; };
+  struct Bounce { void* pinned; void* dst; size_t bytes; hipEvent_t ev; };   // ev: recorded behind the piece's D2H copy (may be null)
   struct PinnedSlot { void* p = nullptr; size_t bytes = 0; };
   std::vector<PinnedSlot> out_pinned;   // result downloads: one pinned buffer per array of a call, kept from call to call
   std::vector<Bounce> bounced_out;
+  std::vector<hipEvent_t> ev_out;         // events of the result pieces in flight (a pool, reused from call to call)
+  size_t ev_out_used = 0;
 
   // host-path staging: a second stream for H2D copies that run ahead of K0 by column chunks
   hipStream_t copy_stream = nullptr;
@@ -196,6 +198,10 @@ void destroy_copy_pool(void* pool);
 int upload_sync(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 // after the stream that carries download() copies has been synchronised: deliver the bounced ones
 void finish_downloads(icikt_ctx* c, bool ok = true);
+// The end of a host entry: waits for the stream AND delivers the bounced results piece by piece as their copies
+// complete (a piece is moved to the caller's array while the next one still crosses PCIe).  ok: nothing failed so far;
+// returns the stream's status.  On an error the caller's arrays may hold part of the results: the call fails.
+hipError_t finish_stream(icikt_ctx* c, bool ok);
 // D2H of a result array into the caller's buffer on c->stream (not synchronised; finish_downloads afterwards)
 int download(icikt_ctx* c, void* dst, const void* src, size_t bytes);
 

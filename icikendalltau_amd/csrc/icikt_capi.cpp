@@ -580,7 +580,8 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
     const int64_t chunk = std::max(1, c->sort_chunk);
     for (int64_t c0 = col_begin; c0 < col_end; c0 += chunk) {
       const int nc = (int)std::min<int64_t>(chunk, col_end - c0);
-      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->k0_mask, c->k0_keep, stream));
+      const int small_shape = (c->k0_shape == 1 || (c->k0_shape < 0 && c->k0_small)) ? 1 : 0;
+      HIPCHK(c, icikt::launch_k0(pv, dX, ld, (int)c0, nc, c->k0_mask, c->k0_keep, small_shape, stream));
     }
   }
   return ICIKT_SUCCESS;
@@ -1005,6 +1006,13 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
       if (pipelined) {
         // the chunk's pre-pass on the pre-pass stream; an event of its own tells the pair kernel's stream when
         if (e == hipSuccess) e = hipStreamWaitEvent(c->prep_stream, ev, 0);
+        // (Every chunk's pre-pass runs the 1 024-thread shape.  A workgroup of it needs an EMPTY CU, so a later chunk's
+        //  pre-pass starts only when the pair-kernel launch in front of it drains -- round 3 put 0.5 ms of a c4 call down to
+        //  that.  Round 4 built the 256-thread shape (k0_prepare_small: fits beside a running pair kernel, plan key k0=1) and
+        //  measured it here: the pre-pass then does finish earlier, 3.9 against 6.4 ms into the call, but the call gets
+        //  LONGER, 11.76 against 11.61 ms staged, 11.24 against 11.13 pinned (profiles/r04_ab_pipe_k0.log) -- both kernels
+        //  are bound by vector issue, so overlapping them gains nothing, and the small shape takes 0.80 ms for the 1 024
+        //  columns where the large one takes 0.65.)
         if (e == hipSuccess) rc = chunk_prepass(c0, c0 + nc, c->prep_stream);
         if ((size_t)k >= c->ev_chunk.size()) {
           hipEvent_t ne = nullptr;
@@ -1112,6 +1120,9 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
       cb = ce;
       const size_t cnt = nt - first;
       if (cnt == 0) return ICIKT_SUCCESS;
+      // (the launches stay on ONE stream: alternating consecutive chunks' launches between two streams, so that one starts
+      //  while the other drains, was measured slower -- 12.3 against 11.6 ms on c4, round 4: two launches in flight share
+      //  the SIMDs and the cache with the small-shape pre-pass and each other)
       hipError_t e = hipMemcpyAsync(c->d_unit_start.p + 2 * first, u + 2 * first, cnt * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_chunk[q], 0);
       if (e != hipSuccess) return fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e));
@@ -1595,13 +1606,14 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 // path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
 // wpb (waves per workgroup), half (0 | 1), tgmax (list-mode limit; -1 = row mode), gridmult (persistent grid as a
 // multiple of the resident waves, always), gridcap (persistent grid: at most this many workgroups),
-// pipe (0 | 1: the host entries' chunk pipeline off / on whenever possible), verbose (0 | 1: print the plan to stderr).
+// pipe (0 | 1: the host entries' chunk pipeline off / on whenever possible), k0 (0 | 1: the pre-pass always in its
+// 1 024-thread / 256-thread shape), verbose (0 | 1: print the plan to stderr).
 // (The keys h2d and regfail of rounds 2-3 are gone with the mode they steered: the library no longer page-locks
 // caller memory, icikt_host.h.)
 int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
   if (!c) return ICIKT_E_INVALID;
   icikt_ctx::PlanOverride ov;
-  int pipe = -1;
+  int pipe = -1, k0 = -1;
   std::string sp = spec ? spec : "";
   size_t pos = 0;
   while (pos < sp.size()) {
@@ -1624,10 +1636,12 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());
     else if (key == "pipe") pipe = (val[0] == '1') ? 1 : 0;
+    else if (key == "k0") k0 = (val[0] == '1') ? 1 : 0;
     else return fail(c, ICIKT_E_INVALID, "debug_set_plan: unknown key '" + key + "'");
   }
   c->plan_ov = ov;
   c->pipe_mode = pipe;
+  c->k0_shape = k0;
 
   c->raw_valid = false;
   c->wpb = 0;  // tasks are rebuilt for the new plan

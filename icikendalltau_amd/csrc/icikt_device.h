@@ -146,8 +146,9 @@ __host__ __device__ inline int k1_lds_stride(int Wp, int half_items) {
 
 // ms: cells to exclude while reading dX (nullptr: NaN = missing, nothing else); keep: optional [n_samp][n] bytes,
 // 1 = not excluded (the reference's `keep = t(!exclude_loc)`, R/kendalltau.R:417)
+// small_shape: 256-thread workgroups (4 waves per column, same results) that fit a CU beside a running pair kernel
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, const MaskSpec* ms,
-                     uint8_t* keep, hipStream_t s);
+                     uint8_t* keep, int small_shape, hipStream_t s);
 // Full-matrix assembly (scale_and_reshape, R/kendalltau.R:357-421) on the device.
 //   launch_out_stats: red[0] = max(taumax) over the pairs, NaN skipped, as a sortable key (0 = none); red[1..5] =
 //     pairs per reason code; red[6] = max(n_good)

@@ -103,6 +103,8 @@ struct icikt_ctx {
   DevBuf<uint8_t> d_keep;
   DevBuf<unsigned long long> d_red;
   DevBuf<int32_t> d_pi_all, d_pj_all;     // icikt_matrix_multi_f64, explicit pair list: the whole list on the first device
+  bool k0_small = false;    // (no caller sets it: the 256-thread shape of the pre-pass is reached through the plan key only)
+  int k0_shape = -1;        // debug plan key "k0": -1 the library's choice (the large shape), 0 the large shape, 1 the small one
   const icikt::MaskSpec* k0_mask = nullptr;
   uint8_t* k0_keep = nullptr;
   DevBuf<int64_t> d_counts;

@@ -137,11 +137,21 @@ __device__ __forceinline__ unsigned long long low_mask64(uint32_t bits /*0..63*/
 // ------------------------------------------------------------------------------------------------
 // K0: per-column pre-pass
 // ------------------------------------------------------------------------------------------------
-constexpr int K0_THREADS = 1024;
+// Two shapes of the pre-pass kernel, the same code: 1 024 threads x 4 elements each (16 waves: the fastest way through
+// ONE column, and what the library runs everywhere), and 256 threads x 16 elements (4 waves, one per SIMD, 96 VGPRs: a
+// workgroup that fits a CU as soon as ONE workgroup of a running pair kernel retires, where the 1 024-thread shape needs
+// all four SIMDs' registers, i.e. an EMPTY CU).  The small shape was built in round 4 to let the later chunks of the
+// pipelined host path sort beside the pair kernel; measured, that overlap makes the call longer (both kernels are bound
+// by vector issue; icikt_capi.cpp, upload_and_prepare), so it is kept as an option of the debug plan (k0=1) and a test.
+constexpr int K0_THREADS = 1024;   // the large shape (and what the shared scratch arrays are sized for)
+constexpr int K0_THREADS_SMALL = 256;
 #ifndef ICIKT_K0_MIN_WAVES
 #define ICIKT_K0_MIN_WAVES 4   // waves per SIMD the pre-pass is compiled for: 4 = one 1 024-thread workgroup per CU (<= 128 VGPRs)
 #endif
-constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB)
+#ifndef ICIKT_K0_WAVES_SMALL
+#define ICIKT_K0_WAVES_SMALL 5    // the small shape is compiled for five waves per SIMD (<= 96 registers): a wave of it fits a SIMD on which ONE pair-kernel wave (80 of 512 registers, six resident) has retired
+#endif
+constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB) = threads x elements per thread, either shape
 
 __device__ __forceinline__ unsigned long long sortable_key(double v) {
   if (v == 0.0) v = 0.0;  // -0.0 and +0.0 tie (x[i] < x[j] is false both ways, kendallc.cpp:9,23)
@@ -152,8 +162,8 @@ __device__ __forceinline__ unsigned long long sortable_key(double v) {
 
 // Block-wide reductions: inside a wave by shuffles, across the waves through one small LDS table -- one or two workgroup
 // barriers per BATCH of values.  (Rounds 1-3 ran a 1 024-entry LDS tree per value: 12 barriers each, 14 values per
-// column: 170 of a column's ~450 barriers, in a kernel whose time IS its barriers.)
-constexpr int K0_WAVES = K0_THREADS / 64;
+// column: 170 of a column's ~450 barriers.  Removing them changed nothing: the pre-pass is bound by the vector
+// instructions of its sort network, see kv_gt.)
 template <typename T, typename Op>
 __device__ __forceinline__ T wave_reduce(T v, Op op) {
 #pragma unroll
@@ -182,10 +192,9 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
 }
 
 // ---- bitonic stages held in registers ---------------------------------------------------------------
-// With a full tile (4096 elements, 1024 threads) thread t owns elements 4t..4t+3: compare-exchange distances
-// 1 and 2 stay inside the thread, distances 4..128 pair it with lane t ^ (j / 4) of its own wave (DPP and
-// permlane exchanges: no LDS, no barrier); only distances >= 256 need the LDS tile and a workgroup barrier.  Of the 78
-// stages of a tile sort 68 run this way.
+// Thread t owns the E consecutive elements E t .. E t + E - 1 of the tile (E = 4 with 1 024 threads, 16 with 256):
+// compare-exchange distances below E stay inside the thread, distances E .. 32 E pair it with lane t ^ (j / E) of its own
+// wave (DPP and permlane exchanges: no LDS, no barrier); only distances >= 64 E need the LDS tile and a workgroup barrier.
 // FAST: the element is ONE word, top 48 bits of the sortable key | row (16 bits) -- unique, so a single 64-bit compare
 // orders it and no index travels beside it: five vector instructions per element of a lane stage instead of nine, two
 // registers instead of three, 8 bytes per element through the LDS tile and the scratch instead of 12.  Exact whenever no
@@ -196,17 +205,17 @@ __device__ __forceinline__ bool kv_gt(unsigned long long ka, uint32_t ia, unsign
   if constexpr (FAST) return ka > kb;
   return (ka > kb) || (ka == kb && ia > ib);
 }
-// stages j = jmax .. 1 (jmax <= 128) of merge step k; gi = global index of the thread's first element
-template <bool FAST>
-__device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint32_t (&ei)[4], int k, int jmax,
+// stages j = jmax .. 1 (jmax <= 32 E) of merge step k; gi = global index of the thread's first element
+template <bool FAST, int E>
+__device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[E], uint32_t (&ei)[E], int k, int jmax,
                                               int gi, int tid) {
   const uint32_t lane = (uint32_t)tid & 63u;
-  const bool up48 = (gi & k) == 0;  // k >= 8 in these stages: the same for the thread's four elements
-  // one stage: partner lane = lane ^ LX (element distance 4 * LX), exchanged in registers (lane_xor: DPP / permlane)
+  const bool upw = (gi & k) == 0;  // lane stages run for k >= 2 E: the direction is the same for the thread's elements
+  // one stage: partner lane = lane ^ LX (element distance E * LX), exchanged in registers (lane_xor: DPP / permlane)
 #define ICIKT_K0_XSTAGE(LX)                                                                              \
-  if (jmax >= 4 * (LX)) {                                                                                \
-    const bool want_gt = (((tid & (LX)) == 0) == up48); /* take the partner's when (mine > theirs) == want_gt */ \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
+  if (jmax >= E * (LX)) {                                                                                \
+    const bool want_gt = (((tid & (LX)) == 0) == upw); /* take the partner's when (mine > theirs) == want_gt */ \
+    _Pragma("unroll") for (int r = 0; r < E; ++r) {                                                      \
       const uint32_t klo = lane_xor<(LX)>((uint32_t)ek[r], lane), khi = lane_xor<(LX)>((uint32_t)(ek[r] >> 32), lane); \
       const uint32_t oi = FAST ? 0u : lane_xor<(LX)>(ei[r], lane);                                       \
       const unsigned long long ok = (unsigned long long)klo | ((unsigned long long)khi << 32);           \
@@ -215,34 +224,36 @@ __device__ __forceinline__ void k0_reg_stages(unsigned long long (&ek)[4], uint3
   }
   ICIKT_K0_XSTAGE(32) ICIKT_K0_XSTAGE(16) ICIKT_K0_XSTAGE(8) ICIKT_K0_XSTAGE(4) ICIKT_K0_XSTAGE(2) ICIKT_K0_XSTAGE(1)
 #undef ICIKT_K0_XSTAGE
-#define ICIKT_CE(a, b, upv)                                                          \
-  {                                                                                  \
-    if (kv_gt<FAST>(ek[a], ei[a], ek[b], ei[b]) == (upv)) {                          \
-      const unsigned long long tk = ek[a]; ek[a] = ek[b]; ek[b] = tk;                \
-      const uint32_t ti = ei[a]; ei[a] = ei[b]; ei[b] = ti;                          \
-    }                                                                                \
+  // inside the thread: distances E / 2 .. 1; the direction of a pair follows its lower element (bit k of gi + a: for
+  // k >= E that of gi, below it the bit of a itself)
+#pragma unroll
+  for (int j = E / 2; j >= 1; j >>= 1) {
+    if (jmax >= j) {
+#pragma unroll
+      for (int a = 0; a < E; ++a) {
+        if ((a & j) == 0) {
+          const int b = a | j;
+          const bool up = ((gi + a) & k) == 0;
+          if (kv_gt<FAST>(ek[a], ei[a], ek[b], ei[b]) == up) {
+            const unsigned long long tk = ek[a]; ek[a] = ek[b]; ek[b] = tk;
+            const uint32_t ti = ei[a]; ei[a] = ei[b]; ei[b] = ti;
+          }
+        }
+      }
+    }
   }
-  if (jmax >= 2) {
-    const bool up = (gi & k) == 0;       // k >= 4
-    ICIKT_CE(0, 2, up) ICIKT_CE(1, 3, up)
-  }
-  {
-    const bool up0 = (gi & k) == 0, up2 = ((gi + 2) & k) == 0;  // differ only for k == 2
-    ICIKT_CE(0, 1, up0) ICIKT_CE(2, 3, up2)
-  }
-#undef ICIKT_CE
 }
 
 // Compare-exchange stages on an array (the LDS tile, or the column's global scratch), TWO stages per pass and barrier: a
 // thread loads the four elements i0, i0 + j/2, i0 + j, i0 + 3j/2, runs stage j (pairs at distance j) and stage j/2 in
 // registers and stores them back -- half the barriers and half the traffic of one stage per pass.  Stages jmax .. jmin
 // (powers of two) of merge step k over `count` elements; dbase = what is added to an index to find its direction bit.
-template <bool FAST, typename KP, typename IP>
+template <bool FAST, int NT, typename KP, typename IP>
 __device__ __forceinline__ void k0_mem_stages(KP tk, IP ti, int count, int dbase, int k, int jmax, int jmin, int tid) {
   int j = jmax;
   while (j >= 2 * jmin) {
     const int jh = j >> 1;
-    for (int t = tid; t < (count >> 2); t += K0_THREADS) {
+    for (int t = tid; t < (count >> 2); t += NT) {
       const int i0 = ((t & ~(jh - 1)) << 2) | (t & (jh - 1));
       const bool up = ((dbase + i0) & k) == 0;      // the same for the four: bits j/2 and j of i0 are clear, j + j/2 < k
       unsigned long long ek[4];
@@ -266,7 +277,7 @@ __device__ __forceinline__ void k0_mem_stages(KP tk, IP ti, int count, int dbase
     j >>= 2;
   }
   if (j >= jmin) {   // an odd number of stages: the last one alone
-    for (int t = tid; t < (count >> 1); t += K0_THREADS) {
+    for (int t = tid; t < (count >> 1); t += NT) {
       const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
       const int l = i | j;
       const bool up = ((dbase + i) & k) == 0;
@@ -453,11 +464,12 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
 
 // WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
 // memory (they outgrow the static LDS), no tie-group list and no rec staging.
-template <bool WIDE>
-__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
-k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms,
-           uint8_t* __restrict__ keep) {
-  __shared__ long long sh_ll[K0_THREADS];
+template <bool WIDE, int NT, int E>
+__device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double* __restrict__ X, int64_t ld, int col_begin,
+                                                const MaskSpec& ms, uint8_t* __restrict__ keep) {
+  static_assert(NT * E == K0_TILE && (NT == K0_THREADS || NT == K0_THREADS_SMALL), "pre-pass shapes");
+  constexpr int NW = NT / 64;                       // waves of the workgroup
+  __shared__ long long sh_ll[K0_THREADS];           // (scratch sized for either shape: a 1 024-word bitset lives here in phase 3)
   __shared__ int sh_i[K0_THREADS];
   __shared__ unsigned long long sh_bits_lds[1024];  // fill-group bitset, W <= 1024 words
   __shared__ unsigned long long sh_st_lds[1028];    // phase 1: the min reduction; phase 3: group starts, n + 1 <= 65 536 bits
@@ -496,7 +508,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
   int nna = 0, nexcl = 0;
   uint8_t* keep_c = keep ? keep + (int64_t)c * n : nullptr;
-  for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+  for (int base = 0; base < pv.n_pad; base += NT) {
     const int i = base + tid;
     const double v = (i < n) ? col[i] : 0.0;
     const bool excl = (i < n) && mask_excluded(ms, v);
@@ -515,15 +527,15 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     nna = wave_reduce(nna, [](int a, int b) { return a + b; });
     nexcl = wave_reduce(nexcl, [](int a, int b) { return a + b; });
     double* sh_d = reinterpret_cast<double*>(sh_st_lds);   // (the start-flag bitset of phase 3 lives here later)
-    if (lane == 0) { sh_d[tid >> 6] = tmin; sh_i[tid >> 6] = nna; sh_i[K0_WAVES + (tid >> 6)] = nexcl; }
+    if (lane == 0) { sh_d[tid >> 6] = tmin; sh_i[tid >> 6] = nna; sh_i[NW + (tid >> 6)] = nexcl; }
     __syncthreads();
-    tmin = sh_d[0]; nna = sh_i[0]; nexcl = sh_i[K0_WAVES];
+    tmin = sh_d[0]; nna = sh_i[0]; nexcl = sh_i[NW];
 #pragma unroll
-    for (int w = 1; w < K0_WAVES; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const double b = sh_d[w];
       tmin = (b < tmin) ? b : tmin;
       nna += sh_i[w];
-      nexcl += sh_i[K0_WAVES + w];
+      nexcl += sh_i[NW + w];
     }
     __syncthreads();
   }
@@ -532,7 +544,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   // ---- phases 1b + 2: sortable keys, sort.  FAST: one word per element (top 48 key bits | row), see kv_gt ------
   auto sort_pass = [&](auto fast_tag) {
   constexpr bool FAST = decltype(fast_tag)::value;
-  for (int i = tid; i < npow2; i += K0_THREADS) {
+  for (int i = tid; i < npow2; i += NT) {
     unsigned long long k = ~0ull;
     uint32_t id = 0xFFFFFFFFu;
     if (i < n) {
@@ -556,55 +568,56 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     const int ntiles = npow2 / T;
     if (T == K0_TILE) {
       // full tiles: register / shuffle stages (k0_reg_stages) around the LDS stages with distance >= 256
-      unsigned long long ek[4];
-      uint32_t ei[4];
+      // (a wave holds 64 E consecutive elements: distances up to 32 E in registers, 64 E and more on the LDS tile)
+      unsigned long long ek[E];
+      uint32_t ei[E];
       for (int tile = 0; tile < ntiles; ++tile) {
         const int tb = tile * T;
         if (tb >= n) continue;  // a tile of padding only (equal keys) is sorted in either direction already
-        const int gi = tb + 4 * tid;
+        const int gi = tb + E * tid;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ek[r] = keys[gi + r]; ei[r] = FAST ? 0u : idx[gi + r]; }
-        for (int k = 2; k <= 256; k <<= 1) k0_reg_stages<FAST>(ek, ei, k, k >> 1, gi, tid);
-        for (int k = 512; k <= T; k <<= 1) {
+        for (int r = 0; r < E; ++r) { ek[r] = keys[gi + r]; ei[r] = FAST ? 0u : idx[gi + r]; }
+        for (int k = 2; k <= 64 * E; k <<= 1) k0_reg_stages<FAST, E>(ek, ei, k, k >> 1, gi, tid);
+        for (int k = 128 * E; k <= T; k <<= 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = ek[r]; if (!FAST) sh_ti[4 * tid + r] = ei[r]; }
+          for (int r = 0; r < E; ++r) { sh_tk[E * tid + r] = ek[r]; if (!FAST) sh_ti[E * tid + r] = ei[r]; }
           __syncthreads();
-          k0_mem_stages<FAST>(sh_tk, sh_ti, T, tb, k, k >> 1, 256, tid);
+          k0_mem_stages<FAST, NT>(sh_tk, sh_ti, T, tb, k, k >> 1, 64 * E, tid);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = FAST ? 0u : sh_ti[4 * tid + r]; }
+          for (int r = 0; r < E; ++r) { ek[r] = sh_tk[E * tid + r]; ei[r] = FAST ? 0u : sh_ti[E * tid + r]; }
           __syncthreads();  // the tile is rewritten by the next step's stores
-          k0_reg_stages<FAST>(ek, ei, k, 128, gi, tid);
+          k0_reg_stages<FAST, E>(ek, ei, k, 32 * E, gi, tid);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
+        for (int r = 0; r < E; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
       }
       __syncthreads();
       // merges across tiles: distances >= T in global memory, 2048..256 on the LDS tile, the rest in registers
       for (int k = 2 * T; k <= npow2; k <<= 1) {
-        k0_mem_stages<FAST>(keys, idx, npow2, 0, k, k >> 1, T, tid);   // (global scratch: __syncthreads orders a workgroup's global accesses)
+        k0_mem_stages<FAST, NT>(keys, idx, npow2, 0, k, k >> 1, T, tid);   // (global scratch: __syncthreads orders a workgroup's global accesses)
         for (int tile = 0; tile < ntiles; ++tile) {
           const int tb = tile * T;
-          const int gi = tb + 4 * tid;
+          const int gi = tb + E * tid;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { sh_tk[4 * tid + r] = keys[gi + r]; if (!FAST) sh_ti[4 * tid + r] = idx[gi + r]; }
+          for (int r = 0; r < E; ++r) { sh_tk[E * tid + r] = keys[gi + r]; if (!FAST) sh_ti[E * tid + r] = idx[gi + r]; }
           __syncthreads();
-          k0_mem_stages<FAST>(sh_tk, sh_ti, T, tb, k, T >> 1, 256, tid);   // (the direction is constant inside a tile: k > T)
+          k0_mem_stages<FAST, NT>(sh_tk, sh_ti, T, tb, k, T >> 1, 64 * E, tid);   // (the direction is constant inside a tile: k > T)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { ek[r] = sh_tk[4 * tid + r]; ei[r] = FAST ? 0u : sh_ti[4 * tid + r]; }
+          for (int r = 0; r < E; ++r) { ek[r] = sh_tk[E * tid + r]; ei[r] = FAST ? 0u : sh_ti[E * tid + r]; }
           __syncthreads();
-          k0_reg_stages<FAST>(ek, ei, k, 128, gi, tid);
+          k0_reg_stages<FAST, E>(ek, ei, k, 32 * E, gi, tid);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
+          for (int r = 0; r < E; ++r) { keys[gi + r] = ek[r]; if (!FAST) idx[gi + r] = ei[r]; }
         }
         __syncthreads();
       }
     } else {
       // short columns (npow2 < 4096): one partial tile, every stage on LDS
-      for (int i = tid; i < T; i += K0_THREADS) { sh_tk[i] = keys[i]; if (!FAST) sh_ti[i] = idx[i]; }
+      for (int i = tid; i < T; i += NT) { sh_tk[i] = keys[i]; if (!FAST) sh_ti[i] = idx[i]; }
       __syncthreads();
       for (int k = 2; k <= T; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int t = tid; t < (T >> 1); t += K0_THREADS) {
+          for (int t = tid; t < (T >> 1); t += NT) {
             const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
             const int l = i | j;
             const bool up = ((i & k) == 0);
@@ -618,7 +631,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
           __syncthreads();
         }
       }
-      for (int i = tid; i < T; i += K0_THREADS) { keys[i] = sh_tk[i]; if (!FAST) idx[i] = sh_ti[i]; }
+      for (int i = tid; i < T; i += NT) { keys[i] = sh_tk[i]; if (!FAST) idx[i] = sh_ti[i]; }
       __syncthreads();
     }
   }
@@ -631,7 +644,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     // values of the column share the top 48 bits of their keys and differ below them; the column is then sorted again
     // with three-word elements (full key, row).  Equal full keys are in row order either way: the row is part of the word.
     sort_pass(std::true_type{});
-    for (int k = tid; k < n; k += K0_THREADS) {
+    for (int k = tid; k < n; k += NT) {
       const uint32_t row = (uint32_t)keys[k] & 0xFFFFu;
       double v = col[row];
       if (v != v || mask_excluded(ms, v)) v = fill;
@@ -640,7 +653,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     }
     __syncthreads();
     int inv = 0;
-    for (int k = tid + 1; k < n; k += K0_THREADS) inv |= (keys[k - 1] > keys[k]) ? 1 : 0;
+    for (int k = tid + 1; k < n; k += NT) inv |= (keys[k - 1] > keys[k]) ? 1 : 0;
     if (__syncthreads_or(inv)) sort_pass(std::false_type{});
   }
 
@@ -653,21 +666,21 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   // gave each thread a run of consecutive positions: the lanes of a wave then read keys and row indices at a
   // stride of 8 n / 1024 bytes, three key loads per position and pass, and carried the open group from thread to
   // thread with two 1 024-wide LDS scans (K0 without its sort: 0.44 of 1.03 ms on c4).
-  for (int base = 0; base <= ((n >> 6) << 6); base += K0_THREADS) {
+  for (int base = 0; base <= ((n >> 6) << 6); base += NT) {
     const int k = base + tid;
     const bool st = (k <= n) && (k == 0 || k == n || keys[k - 1] != keys[k]);
     const unsigned long long b = __ballot(st);
     if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
   }
   unsigned long long* sh_big = reinterpret_cast<unsigned long long*>(sh_ll);  // bit k: a group of >= 2 rows starts at k
-  for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += K0_THREADS) {
+  for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += NT) {
     sh_bits[w] = 0ull;
     if (!WIDE) sh_big[w] = 0ull;
   }
   if (WIDE) {
-    for (int k = n + tid; k < pv.n_pad; k += K0_THREADS) order32[k] = 0u;
+    for (int k = n + tid; k < pv.n_pad; k += NT) order32[k] = 0u;
   } else {
-    for (int k = n + tid; k < pv.n_ord; k += K0_THREADS) order[k] = 0;  // zero padding: K1 prefetches one step ahead
+    for (int k = n + tid; k < pv.n_ord; k += NT) order[k] = 0;  // zero padding: K1 prefetches one step ahead
   }
   __syncthreads();
   auto is_start = [&](int k) -> bool { return (sh_st[k >> 6] >> (k & 63)) & 1ull; };   // 0 <= k <= n
@@ -689,7 +702,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0, oddtie = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
   long long e0 = 0, e1 = 0, e2 = 0;     // exact
-  for (int base = 0; base < n; base += K0_THREADS) {
+  for (int base = 0; base < n; base += NT) {
     const int k = base + tid;
     bool big = false;
     if (k < n) {
@@ -732,11 +745,11 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   }
   __syncthreads();
   if (stage_rec) {
-    for (int r = tid; r < n; r += K0_THREADS) rec[2 * r] = rec_s[r];
+    for (int r = tid; r < n; r += NT) rec[2 * r] = rec_s[r];
   }
 
   // group-start flags in PROCESSING order k' = n-1-k: a group starts at k' where it ends at k
-  for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+  for (int base = 0; base < pv.n_pad; base += NT) {
     const int kp = base + tid;
     bool flag = false;
     if (kp < n) {
@@ -747,12 +760,12 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     if (lane == 0 && (kp >> 6) < W) gflag[kp >> 6] = b;
   }
   if (tid == 0) { gflag[W] = 0ull; }
-  for (int w = tid; w <= W; w += K0_THREADS) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
+  for (int w = tid; w <= W; w += NT) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
   if (!WIDE && pv.tp_stride > 0) {
     // the tie program of the column: its flag words, still in registers of the lanes that wrote them, go to LDS (the
     // fill-group bitset there has just been copied out) and one wave cuts the steps from that copy
     __syncthreads();
-    for (int base = 0; base < pv.n_pad; base += K0_THREADS) {
+    for (int base = 0; base < pv.n_pad; base += NT) {
       const int kp = base + tid;
       const bool flag = (kp < n) && is_start(n - kp);          // the same bit as above: position n-1-kp ends a group
       const unsigned long long b = __ballot(flag);
@@ -761,11 +774,11 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     if (tid == 0) sh_bits_lds[W] = 0ull;
     __syncthreads();
     // scratch in the sort tile / rec staging area (48 KB, copied out above): E TPROG_WIN u16 | crossT 2 048 u32 | list
-    uint16_t* E = reinterpret_cast<uint16_t*>(sh_sort);
-    uint32_t* crossT = reinterpret_cast<uint32_t*>(E + TPROG_WIN);
+    uint16_t* Ewin = reinterpret_cast<uint16_t*>(sh_sort);
+    uint32_t* crossT = reinterpret_cast<uint32_t*>(Ewin + TPROG_WIN);
     uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
-    k0_tie_program(sh_bits_lds, E, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
-                   pv.tmask + (int64_t)c * pv.n_ord, tid, K0_THREADS);
+    k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+                   pv.tmask + (int64_t)c * pv.n_ord, tid, NT);
     __syncthreads();   // (sh_i is used by the reductions below)
   }
 
@@ -773,23 +786,32 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   // tie group of the OTHER column that spans several steps once, when that group closes.  A group's place in the
   // list = the groups of >= 2 rows that start before it: a prefix over the words of sh_big.
   if (!WIDE) {
-    const int nw = (n + 63) >> 6;                  // <= 1024 words, one per thread
-    const int cnt = (tid < nw) ? (int)__popcll(sh_big[tid]) : 0;
-    const int incl = (int)wave_incl_scan((uint32_t)cnt);           // inside the wave; the waves' totals through LDS
-    if (lane == 63) sh_i[tid >> 6] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wbase += sh_i[w];
-    if (tid < nw) {
-      int off = wbase + incl - cnt;
-      unsigned long long m = sh_big[tid];
-      while (m != 0ull) {
-        const int k = (tid << 6) + (int)__builtin_ctzll(m);
-        m &= m - 1ull;
-        tgl[off++] = (uint32_t)k | ((uint32_t)(next_start(k) - 1) << 16);
+    const int nw = (n + 63) >> 6;                  // <= 1024 words: one per thread and block of NT words
+    int gbase = 0;                                 // groups listed by the blocks before this one (the same in every thread)
+    for (int wb = 0; wb < nw; wb += NT) {
+      const int wi = wb + tid;
+      const int cnt = (wi < nw) ? (int)__popcll(sh_big[wi]) : 0;
+      const int incl = (int)wave_incl_scan((uint32_t)cnt);           // inside the wave; the waves' totals through LDS
+      if (lane == 63) sh_i[tid >> 6] = incl;
+      __syncthreads();
+      int wbase = gbase, btot = 0;
+      for (int w = 0; w < NW; ++w) {
+        const int t = sh_i[w];
+        if (w < (tid >> 6)) wbase += t;
+        btot += t;
       }
+      if (wi < nw) {
+        int off = wbase + incl - cnt;
+        unsigned long long m = sh_big[wi];
+        while (m != 0ull) {
+          const int k = (wi << 6) + (int)__builtin_ctzll(m);
+          m &= m - 1ull;
+          tgl[off++] = (uint32_t)k | ((uint32_t)(next_start(k) - 1) << 16);
+        }
+      }
+      gbase += btot;
+      __syncthreads();   // (sh_i is rewritten by the next block)
     }
-    __syncthreads();
   }
   // the column's statistics: every value reduced inside its wave, the waves' results combined by thread 0 -- one barrier
   const auto add_i = [](int a, int b) { return a + b; };
@@ -813,7 +835,7 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
   int ntg = 0;
   if (tid == 0) {
     ngroups = 0; maxgroup = 0; tfill = 0; oddtie = 0; s0 = s1 = s2 = 0u; e0 = e1 = e2 = 0;
-    for (int w = 0; w < K0_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const int* wi = sh_i + w * 8;
       ntg += wi[0]; ngroups += wi[1];
       maxgroup = ((uint32_t)wi[2] > (uint32_t)maxgroup) ? wi[2] : maxgroup;
@@ -837,6 +859,20 @@ k0_prepare(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin,
     st.flags = oddtie ? COL_ODD_TIE : 0;
     *pv.col_stats(c) = st;
   }
+}
+
+// the three kernels of the pre-pass: one body, three shapes (a register budget is a per-kernel attribute)
+__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
+k0_prepare_large(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
+  k0_prepare_body<false, K0_THREADS, K0_TILE / K0_THREADS>(pv, X, ld, col_begin, ms, keep);
+}
+__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
+k0_prepare_wide(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
+  k0_prepare_body<true, K0_THREADS, K0_TILE / K0_THREADS>(pv, X, ld, col_begin, ms, keep);
+}
+__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_WAVES_SMALL)   // (bounds of the LARGE shape: they make the register budget binding; launched with K0_THREADS_SMALL threads)
+k0_prepare_small(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
+  k0_prepare_body<false, K0_THREADS_SMALL, K0_TILE / K0_THREADS_SMALL>(pv, X, ld, col_begin, ms, keep);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3231,12 +3267,16 @@ __global__ void k_selftest(uint32_t* out) {
 // (every launcher first drops whatever error an earlier, unrelated HIP call of the calling thread left behind: the
 //  hipGetLastError() after the launch must report THIS launch)
 hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_begin, int ncols, const MaskSpec* msp,
-                     uint8_t* keep, hipStream_t s) {
+                     uint8_t* keep, int small_shape, hipStream_t s) {
   (void)hipGetLastError();
   MaskSpec ms{};
   if (msp) ms = *msp;
-  if (pv.wide) hipLaunchKernelGGL(k0_prepare<true>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
-  else hipLaunchKernelGGL(k0_prepare<false>, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
+  if (pv.wide)
+    hipLaunchKernelGGL(k0_prepare_wide, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
+  else if (small_shape)   // 4 waves per column: fits beside a running pair kernel (the later chunks of the pipelined host path)
+    hipLaunchKernelGGL(k0_prepare_small, dim3(ncols), dim3(K0_THREADS_SMALL), 0, s, pv, dX, ld, col_begin, ms, keep);
+  else
+    hipLaunchKernelGGL(k0_prepare_large, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
   return hipGetLastError();
 }
 

@@ -342,8 +342,7 @@ void rank_main(Call& a, int r) {
       if (a.counts) RANKCHK(icikt::host::download(c, a.counts, m->root_counts, (size_t)a.P * ICIKT_CNT_FIELDS * sizeof(int64_t)));
       if (a.reasons) RANKCHK(icikt::host::download(c, a.reasons, m->root_reasons, (size_t)a.P * sizeof(int32_t)));
     }
-    const hipError_t es = hipStreamSynchronize(c->stream);
-    icikt::host::finish_downloads(c, es == hipSuccess);
+    const hipError_t es = icikt::host::finish_stream(c, true);   // (delivers the bounced results piece by piece as they arrive)
     RANKCHK_HIP(es);
   };
   phase_c();

@@ -290,7 +290,8 @@ int icikt_selftest(icikt_ctx *ctx);
  * choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g: open-group bitset in LDS | global memory), wpb (waves
  * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), gridmult / gridcap (persistent grid
  * of the long-column kernel: a multiple of the resident workgroups / at most this many), pipe (0 | 1: the host entries'
- * chunk pipeline), verbose (0 | 1: print the chosen plan to stderr). */
+ * chunk pipeline), k0 (0 | 1: the pre-pass always in its 1 024-thread / 256-thread shape), verbose (0 | 1: print the
+ * chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
 /* Development hook: per step kind of the pair kernel (hot loop, hot step in the main loop, MIXED, GROUP, general,
  * closed-form tail, set-up) the steps taken, their rows and the wave cycles spent, as out24 = [steps x 8 | rows x 8 |

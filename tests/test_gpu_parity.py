@@ -73,6 +73,35 @@ def test_values_that_differ_only_in_their_low_bits(hip_ctx, n):
         _check(hip_ctx, X, perspective=p)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4095, 4096, 4097, 8200, 10000, 16384, 16385, 30000, 50000, 65535])
+def test_prepass_small_shape(plan_ctx, n):
+    """The pre-pass has two shapes of one body: 1 024 threads x 4 elements (default) and 256 threads x 16 (what the
+    later chunks of the pipelined host path run beside the pair kernel).  Forced by the plan key k0 = 1 / 0 they must
+    prepare the SAME state -- the same results bit for bit, counts included -- on short and long columns, with ties, with
+    values that collide in the one-word sort (second pass), and each equals the oracle."""
+    rng = np.random.default_rng(n + 5)
+    S = 6
+    X = rng.standard_normal((n, S))
+    if n > 8:
+        X[:, 1] = np.round(X[:, 1] * 3)
+        X[:, 2] = np.round(X[:, 2] * 200)
+        X[:, 3] = 1.0 + (rng.permutation(n) % 50000) * 2.0 ** -52        # one-word collisions everywhere
+        X[rng.random(X.shape) < 0.07] = np.nan
+        X[:, 5] = np.where(rng.random(n) < 0.6, np.nan, X[:, 5])
+    res = {}
+    for shape in (0, 1):
+        plan_ctx.debug_set_plan({"k0": shape})
+        res[shape] = _check(plan_ctx, X, perspective="global") if n <= 20000 else plan_ctx.pairs(X, perspective="global")
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    if n > 20000:   # (the oracle on a few pairs only: long columns)
+        O = _oracle()
+        pi, pj = np.triu_indices(S, k=1)
+        ref, rcnt, rrsn = O.ici_pairs(X, pi[:5], pj[:5], "global")
+        assert np.array_equal(res[1][1][:5], rcnt[:, :res[1][1].shape[1]]) and np.array_equal(res[1][2][:5], rrsn)
+        assert float(np.nanmax(np.abs(res[1][0][:5] - ref))) <= ATOL
+
+
 @pytest.mark.parametrize("levels", [2, 3, 7, 50])
 @pytest.mark.parametrize("perspective", ["global", "local"])
 def test_heavy_ties(hip_ctx, levels, perspective):

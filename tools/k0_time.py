@@ -7,6 +7,8 @@ from bench import make_matrix
 for (n, S, na, seed) in ((10000, 1024, 1000, 4), (10000, 256, 500, 3), (50000, 512, 1000, 5)):
     X = make_matrix(n, S, na, seed)
     ctx = _lib.Context(0)
+    if len(sys.argv) > 1:
+        ctx.debug_set_plan(sys.argv[1])     # e.g. k0=1: the 256-thread shape
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
     ts = []
     for _ in range(6):

@@ -151,7 +151,8 @@ constexpr int K0_THREADS_SMALL = 256;
 #ifndef ICIKT_K0_WAVES_SMALL
 #define ICIKT_K0_WAVES_SMALL 5    // the small shape is compiled for five waves per SIMD (<= 96 registers): a wave of it fits a SIMD on which ONE pair-kernel wave (80 of 512 registers, six resident) has retired
 #endif
-constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB) = threads x elements per thread, either shape
+constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB) = threads x elements per thread of the standard shapes
+
 
 __device__ __forceinline__ unsigned long long sortable_key(double v) {
   if (v == 0.0) v = 0.0;  // -0.0 and +0.0 tie (x[i] < x[j] is false both ways, kendallc.cpp:9,23)
@@ -467,7 +468,8 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
 template <bool WIDE, int NT, int E>
 __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double* __restrict__ X, int64_t ld, int col_begin,
                                                 const MaskSpec& ms, uint8_t* __restrict__ keep) {
-  static_assert(NT * E == K0_TILE && (NT == K0_THREADS || NT == K0_THREADS_SMALL), "pre-pass shapes");
+  static_assert((NT == K0_THREADS || NT == K0_THREADS_SMALL) && (E == 4 || E == 8 || E == 16), "pre-pass shapes");
+  constexpr int TILE = NT * E;                      // elements of the LDS-resident sort tile
   constexpr int NW = NT / 64;                       // waves of the workgroup
   __shared__ long long sh_ll[K0_THREADS];           // (scratch sized for either shape: a 1 024-word bitset lives here in phase 3)
   __shared__ int sh_i[K0_THREADS];
@@ -475,11 +477,11 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   __shared__ unsigned long long sh_st_lds[1028];    // phase 1: the min reduction; phase 3: group starts, n + 1 <= 65 536 bits
   unsigned long long* const sh_bits = WIDE ? pv.k0_bits + (size_t)blockIdx.x * 2 * (size_t)(pv.Wp + 1) : sh_bits_lds;
   unsigned long long* const sh_st = WIDE ? sh_bits + (pv.Wp + 1) : sh_st_lds;
-  __shared__ unsigned long long sh_sort[K0_TILE + K0_TILE / 2];  // 48 KB: the sort tile, later the rec staging area
+  __shared__ unsigned long long sh_sort[TILE + TILE / 2];  // 48 KB: the sort tile, later the rec staging area
   unsigned long long* sh_tk = sh_sort;                                      // sort tile: keys
-  uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + K0_TILE);         // sort tile: row indices
+  uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + TILE);         // sort tile: row indices
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(sh_sort);                   // after the sort: rec by row
-  const bool stage_rec = !WIDE && pv.n_pad <= 3 * K0_TILE;                  // 12 288 rows x 4 B fit
+  const bool stage_rec = !WIDE && pv.n_pad <= 3 * TILE;                  // 12 288 rows x 4 B fit
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -564,9 +566,9 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   //      distances below the tile size run on an LDS-resident tile; only the long distances of the
   //      last merges touch global memory. -------------------------------------------------------------
   {
-    const int T = (npow2 < K0_TILE) ? npow2 : K0_TILE;
+    const int T = (npow2 < TILE) ? npow2 : TILE;
     const int ntiles = npow2 / T;
-    if (T == K0_TILE) {
+    if (T == TILE) {
       // full tiles: register / shuffle stages (k0_reg_stages) around the LDS stages with distance >= 256
       // (a wave holds 64 E consecutive elements: distances up to 32 E in registers, 64 E and more on the LDS tile)
       unsigned long long ek[E];
@@ -861,10 +863,18 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   }
 }
 
-// the three kernels of the pre-pass: one body, three shapes (a register budget is a per-kernel attribute)
+// the kernels of the pre-pass: one body, four shapes (a register budget is a per-kernel attribute)
 __global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
 k0_prepare_large(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
-  k0_prepare_body<false, K0_THREADS, K0_TILE / K0_THREADS>(pv, X, ld, col_begin, ms, keep);
+  k0_prepare_body<false, K0_THREADS, 4>(pv, X, ld, col_begin, ms, keep);
+}
+// columns of more than 4 096 rows: 8 elements per thread, an 8 192-element tile (96 KB of LDS, 124 KB with the bitsets) --
+// half the tiles, one merge level less through the global scratch: 20 000 rows 0.90 -> 0.70 ms per 512 columns, the yeast
+// shape 0.090 -> 0.079, 50 000 rows 2.80 -> 2.62 (round 4).  Shorter columns would take the all-LDS path of a partial
+// tile there (3 000 rows: 0.19 -> 0.26 ms per 1 024 columns) and keep the 4 096-element tile.
+__global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
+k0_prepare_large8(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
+  k0_prepare_body<false, K0_THREADS, 8>(pv, X, ld, col_begin, ms, keep);
 }
 __global__ void __launch_bounds__(K0_THREADS, ICIKT_K0_MIN_WAVES)
 k0_prepare_wide(PrepView pv, const double* __restrict__ X, int64_t ld, int col_begin, const MaskSpec ms, uint8_t* __restrict__ keep) {
@@ -3275,6 +3285,8 @@ hipError_t launch_k0(const PrepView& pv, const double* dX, int64_t ld, int col_b
     hipLaunchKernelGGL(k0_prepare_wide, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
   else if (small_shape)   // 4 waves per column: fits beside a running pair kernel (the later chunks of the pipelined host path)
     hipLaunchKernelGGL(k0_prepare_small, dim3(ncols), dim3(K0_THREADS_SMALL), 0, s, pv, dX, ld, col_begin, ms, keep);
+  else if (pv.npow2 >= 2 * K0_TILE)
+    hipLaunchKernelGGL(k0_prepare_large8, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
   else
     hipLaunchKernelGGL(k0_prepare_large, dim3(ncols), dim3(K0_THREADS), 0, s, pv, dX, ld, col_begin, ms, keep);
   return hipGetLastError();

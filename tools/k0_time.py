@@ -1,10 +1,11 @@
-"""K0 (the per-column pre-pass) alone on the c4 and c3 matrices: device-resident timing (development aid)."""
+"""K0 (the per-column pre-pass) alone on the c4 and c3 matrices and longer / shorter columns: device-resident timing
+(development aid).  argv[1]: a debug plan, e.g. k0=1 (the 256-thread shape)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from icikendalltau_amd import _lib
 from bench import make_matrix
-for (n, S, na, seed) in ((10000, 1024, 1000, 4), (10000, 256, 500, 3), (50000, 512, 1000, 5)):
+for (n, S, na, seed) in ((10000, 1024, 1000, 4), (10000, 256, 500, 3), (50000, 512, 1000, 5), (6887, 96, 300, 2), (3000, 1024, 100, 6), (20000, 512, 500, 7)):
     X = make_matrix(n, S, na, seed)
     ctx = _lib.Context(0)
     if len(sys.argv) > 1:

@@ -27,6 +27,7 @@ ALT_OTHER = 3
 FLAG_EXACT_INT64 = 1
 FLAG_TIMING = 2
 FLAG_REUSE_COUNTS = 4
+FLAG_BALANCE_COST = 16  # multi-device entries: pair blocks of equal cost (the streamed columns' tie structure) instead of equal length
 FLAG_HOST_PINNED = 8     # the caller has page-locked the matrix and the result arrays of the call (pinned_empty)
 CNT_FIELDS = ("n", "missing", "dis", "ntie", "xtie", "ytie", "x0", "x1", "y0", "y1", "tot")
 K_PREPARE, K_PAIRS, K_EPILOGUE = 0, 1, 2
@@ -51,7 +52,7 @@ EXPORTS = (
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
     "icikt_matrix_f64", "icikt_matrix_multi_f64", "icikt_multi_rank_phase_ms", "icikt_multi_ranks_used",
-    "icikt_debug_step_stats", "icikt_multi_comm_ranks",
+    "icikt_debug_step_stats", "icikt_multi_comm_ranks", "icikt_multi_block_bounds",
 )
 
 
@@ -145,6 +146,7 @@ def lib():
     L.icikt_multi_n_gpu.argtypes = [c_vp]
     L.icikt_multi_uses_rccl.argtypes = [c_vp]
     L.icikt_multi_comm_ranks.argtypes = [c_vp]
+    L.icikt_multi_block_bounds.argtypes = [c_vp, ctypes.POINTER(c_i64)]
     L.icikt_pairs_multi_f64.argtypes = L.icikt_pairs_f64.argtypes
     L.icikt_multi_phase_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double)]
     L.icikt_multi_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
@@ -430,6 +432,13 @@ class MultiContext:
     @property
     def uses_rccl(self) -> bool:
         return bool(lib().icikt_multi_uses_rccl(self._h))
+
+    def block_bounds(self) -> list:
+        """Pair blocks of the last call: rank r ran pairs [b[r], b[r + 1]) of the list."""
+        n = self.ranks_used + 1
+        b = (ctypes.c_int64 * n)()
+        self._chk(lib().icikt_multi_block_bounds(self._h, b), "icikt_multi_block_bounds")
+        return list(b)
 
     @property
     def comm_ranks(self) -> int:

@@ -23,9 +23,12 @@ struct ColStats {
   double fill;           // min - 0.1
   int32_t nexcl;         // rows excluded by the caller's global_na rule (MaskSpec): exclude_loc of R/utils.R:1-23.
                          // == nna unless the data hold NaN and NaN is not in global_na
-  int32_t flags;         // COL_ODD_TIE: some tie group of >= 2 rows starts at an ODD ascending position
+  int32_t flags;         // bit 0 COL_ODD_TIE: some tie group of >= 2 rows starts at an ODD ascending position;
+                         // bits 8..31: what STREAMING the column costs a pair kernel task, in half hot steps (2 per 64-row hot
+                         // step, 4 per MIXED, 3 per GROUP step): the cost-weighted pair blocks of the multi-device driver
 };
 constexpr int COL_ODD_TIE = 1;
+__host__ __device__ inline uint32_t col_stream_cost(const ColStats& st) { return (uint32_t)st.flags >> 8; }
 
 // tie-program entry: rows of the step | kind << 7 | closes << 9 | n0 << 10 (MIXED: rows of its first sub-step)
 constexpr uint32_t TPROG_KIND_HOT = 0u, TPROG_KIND_MIXED = 1u, TPROG_KIND_GROUP = 2u;

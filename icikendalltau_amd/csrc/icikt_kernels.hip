@@ -410,7 +410,8 @@ __device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, 
 // the entries and lists the MIXED steps; (C) the waves share out the window's MIXED steps and write their rows' masks.
 // scratch: E (TPROG_WIN u16) | list of MIXED step positions (TPROG_LIST u16: a MIXED step of complete groups that does
 // not reach 33 rows is followed by a longer group, so a window starts at most TPROG_WIN / 17 of them) | crossT (32 x 64
-// u32); `cnt`: three shared ints (MIXED steps of the window; the chain's position and entry count between windows).
+// u32); `cnt`: four shared ints (MIXED steps of the window; the chain's position and entry count between windows; the
+// column's streaming cost, see below).
 constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;   // (list: TPROG_LIST pairs of u16 -- window offset, entry index)
 __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
                                       int n, int W, uint32_t* prog, uint2* tmask, int tid, int nthreads) {
@@ -426,7 +427,9 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     }
     first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
     const int hot_until = (first_cont < n) ? first_cont - 1 : n;
-    if (lane == 0u) { cnt[1] = (hot_until >> 6) << 6; cnt[2] = 0; }
+    // cnt[3]: what streaming this column costs a pair, in half hot steps (a hot step of 64 rows = 2, a MIXED step = 4, a
+    // GROUP step = 3: their vector instructions): the singleton region now, the program's steps below
+    if (lane == 0u) { cnt[1] = (hot_until >> 6) << 6; cnt[2] = 0; cnt[3] = 2 * (hot_until >> 6); }
   }
   __syncthreads();
   for (int win = (cnt[1] / TPROG_WIN) * TPROG_WIN; win < n; win += TPROG_WIN) {
@@ -434,9 +437,10 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     for (int p = win + tid; p < wend; p += nthreads) E[p - win] = (uint16_t)k0_step_at(gf, n, W, p);
     __syncthreads();
     if (wave == 0) {
-      int pos = cnt[1], ne = cnt[2], nm = 0;
+      int pos = cnt[1], ne = cnt[2], nm = 0, cost = cnt[3];
       while (pos < wend) {
         const uint32_t e = (uint32_t)E[pos - win];
+        cost += (tprog_kind(e) == TPROG_KIND_MIXED) ? 4 : (tprog_kind(e) == TPROG_KIND_GROUP) ? 3 : 2;
         if (lane == 0u) {
           prog[ne] = e;
           if (tprog_kind(e) == TPROG_KIND_MIXED) { mlist[2 * nm] = (uint16_t)(pos - win); mlist[2 * nm + 1] = (uint16_t)ne; }
@@ -447,7 +451,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
       }
       if (lane == 0u) {
         if (wend == n) prog[ne] = 0u;
-        cnt[0] = nm; cnt[1] = pos; cnt[2] = ne;
+        cnt[0] = nm; cnt[1] = pos; cnt[2] = ne; cnt[3] = cost;
       }
     }
     __syncthreads();
@@ -763,6 +767,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   }
   if (tid == 0) { gflag[W] = 0ull; }
   for (int w = tid; w <= W; w += NT) fmask[w] = (w < W) ? sh_bits[w] : 0ull;
+  int stream_cost = 2 * ((n + 63) >> 6);   // columns without a tie program (long, wide): the steps of their walk
   if (!WIDE && pv.tp_stride > 0) {
     // the tie program of the column: its flag words, still in registers of the lanes that wrote them, go to LDS (the
     // fill-group bitset there has just been copied out) and one wave cuts the steps from that copy
@@ -781,6 +786,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
     k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
                    pv.tmask + (int64_t)c * pv.n_ord, tid, NT);
+    stream_cost = sh_i[3];   // (every thread reads it; thread 0 stores it with the statistics)
     __syncthreads();   // (sh_i is used by the reductions below)
   }
 
@@ -858,7 +864,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     st.e0 = e0; st.e1 = e1; st.e2 = e2;
     st.fill = fill;
     st.nexcl = nexcl;
-    st.flags = oddtie ? COL_ODD_TIE : 0;
+    st.flags = (oddtie ? COL_ODD_TIE : 0) | (int32_t)((uint32_t)min(stream_cost, 0xFFFFFF) << 8);
     *pv.col_stats(c) = st;
   }
 }
@@ -907,7 +913,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   __shared__ uint32_t kx_cross[32 * 64];   // k0_tie_program's scratch: cross table, would-be steps, MIXED step list
   __shared__ uint16_t kx_E[TPROG_WIN];
   __shared__ uint16_t kx_list[2 * TPROG_LIST];
-  __shared__ int kx_cnt[3];
+  __shared__ int kx_cnt[4];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   const int c = col_begin + (int)blockIdx.x;

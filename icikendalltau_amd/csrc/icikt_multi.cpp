@@ -80,6 +80,9 @@ struct icikt_multi {
   double phase_ms[ICIKT_MULTI_PHASES] = {};          // of the last call: maximum over the ranks
   std::vector<double> rank_ms;                        // [rank][ICIKT_MULTI_PHASES + 1]: its phases, then its barrier waits
   int ranks_used = 0;                                 // of the last call: n, or 1 when it ran on the first device alone
+  std::vector<int64_t> bounds;                        // of the last call: rank r ran pairs [bounds[r], bounds[r + 1]) of the list
+  void* root_compact = nullptr;                       // cost-weighted blocks, matrix entry: the gathered slots made contiguous
+  size_t root_compact_bytes = 0;
   // rank 0's gather targets
   void* root_out4 = nullptr;
   void* root_counts = nullptr;
@@ -100,6 +103,9 @@ struct Call {
   int64_t n_feat, n_samp, ld;
   const int32_t *pi, *pj;
   int64_t P, n_each;
+  int64_t slot;                   // pairs a rank's result buffers hold (= n_each; 2 n_each with cost-weighted blocks)
+  bool balance;                   // ICIKT_FLAG_BALANCE_COST: block boundaries by the streamed columns' cost, not by count
+  std::vector<int64_t> bounds;    // [G + 1]; equal counts: known up front; cost-weighted: every rank computes the same in phase B
   int perspective, alternative, continuity;
   uint32_t flags;
   double* out4;
@@ -185,8 +191,8 @@ void rank_main(Call& a, int r) {
   const int G = m->n;
   const int64_t S = a.n_samp;
   const int64_t c0 = std::min(S, (int64_t)r * a.cols_per), c1 = std::min(S, (int64_t)(r + 1) * a.cols_per);
-  const int64_t begin = std::min(a.P, (int64_t)r * a.n_each), end = std::min(a.P, (int64_t)(r + 1) * a.n_each);
-  const int64_t P_local = end - begin;
+  int64_t begin = a.bounds[(size_t)r], end = a.bounds[(size_t)r + 1];   // (cost-weighted blocks: set in phase B)
+  int64_t P_local = end - begin;
   double t_prev = now_ms();
   double* my_ms = m->rank_ms.data() + (size_t)r * (ICIKT_MULTI_PHASES + 1);
   // every rank keeps the wall clock of ITS phases (with ICIKT_FLAG_TIMING: after a stream synchronisation, so the
@@ -209,8 +215,10 @@ void rank_main(Call& a, int r) {
   // ---- phase A: this rank's pair block, its share of the columns: H2D + K0 ---------------------------------
   auto phase_a = [&]() {
     RANKCHK(icikt::host::use_device(c));
-    if (a.pi) RANKCHK(icikt_set_pairs(c, a.pi + begin, a.pj + begin, P_local));
-    else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
+    if (!a.balance) {
+      if (a.pi) RANKCHK(icikt_set_pairs(c, a.pi + begin, a.pj + begin, P_local));
+      else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
+    }
     RANKCHK(icikt::host::prepare_alloc(c, a.n_feat, S, a.alloc_cols, std::max<int64_t>(c1 - c0, 1)));
     if (a.matrix) {
       c->k0_mask = &a.mask;
@@ -223,13 +231,13 @@ void rank_main(Call& a, int r) {
     c->k0_mask = nullptr;
     c->k0_keep = nullptr;
     RANKCHK(rc_up);
-    icikt::host::prebuild_units(c);   // the task list of this rank's pair block, while its columns are copied
-    RANKCHK_HIP(c->d_out4.reserve((size_t)std::max<int64_t>(a.n_each, 1) * 4));
-    if (a.counts) RANKCHK_HIP(c->d_counts.reserve((size_t)std::max<int64_t>(a.n_each, 1) * ICIKT_CNT_FIELDS));
-    if (a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));
-    if (a.matrix && !a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.n_each, 1)));
+    if (!a.balance) icikt::host::prebuild_units(c);   // the task list of this rank's pair block, while its columns are copied
+    RANKCHK_HIP(c->d_out4.reserve((size_t)std::max<int64_t>(a.slot, 1) * 4));
+    if (a.counts) RANKCHK_HIP(c->d_counts.reserve((size_t)std::max<int64_t>(a.slot, 1) * ICIKT_CNT_FIELDS));
+    if (a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.slot, 1)));
+    if (a.matrix && !a.reasons) RANKCHK_HIP(c->d_reasons.reserve((size_t)std::max<int64_t>(a.slot, 1)));
     if (r == 0 && a.matrix) {
-      RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.n_each * sizeof(int32_t)));
+      RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.slot * sizeof(int32_t)));
       RANKCHK_HIP(c->d_out5.reserve(5 * (size_t)S * (size_t)S));
       RANKCHK_HIP(c->d_red.reserve(8));
       if (a.pi) {   // the assembly needs the WHOLE pair list on the first device (combn order is computed)
@@ -239,11 +247,13 @@ void rank_main(Call& a, int r) {
         RANKCHK(icikt::host::upload_sync(c, c->d_pj_all.p, a.pj, (size_t)a.P * sizeof(int32_t)));
       }
     }
+    if (r == 0 && a.balance && a.matrix)
+      RANKCHK_HIP(grow(&m->root_compact, &m->root_compact_bytes, (size_t)a.P * 4 * sizeof(double) + (size_t)a.P * sizeof(int32_t) + 64));
     if (r == 0) {
-      RANKCHK_HIP(grow(&m->root_out4, &m->root_out4_bytes, (size_t)G * a.n_each * 4 * sizeof(double)));
+      RANKCHK_HIP(grow(&m->root_out4, &m->root_out4_bytes, (size_t)G * a.slot * 4 * sizeof(double)));
       if (a.counts)
-        RANKCHK_HIP(grow(&m->root_counts, &m->root_counts_bytes, (size_t)G * a.n_each * ICIKT_CNT_FIELDS * sizeof(int64_t)));
-      if (a.reasons) RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.n_each * sizeof(int32_t)));
+        RANKCHK_HIP(grow(&m->root_counts, &m->root_counts_bytes, (size_t)G * a.slot * ICIKT_CNT_FIELDS * sizeof(int64_t)));
+      if (a.reasons) RANKCHK_HIP(grow(&m->root_reasons, &m->root_reasons_bytes, (size_t)G * a.slot * sizeof(int32_t)));
     }
     order_slice = (size_t)a.cols_per * (size_t)c->pv.n_ord * sizeof(uint16_t);
     meta_slice = (size_t)a.cols_per * (size_t)c->pv.mstride * sizeof(unsigned long long);
@@ -282,6 +292,67 @@ void rank_main(Call& a, int r) {
     c->prepared = true;
     if (c0 > 0) RANKCHK(icikt_expand_cols_dev(c, 0, c0, 0));
     if (c1 < S) RANKCHK(icikt_expand_cols_dev(c, c1, S, 0));
+    if (a.balance) {
+      // Cost-weighted blocks: the pre-pass leaves with every column what STREAMING it costs a pair-kernel task
+      // (ColStats::flags, bits 8..: hot / MIXED / GROUP steps weighted by their instructions); a pair (i, j) streams j.
+      // Every rank holds every column's statistics now and cuts the list at the same places: consecutive blocks of
+      // equal COST, no block longer than twice the equal share (the result buffers' size).
+      std::vector<int32_t> fl((size_t)S);
+      RANKCHK_HIP(hipMemcpy2DAsync(fl.data(), sizeof(int32_t), &c->pv.col_stats(0)->flags,
+                                   (size_t)c->pv.mstride * sizeof(unsigned long long), sizeof(int32_t), (size_t)S,
+                                   hipMemcpyDeviceToHost, c->stream));
+      RANKCHK_HIP(hipStreamSynchronize(c->stream));
+      std::vector<int64_t> b((size_t)G + 1, 0);
+      {
+        // integer arithmetic throughout: every rank must cut at exactly the same pairs
+        std::vector<uint64_t> cost((size_t)S), pre((size_t)S + 1, 0);   // pre[j] = cost of columns 0 .. j-1
+        for (int64_t j = 0; j < S; ++j) {
+          cost[(size_t)j] = std::max<uint32_t>(1u, (uint32_t)fl[(size_t)j] >> 8);
+          pre[(size_t)j + 1] = pre[(size_t)j] + cost[(size_t)j];
+        }
+        // pair p of the list "starts at" the cost of the pairs before it; block k begins with the first pair that starts
+        // at or beyond total * k / G
+        int k = 1;
+        if (a.pi) {
+          uint64_t total = 0, run = 0;
+          for (int64_t p = 0; p < a.P; ++p) total += cost[(size_t)a.pj[p]];
+          for (int64_t p = 0; p < a.P && k < G; ++p) {
+            while (k < G && run * (uint64_t)G >= total * (uint64_t)k) b[(size_t)k++] = p;
+            run += cost[(size_t)a.pj[p]];
+          }
+        } else {
+          // combn order: row i holds the pairs (i, i + 1 .. S - 1), each streaming its second column; a row costs
+          // pre[S] - pre[i + 1], so whole rows are skipped and a cut is a binary search inside one row
+          uint64_t total = 0, run = 0;
+          for (int64_t j = 1; j < S; ++j) total += cost[(size_t)j] * (uint64_t)j;
+          int64_t p_row = 0;
+          for (int64_t i = 0; i + 1 < S && k < G; ++i) {
+            const uint64_t base = pre[(size_t)i + 1], row_cost = pre[(size_t)S] - base;
+            while (k < G) {
+              const uint64_t target = (total * (uint64_t)k + (uint64_t)G - 1) / (uint64_t)G;   // run' >= total k / G
+              if (target > run + row_cost - cost[(size_t)S - 1]) break;                      // beyond the row's last pair
+              // first j in (i, S) with run + pre[j] - base >= target
+              const uint64_t want = (target > run) ? target - run + base : base;
+              const int64_t j = std::max<int64_t>(i + 1, std::lower_bound(pre.begin() + (i + 1), pre.begin() + S, want) - pre.begin());
+              b[(size_t)k++] = p_row + (j - i - 1);
+            }
+            run += row_cost;
+            p_row += S - 1 - i;
+          }
+        }
+        while (k <= G) b[(size_t)k++] = a.P;
+        for (int q = 1; q <= G; ++q) {   // a block holds at most `slot` pairs, and what is left must fit the ranks behind it
+          b[(size_t)q] = std::min(b[(size_t)q], b[(size_t)q - 1] + a.slot);
+          b[(size_t)q] = std::max(b[(size_t)q], a.P - (int64_t)(G - q) * a.slot);
+          b[(size_t)q] = std::max(b[(size_t)q], b[(size_t)q - 1]);
+        }
+        b[(size_t)G] = a.P;
+      }
+      begin = b[(size_t)r]; end = b[(size_t)r + 1]; P_local = end - begin;
+      if (r == 0) a.bounds = b;   // (the ranks agree; rank 0's copy is the call's record and what phase C reads)
+      if (a.pi) RANKCHK(icikt_set_pairs(c, a.pi + begin, a.pj + begin, P_local));
+      else RANKCHK(icikt_set_pairs_combn(c, S, begin, end));
+    }
     if (a.timing) mark(ICIKT_MULTI_PHASE_EXCHANGE);   // (without the flag the exchange is only enqueued: counted with the pairs)
     RANKCHK(icikt_run_dev(c, a.perspective, a.alternative, a.continuity, a.flags & ~ICIKT_FLAG_TIMING, c->d_out4.p,
                           a.counts ? c->d_counts.p : nullptr, (a.reasons || a.matrix) ? c->d_reasons.p : nullptr));
@@ -300,25 +371,25 @@ void rank_main(Call& a, int r) {
 
   // ---- phase C: gather to rank 0, one D2H -------------------------------------------------------------------
   auto phase_c = [&]() {
-    const size_t n4 = (size_t)a.n_each * 4;
+    const size_t n4 = (size_t)a.slot * 4;
     if (m->rccl) {
       RANKCHK_NCCL(ncclGather(c->d_out4.p, m->root_out4, n4, ncclDouble, 0, m->comms[(size_t)r], c->stream));
       if (a.counts)
-        RANKCHK_NCCL(ncclGather(c->d_counts.p, m->root_counts, (size_t)a.n_each * ICIKT_CNT_FIELDS, ncclInt64, 0,
+        RANKCHK_NCCL(ncclGather(c->d_counts.p, m->root_counts, (size_t)a.slot * ICIKT_CNT_FIELDS, ncclInt64, 0,
                                 m->comms[(size_t)r], c->stream));
       if (a.reasons || a.matrix)
-        RANKCHK_NCCL(ncclGather(c->d_reasons.p, m->root_reasons, (size_t)a.n_each, ncclInt32, 0, m->comms[(size_t)r], c->stream));
+        RANKCHK_NCCL(ncclGather(c->d_reasons.p, m->root_reasons, (size_t)a.slot, ncclInt32, 0, m->comms[(size_t)r], c->stream));
     } else if (r == 0) {
       for (int p = 0; p < G; ++p) {
         RANKCHK_HIP(peer_copy(static_cast<double*>(m->root_out4) + (size_t)p * n4, m->devices[0], a.out4_dev[(size_t)p],
                               m->devices[(size_t)p], n4 * sizeof(double), c->stream));
         if (a.counts)
-          RANKCHK_HIP(peer_copy(static_cast<int64_t*>(m->root_counts) + (size_t)p * a.n_each * ICIKT_CNT_FIELDS, m->devices[0],
+          RANKCHK_HIP(peer_copy(static_cast<int64_t*>(m->root_counts) + (size_t)p * a.slot * ICIKT_CNT_FIELDS, m->devices[0],
                                 a.counts_dev[(size_t)p], m->devices[(size_t)p],
-                                (size_t)a.n_each * ICIKT_CNT_FIELDS * sizeof(int64_t), c->stream));
+                                (size_t)a.slot * ICIKT_CNT_FIELDS * sizeof(int64_t), c->stream));
         if (a.reasons || a.matrix)
-          RANKCHK_HIP(peer_copy(static_cast<int32_t*>(m->root_reasons) + (size_t)p * a.n_each, m->devices[0],
-                                a.reasons_dev[(size_t)p], m->devices[(size_t)p], (size_t)a.n_each * sizeof(int32_t), c->stream));
+          RANKCHK_HIP(peer_copy(static_cast<int32_t*>(m->root_reasons) + (size_t)p * a.slot, m->devices[0],
+                                a.reasons_dev[(size_t)p], m->devices[(size_t)p], (size_t)a.slot * sizeof(int32_t), c->stream));
       }
     }
     if (a.matrix) {
@@ -328,19 +399,49 @@ void rank_main(Call& a, int r) {
         RANKCHK(icikt::host::download(c, a.keep + (size_t)c0 * (size_t)a.n_feat, c->d_keep.p + (size_t)c0 * (size_t)a.n_feat,
                                       (size_t)(c1 - c0) * (size_t)a.n_feat));
       if (r == 0) {
-        RANKCHK_HIP(icikt::launch_out_stats(c->pv, static_cast<const double*>(m->root_out4),
-                                            static_cast<const int32_t*>(m->root_reasons), a.P, nullptr, c->d_red.p, c->stream));
-        RANKCHK_HIP(icikt::launch_assemble(c->pv, static_cast<const double*>(m->root_out4), a.pi ? c->d_pi_all.p : nullptr,
+        const double* all4 = static_cast<const double*>(m->root_out4);
+        const int32_t* allr = static_cast<const int32_t*>(m->root_reasons);
+        if (a.balance) {
+          // cost-weighted blocks have different lengths: the ranks' slots are made one contiguous list, in list order
+          double* c4 = static_cast<double*>(m->root_compact);
+          int32_t* cr = reinterpret_cast<int32_t*>(c4 + (size_t)a.P * 4);
+          for (int p = 0; p < G; ++p) {
+            const size_t len = (size_t)(a.bounds[(size_t)p + 1] - a.bounds[(size_t)p]);
+            if (len == 0) continue;
+            RANKCHK_HIP(hipMemcpyAsync(c4 + (size_t)a.bounds[(size_t)p] * 4, all4 + (size_t)p * n4, len * 4 * sizeof(double),
+                                       hipMemcpyDeviceToDevice, c->stream));
+            RANKCHK_HIP(hipMemcpyAsync(cr + (size_t)a.bounds[(size_t)p], allr + (size_t)p * (size_t)a.slot, len * sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, c->stream));
+          }
+          all4 = c4; allr = cr;
+        }
+        RANKCHK_HIP(icikt::launch_out_stats(c->pv, all4, allr, a.P, nullptr, c->d_red.p, c->stream));
+        RANKCHK_HIP(icikt::launch_assemble(c->pv, all4, a.pi ? c->d_pi_all.p : nullptr,
                                            a.pi ? c->d_pj_all.p : nullptr, a.P, nullptr, c->d_red.p, a.scale_max, a.diag_good,
                                            c->d_out5.p, c->stream));
         RANKCHK(icikt::host::download(c, a.out5, c->d_out5.p, 5 * (size_t)S * (size_t)S * sizeof(double)));
         RANKCHK(icikt::host::download(c, a.red, c->d_red.p, sizeof(a.red)));
       }
-    } else if (r == 0) {
+    } else if (r == 0 && !a.balance) {
       // blocks are consecutive and only the last one is short: the first P records of the gathered array
       RANKCHK(icikt::host::download(c, a.out4, m->root_out4, (size_t)a.P * 4 * sizeof(double)));
       if (a.counts) RANKCHK(icikt::host::download(c, a.counts, m->root_counts, (size_t)a.P * ICIKT_CNT_FIELDS * sizeof(int64_t)));
       if (a.reasons) RANKCHK(icikt::host::download(c, a.reasons, m->root_reasons, (size_t)a.P * sizeof(int32_t)));
+    } else if (r == 0) {
+      // cost-weighted blocks: every rank's slot holds a block of its own length -> one copy per rank and array
+      for (int p = 0; p < G; ++p) {
+        const size_t b0 = (size_t)a.bounds[(size_t)p], len = (size_t)(a.bounds[(size_t)p + 1] - a.bounds[(size_t)p]);
+        if (len == 0) continue;
+        RANKCHK(icikt::host::download(c, a.out4 + b0 * 4, static_cast<const double*>(m->root_out4) + (size_t)p * n4,
+                                      len * 4 * sizeof(double)));
+        if (a.counts)
+          RANKCHK(icikt::host::download(c, a.counts + b0 * ICIKT_CNT_FIELDS,
+                                        static_cast<const int64_t*>(m->root_counts) + (size_t)p * (size_t)a.slot * ICIKT_CNT_FIELDS,
+                                        len * ICIKT_CNT_FIELDS * sizeof(int64_t)));
+        if (a.reasons)
+          RANKCHK(icikt::host::download(c, a.reasons + b0, static_cast<const int32_t*>(m->root_reasons) + (size_t)p * (size_t)a.slot,
+                                        len * sizeof(int32_t)));
+      }
     }
     const hipError_t es = icikt::host::finish_stream(c, true);   // (delivers the bounced results piece by piece as they arrive)
     RANKCHK_HIP(es);
@@ -417,6 +518,7 @@ void icikt_multi_destroy(icikt_multi* m) {
   if (m->root_out4) (void)hipFree(m->root_out4);
   if (m->root_counts) (void)hipFree(m->root_counts);
   if (m->root_reasons) (void)hipFree(m->root_reasons);
+  if (m->root_compact) (void)hipFree(m->root_compact);
   for (icikt_ctx* c : m->ctx) icikt_ctx_destroy(c);
   delete m;
 }
@@ -444,6 +546,13 @@ int icikt_multi_rank_phase_ms(const icikt_multi* m, int rank, double* ms) {
 }
 
 int icikt_multi_ranks_used(const icikt_multi* m) { return m ? m->ranks_used : 0; }
+
+int icikt_multi_block_bounds(const icikt_multi* m, int64_t* bounds) {
+  if (!m || !bounds) return ICIKT_E_INVALID;
+  if ((int)m->bounds.size() != m->ranks_used + 1) return ICIKT_E_STATE;
+  for (size_t k = 0; k < m->bounds.size(); ++k) bounds[k] = m->bounds[k];
+  return ICIKT_SUCCESS;
+}
 
 int icikt_multi_debug_set_plan(icikt_multi* m, const char* spec) {
   if (!m) return ICIKT_E_INVALID;
@@ -474,6 +583,7 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   for (double& v : m->phase_ms) v = 0.0;
   m->rank_ms.assign((size_t)m->n * (ICIKT_MULTI_PHASES + 1), 0.0);
   m->ranks_used = 0;
+  m->bounds.clear();
   if (n_feat < 0 || n_samp < 0 || ld < n_feat) return mfail(m, ICIKT_E_INVALID, "pairs_multi: bad matrix shape");
   if (pi == nullptr) {
     if (pj != nullptr) return mfail(m, ICIKT_E_INVALID, "pairs_multi: pi is null but pj is not");
@@ -498,6 +608,8 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
                                         out4, counts, reasons);
     if (rc) return mfail(m, rc, icikt_last_error(c));
     m->ranks_used = 1;   // the caller can tell (icikt_multi_ranks_used); the whole call is booked as the pairs phase
+    m->bounds.assign(2, 0);
+    m->bounds[1] = n_pairs;
     m->phase_ms[ICIKT_MULTI_PHASE_PAIRS] = m->rank_ms[ICIKT_MULTI_PHASE_PAIRS] = now_ms() - t0;
     return ICIKT_SUCCESS;
   }
@@ -516,6 +628,10 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   Call a{};
   a.m = m; a.X = X; a.n_feat = n_feat; a.n_samp = n_samp; a.ld = ld; a.pi = pi; a.pj = pj; a.P = n_pairs;
   a.n_each = (n_pairs + G - 1) / G;  // ceiling(n_todo / ncore), R/kendalltau.R:250
+  a.balance = (flags & ICIKT_FLAG_BALANCE_COST) != 0;
+  a.slot = a.balance ? std::min<int64_t>(n_pairs, 2 * a.n_each) : a.n_each;
+  a.bounds.assign((size_t)G + 1, 0);
+  for (int r = 0; r <= G; ++r) a.bounds[(size_t)r] = std::min<int64_t>(n_pairs, (int64_t)r * a.n_each);   // (cost-weighted: replaced in phase B)
   a.perspective = perspective; a.alternative = alternative; a.continuity = continuity; a.flags = flags;
   a.out4 = out4; a.counts = counts; a.reasons = reasons;
   a.cols_per = 2 * ((n_samp + 2 * G - 1) / (2 * G));  // even: the rec table interleaves column pairs
@@ -556,6 +672,7 @@ int multi_impl(icikt_multi* m, const double* X, int64_t n_feat, int64_t n_samp, 
   for (auto& t : th) t.join();
   for (icikt_ctx* c : m->ctx) c->host_pinned = false;
   m->ranks_used = G;
+  m->bounds = a.bounds;
   for (int r = 0; r < G; ++r)
     for (int k = 0; k < ICIKT_MULTI_PHASES; ++k)
       m->phase_ms[k] = std::max(m->phase_ms[k], m->rank_ms[(size_t)r * (ICIKT_MULTI_PHASES + 1) + (size_t)k]);

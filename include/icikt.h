@@ -79,6 +79,13 @@ extern "C" {
                                      and never probes caller memory.  Setting it for pageable memory is a caller error
                                      with the consequences of an asynchronous copy from pageable memory. */
 
+#define ICIKT_FLAG_BALANCE_COST 16u /* icikt_pairs_multi_f64 / icikt_matrix_multi_f64: cut the pair list into blocks of equal COST
+                                     instead of equal length.  The reference's chunks are ceiling(n_todo / ncore) pairs each
+                                     (R/kendalltau.R:250-255), and one ici_kt costs the same whatever the data; here a pair's
+                                     cost follows the tie structure of the column it streams (up to 2.5x between columns), and
+                                     the pre-pass leaves that cost with every column.  Blocks stay consecutive in list order
+                                     (no block longer than twice the equal share); results are the same, in the same order. */
+
 /* per-pair reason codes; the host wrapper raises the reference's warnings from them */
 #define ICIKT_OK 0
 #define ICIKT_NA_ALL_MISSING 1   /* src/kendallc.cpp:190-199: silent NA x4 */
@@ -267,6 +274,9 @@ int icikt_multi_rank_phase_ms(const icikt_multi *m, int rank, double *ms);
  * than two columns or 64 pairs per rank, no rows) or had wide columns (n_feat > ICIKT_MAX_FEATURES) and ran on the
  * first device alone; 0 after a call that failed its argument checks. */
 int icikt_multi_ranks_used(const icikt_multi *m);
+/* The pair blocks of the last call: rank r ran pairs [bounds[r], bounds[r + 1]) of the list (ranks_used + 1 values:
+ * the reference's `core` chunks, or the cost-weighted cut of ICIKT_FLAG_BALANCE_COST). */
+int icikt_multi_block_bounds(const icikt_multi *m, int64_t *bounds);
 /* icikt_debug_set_plan() on every rank's context. */
 int icikt_multi_debug_set_plan(icikt_multi *m, const char *spec);
 

@@ -144,3 +144,55 @@ def test_api_n_gpu_argument(single):
     assert list(one["core"]) == [1] * 210 + [0] * 21
     m = api.ici_kendalltau(X, colnames=names, n_gpu=1, perspective="local")
     assert m["cor"].shape == (21, 21)
+
+
+@pytest.mark.parametrize("devices,exchange", [([0, 0, 0, 0], "copy"), ([0, 0, 0], "copy"), ([0], "rccl")])
+def test_cost_weighted_blocks(single, devices, exchange):
+    """ICIKT_FLAG_BALANCE_COST: the pair list is cut into consecutive blocks of equal COST -- the pre-pass leaves with
+    every column what streaming it costs the pair kernel (hot / MIXED / GROUP steps) -- instead of the reference's
+    ceiling(n_todo / ncore) pairs per chunk (R/kendalltau.R:250-255).  The second half of this matrix is tied (its
+    columns cost about twice the continuous ones), so the cut moves; the results, their order, counts and reasons are
+    those of one device, for all pairs of the triangle, an explicit list and the full-matrix entry."""
+    from icikendalltau_amd import _lib
+    rng = np.random.default_rng(17)
+    n, S = 6000, 48
+    X = rng.standard_normal((n, S))
+    X[:, S // 2:] = np.round(X[:, S // 2:] * 300)          # ~2 000 distinct values: MIXED steps when streamed
+    X[rng.random(X.shape) < 0.04] = np.nan
+    X = np.asfortranarray(X)
+    P = S * (S - 1) // 2
+    G = len(devices)
+    m = _lib.MultiContext(devices, exchange=exchange)
+    try:
+        ref = single.pairs(X, perspective="global")
+        eq = m.pairs(X, perspective="global")
+        b_eq = m.block_bounds()
+        _same(eq, ref)
+        got = m.pairs(X, perspective="global", flags=_lib.FLAG_BALANCE_COST)
+        b = m.block_bounds()
+        _same(got, ref)
+        assert m.ranks_used == G and len(b) == G + 1 and b[0] == 0 and b[-1] == P and all(x <= y for x, y in zip(b, b[1:]))
+        each = -(-P // G)
+        assert b_eq == [min(P, r * each) for r in range(G + 1)]
+        assert all(y - x <= 2 * each for x, y in zip(b, b[1:]))
+        if G > 1:
+            # pairs (i, j) stream column j: the late rows of combn order hold tied columns only, the early ones both kinds --
+            # equal-cost blocks are therefore not equal-count blocks
+            assert b != b_eq
+            pi, pj = np.triu_indices(S, k=1)
+            cost = np.where(pj >= S // 2, 2.0, 1.0)          # a model of it: tied columns about twice the cost
+            share = [cost[x:y].sum() / cost.sum() for x, y in zip(b, b[1:])]
+            share_eq = [cost[x:y].sum() / cost.sum() for x, y in zip(b_eq, b_eq[1:])]
+            assert max(share) - min(share) < max(share_eq) - min(share_eq)
+        # an explicit list (unsorted, both orientations) and "local"
+        sel = rng.permutation(P)[:700]
+        iu, ju = np.triu_indices(S, k=1)
+        qi = np.where(rng.random(700) < 0.5, iu[sel], ju[sel]).astype(np.int32)
+        qj = np.where(qi == iu[sel], ju[sel], iu[sel]).astype(np.int32)
+        _same(m.pairs(X, qi, qj, "local", flags=_lib.FLAG_BALANCE_COST), single.pairs(X, qi, qj, "local"))
+        # the full-matrix entry: the first device assembles from blocks of different lengths
+        o5, k5, r5 = m.matrix(X, (float("nan"),), flags=_lib.FLAG_BALANCE_COST)
+        e5, ek5, er5 = single.matrix(X, (float("nan"),))
+        assert np.array_equal(o5, e5, equal_nan=True) and np.array_equal(k5, ek5) and np.array_equal(r5, er5)
+    finally:
+        m.close()

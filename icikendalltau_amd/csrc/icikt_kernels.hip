@@ -642,25 +642,41 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     }
   }
   };   // sort_pass
+  bool starts_done = false;   // the group-start bitset has been made (by the pass behind the one-word sort)
   if constexpr (WIDE) {
     sort_pass(std::false_type{});
   } else {
-    // One-word elements first.  Then the words become what phase 3 reads -- the FULL key and the row of every position
-    // (one gather of the column per position) -- and the order is checked against the full keys: an inversion means two
-    // values of the column share the top 48 bits of their keys and differ below them; the column is then sorted again
-    // with three-word elements (full key, row).  Equal full keys are in row order either way: the row is part of the word.
+    // One-word elements first.  ONE pass then turns the sorted words into what phase 3 needs -- the row of every position
+    // (idx) and the group-start bitset -- from the FULL keys (one gather of the column per position; a position's
+    // predecessor is the lane below, a wave's first lane gathers its predecessor itself), and checks the order against the
+    // full keys on the way: an inversion means two values of the column share the top 48 bits of their keys and differ
+    // below them; the column is then sorted again with three-word elements (full key, row) and the bitset is made from
+    // those.  Equal full keys are in row order either way: the row is part of the word.
     sort_pass(std::true_type{});
-    for (int k = tid; k < n; k += NT) {
-      const uint32_t row = (uint32_t)keys[k] & 0xFFFFu;
-      double v = col[row];
-      if (v != v || mask_excluded(ms, v)) v = fill;
-      keys[k] = sortable_key(v);
-      idx[k] = row;
-    }
-    __syncthreads();
     int inv = 0;
-    for (int k = tid + 1; k < n; k += NT) inv |= (keys[k - 1] > keys[k]) ? 1 : 0;
+    for (int base = 0; base <= ((n >> 6) << 6); base += NT) {
+      const int k = base + tid;
+      unsigned long long fk = 0ull;
+      if (k < n) {
+        const uint32_t row = (uint32_t)keys[k] & 0xFFFFu;
+        double v = col[row];
+        if (v != v || mask_excluded(ms, v)) v = fill;
+        fk = sortable_key(v);
+        idx[k] = row;
+      }
+      unsigned long long prev = __shfl_up(fk, 1, 64);
+      if (lane == 0 && k > 0 && k < n) {
+        double v = col[(uint32_t)keys[k - 1] & 0xFFFFu];
+        if (v != v || mask_excluded(ms, v)) v = fill;
+        prev = sortable_key(v);
+      }
+      const bool st = (k <= n) && (k == 0 || k == n || prev != fk);
+      inv |= (k > 0 && k < n && prev > fk) ? 1 : 0;
+      const unsigned long long b = __ballot(st);
+      if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
+    }
     if (__syncthreads_or(inv)) sort_pass(std::false_type{});
+    else starts_done = true;
   }
 
   // ---- phase 3: tie groups in ascending order -----------------------------------------------------
@@ -672,11 +688,13 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   // gave each thread a run of consecutive positions: the lanes of a wave then read keys and row indices at a
   // stride of 8 n / 1024 bytes, three key loads per position and pass, and carried the open group from thread to
   // thread with two 1 024-wide LDS scans (K0 without its sort: 0.44 of 1.03 ms on c4).
-  for (int base = 0; base <= ((n >> 6) << 6); base += NT) {
-    const int k = base + tid;
-    const bool st = (k <= n) && (k == 0 || k == n || keys[k - 1] != keys[k]);
-    const unsigned long long b = __ballot(st);
-    if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
+  if (!starts_done) {
+    for (int base = 0; base <= ((n >> 6) << 6); base += NT) {
+      const int k = base + tid;
+      const bool st = (k <= n) && (k == 0 || k == n || keys[k - 1] != keys[k]);
+      const unsigned long long b = __ballot(st);
+      if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
+    }
   }
   unsigned long long* sh_big = reinterpret_cast<unsigned long long*>(sh_ll);  // bit k: a group of >= 2 rows starts at k
   for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += NT) {

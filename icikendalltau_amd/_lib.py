@@ -52,7 +52,7 @@ EXPORTS = (
     "icikt_multi_create", "icikt_multi_destroy", "icikt_multi_last_error", "icikt_multi_n_gpu", "icikt_multi_uses_rccl",
     "icikt_pairs_multi_f64", "icikt_multi_phase_ms", "icikt_multi_debug_set_plan",
     "icikt_matrix_f64", "icikt_matrix_multi_f64", "icikt_multi_rank_phase_ms", "icikt_multi_ranks_used",
-    "icikt_debug_step_stats", "icikt_multi_comm_ranks", "icikt_multi_block_bounds",
+    "icikt_debug_step_stats", "icikt_multi_comm_ranks", "icikt_multi_block_bounds", "icikt_cost_blocks",
 )
 
 
@@ -147,6 +147,7 @@ def lib():
     L.icikt_multi_uses_rccl.argtypes = [c_vp]
     L.icikt_multi_comm_ranks.argtypes = [c_vp]
     L.icikt_multi_block_bounds.argtypes = [c_vp, ctypes.POINTER(c_i64)]
+    L.icikt_cost_blocks.argtypes = [c_vp, c_i64, c_vp, c_i64, c_int, c_i64, c_vp]
     L.icikt_pairs_multi_f64.argtypes = L.icikt_pairs_f64.argtypes
     L.icikt_multi_phase_ms.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double)]
     L.icikt_multi_debug_set_plan.argtypes = [c_vp, ctypes.c_char_p]
@@ -396,6 +397,18 @@ class Context:
         self._chk(lib().icikt_missingness_f64(self._h, _ptr(Xf), n_feat, n_samp, max(n_feat, 0), _ptr(pi_a),
                                               _ptr(pj_a), pi_a.shape[0], _ptr(out)), "icikt_missingness_f64")
         return out
+
+
+def cost_blocks(col_cost, n_blocks: int, pj=None, max_block: int = 0):
+    """The cost-weighted cut of the pair list (icikt_cost_blocks; host arithmetic, no device): bounds[0 .. n_blocks]."""
+    cost = np.ascontiguousarray(col_cost, dtype=np.uint32)
+    pj_a = None if pj is None else np.ascontiguousarray(pj, dtype=np.int32)
+    b = np.zeros(n_blocks + 1, dtype=np.int64)
+    rc = lib().icikt_cost_blocks(_ptr(cost), cost.shape[0], _ptr(pj_a), -1 if pj_a is None else pj_a.shape[0], n_blocks,
+                                 int(max_block), _ptr(b))
+    if rc != SUCCESS:
+        raise IciktError(f"icikt_cost_blocks failed (code {rc})")
+    return b.tolist()
 
 
 EXCHANGE = {"auto": 0, "rccl": 1, "copy": 2}

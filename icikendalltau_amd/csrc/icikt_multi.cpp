@@ -90,6 +90,65 @@ struct icikt_multi {
   size_t root_out4_bytes = 0, root_counts_bytes = 0, root_reasons_bytes = 0;
 };
 
+extern "C" int icikt_cost_blocks(const uint32_t* col_cost, int64_t n_samp, const int32_t* pj, int64_t n_pairs, int n_blocks,
+                                 int64_t max_block, int64_t* bounds) {
+  // integer arithmetic throughout: every rank must cut at exactly the same pairs
+  if (!col_cost || !bounds || n_samp < 0 || n_blocks < 1 || (n_pairs >= 0 && n_pairs > 0 && !pj)) return ICIKT_E_INVALID;
+  const int64_t S = n_samp;
+  const int G = n_blocks;
+  const bool list = n_pairs >= 0;
+  const int64_t P = list ? n_pairs : S * (S - 1) / 2;
+  if (max_block <= 0) max_block = P;
+  if ((__int128)max_block * G < (__int128)P) return ICIKT_E_INVALID;   // the blocks could not hold the list
+  std::vector<uint64_t> cost((size_t)std::max<int64_t>(S, 1)), pre((size_t)S + 1, 0);   // pre[j] = cost of columns 0 .. j-1
+  for (int64_t j = 0; j < S; ++j) {
+    cost[(size_t)j] = std::max<uint32_t>(1u, col_cost[(size_t)j]);
+    pre[(size_t)j + 1] = pre[(size_t)j] + cost[(size_t)j];
+  }
+  for (int q = 0; q <= G; ++q) bounds[q] = 0;
+  // pair p of the list "starts at" the cost of the pairs before it; block k begins with the first pair that starts at
+  // or beyond total * k / G
+  int k = 1;
+  if (list) {
+    uint64_t total = 0, run = 0;
+    for (int64_t p = 0; p < P; ++p) {
+      if (pj[p] < 0 || pj[p] >= S) return ICIKT_E_INVALID;
+      total += cost[(size_t)pj[p]];
+    }
+    for (int64_t p = 0; p < P && k < G; ++p) {
+      while (k < G && run * (uint64_t)G >= total * (uint64_t)k) bounds[k++] = p;
+      run += cost[(size_t)pj[p]];
+    }
+  } else if (S >= 2) {
+    // combn order: row i holds the pairs (i, i + 1 .. S - 1), each streaming its second column; a row costs
+    // pre[S] - pre[i + 1], so whole rows are skipped and a cut is a binary search inside one row
+    uint64_t total = 0, run = 0;
+    for (int64_t j = 1; j < S; ++j) total += cost[(size_t)j] * (uint64_t)j;
+    int64_t p_row = 0;
+    for (int64_t i = 0; i + 1 < S && k < G; ++i) {
+      const uint64_t base = pre[(size_t)i + 1], row_cost = pre[(size_t)S] - base;
+      while (k < G) {
+        const uint64_t target = (total * (uint64_t)k + (uint64_t)G - 1) / (uint64_t)G;   // run' >= total k / G
+        if (target > run + row_cost - cost[(size_t)S - 1]) break;                      // beyond the row's last pair
+        // first j in (i, S) with run + pre[j] - base >= target
+        const uint64_t want = (target > run) ? target - run + base : base;
+        const int64_t j = std::max<int64_t>(i + 1, std::lower_bound(pre.begin() + (i + 1), pre.begin() + S, want) - pre.begin());
+        bounds[k++] = p_row + (j - i - 1);
+      }
+      run += row_cost;
+      p_row += S - 1 - i;
+    }
+  }
+  while (k <= G) bounds[k++] = P;
+  for (int q = 1; q <= G; ++q) {   // a block holds at most max_block pairs, and what is left must fit the blocks behind it
+    bounds[q] = std::min(bounds[q], bounds[q - 1] + max_block);
+    bounds[q] = std::max(bounds[q], P - (int64_t)(G - q) * max_block);
+    bounds[q] = std::max(bounds[q], bounds[q - 1]);
+  }
+  bounds[G] = P;
+  return ICIKT_SUCCESS;
+}
+
 namespace {
 
 int mfail(icikt_multi* m, int code, const std::string& msg) {
@@ -304,49 +363,10 @@ void rank_main(Call& a, int r) {
       RANKCHK_HIP(hipStreamSynchronize(c->stream));
       std::vector<int64_t> b((size_t)G + 1, 0);
       {
-        // integer arithmetic throughout: every rank must cut at exactly the same pairs
-        std::vector<uint64_t> cost((size_t)S), pre((size_t)S + 1, 0);   // pre[j] = cost of columns 0 .. j-1
-        for (int64_t j = 0; j < S; ++j) {
-          cost[(size_t)j] = std::max<uint32_t>(1u, (uint32_t)fl[(size_t)j] >> 8);
-          pre[(size_t)j + 1] = pre[(size_t)j] + cost[(size_t)j];
-        }
-        // pair p of the list "starts at" the cost of the pairs before it; block k begins with the first pair that starts
-        // at or beyond total * k / G
-        int k = 1;
-        if (a.pi) {
-          uint64_t total = 0, run = 0;
-          for (int64_t p = 0; p < a.P; ++p) total += cost[(size_t)a.pj[p]];
-          for (int64_t p = 0; p < a.P && k < G; ++p) {
-            while (k < G && run * (uint64_t)G >= total * (uint64_t)k) b[(size_t)k++] = p;
-            run += cost[(size_t)a.pj[p]];
-          }
-        } else {
-          // combn order: row i holds the pairs (i, i + 1 .. S - 1), each streaming its second column; a row costs
-          // pre[S] - pre[i + 1], so whole rows are skipped and a cut is a binary search inside one row
-          uint64_t total = 0, run = 0;
-          for (int64_t j = 1; j < S; ++j) total += cost[(size_t)j] * (uint64_t)j;
-          int64_t p_row = 0;
-          for (int64_t i = 0; i + 1 < S && k < G; ++i) {
-            const uint64_t base = pre[(size_t)i + 1], row_cost = pre[(size_t)S] - base;
-            while (k < G) {
-              const uint64_t target = (total * (uint64_t)k + (uint64_t)G - 1) / (uint64_t)G;   // run' >= total k / G
-              if (target > run + row_cost - cost[(size_t)S - 1]) break;                      // beyond the row's last pair
-              // first j in (i, S) with run + pre[j] - base >= target
-              const uint64_t want = (target > run) ? target - run + base : base;
-              const int64_t j = std::max<int64_t>(i + 1, std::lower_bound(pre.begin() + (i + 1), pre.begin() + S, want) - pre.begin());
-              b[(size_t)k++] = p_row + (j - i - 1);
-            }
-            run += row_cost;
-            p_row += S - 1 - i;
-          }
-        }
-        while (k <= G) b[(size_t)k++] = a.P;
-        for (int q = 1; q <= G; ++q) {   // a block holds at most `slot` pairs, and what is left must fit the ranks behind it
-          b[(size_t)q] = std::min(b[(size_t)q], b[(size_t)q - 1] + a.slot);
-          b[(size_t)q] = std::max(b[(size_t)q], a.P - (int64_t)(G - q) * a.slot);
-          b[(size_t)q] = std::max(b[(size_t)q], b[(size_t)q - 1]);
-        }
-        b[(size_t)G] = a.P;
+        std::vector<uint32_t> cost((size_t)S);
+        for (int64_t j = 0; j < S; ++j) cost[(size_t)j] = (uint32_t)fl[(size_t)j] >> 8;
+        const int rcc = icikt_cost_blocks(cost.data(), S, a.pj, a.pi ? a.P : -1, G, a.slot, b.data());
+        if (rcc != ICIKT_SUCCESS) { a.rc[r] = rcc; a.msg[r] = "cost-weighted blocks: bad arguments"; return; }
       }
       begin = b[(size_t)r]; end = b[(size_t)r + 1]; P_local = end - begin;
       if (r == 0) a.bounds = b;   // (the ranks agree; rank 0's copy is the call's record and what phase C reads)

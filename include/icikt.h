@@ -274,6 +274,12 @@ int icikt_multi_rank_phase_ms(const icikt_multi *m, int rank, double *ms);
  * than two columns or 64 pairs per rank, no rows) or had wide columns (n_feat > ICIKT_MAX_FEATURES) and ran on the
  * first device alone; 0 after a call that failed its argument checks. */
 int icikt_multi_ranks_used(const icikt_multi *m);
+/* The cut of ICIKT_FLAG_BALANCE_COST as a function of its own (host arithmetic only, no device): col_cost[n_samp] = what
+ * streaming each column costs; pj = the list's second indices (n_pairs of them), or n_pairs = -1 for all C(n_samp, 2)
+ * pairs in combn order; n_blocks consecutive blocks of equal cost, none longer than max_block pairs (<= 0: no limit):
+ * bounds[0 .. n_blocks], bounds[0] = 0, bounds[n_blocks] = the number of pairs. */
+int icikt_cost_blocks(const uint32_t *col_cost, int64_t n_samp, const int32_t *pj, int64_t n_pairs, int n_blocks,
+                      int64_t max_block, int64_t *bounds);
 /* The pair blocks of the last call: rank r ran pairs [bounds[r], bounds[r + 1]) of the list (ranks_used + 1 values:
  * the reference's `core` chunks, or the cost-weighted cut of ICIKT_FLAG_BALANCE_COST). */
 int icikt_multi_block_bounds(const icikt_multi *m, int64_t *bounds);

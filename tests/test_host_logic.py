@@ -313,3 +313,46 @@ def test_bench_self_launch_command_line():
     # by torchrun itself; here the child is made to fail at once through an invalid argument)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "nope"], cwd=bench.ROOT, capture_output=True, text=True)
     assert r.returncode != 0 and "invalid choice" in r.stderr
+
+
+def test_cost_weighted_block_cut_arithmetic():
+    """icikt_cost_blocks (the cut behind ICIKT_FLAG_BALANCE_COST; host arithmetic of the C library, no device): against a
+    brute-force walk over the pairs -- block k begins with the first pair whose preceding pairs cost >= total k / G --
+    for all pairs of the triangle (each pair streams its SECOND column) and for explicit lists; block-length limit; and
+    with equal costs the cut is the reference's ceiling(n_todo / ncore) chunks wherever those divide evenly
+    (R/kendalltau.R:250-255)."""
+    from icikendalltau_amd import _lib
+    rng = np.random.default_rng(0)
+
+    def brute(costs, G):
+        tot, run, k, b = sum(costs), 0, 1, [0] * (G + 1)
+        for p, c in enumerate(costs):
+            while k < G and run * G >= tot * k:
+                b[k] = p
+                k += 1
+            run += c
+        while k <= G:
+            b[k] = len(costs)
+            k += 1
+        return b
+
+    for _ in range(200):
+        S, G = int(rng.integers(2, 45)), int(rng.integers(1, 9))
+        cost = rng.integers(1, 60, S).astype(np.uint32)
+        iu, ju = np.triu_indices(S, k=1)
+        assert _lib.cost_blocks(cost, G) == brute([int(cost[j]) for j in ju], G)
+        m = int(rng.integers(1, 400))
+        pj = rng.integers(0, S, m).astype(np.int32)
+        assert _lib.cost_blocks(cost, G, pj=pj) == brute([int(cost[j]) for j in pj], G)
+    # a block-length limit: no block longer than it, all pairs covered, order kept
+    cost = np.array([1] * 20 + [50] * 20, dtype=np.uint32)
+    P = 40 * 39 // 2
+    each = -(-P // 4)
+    b = _lib.cost_blocks(cost, 4, max_block=each + 10)
+    assert b[0] == 0 and b[-1] == P and all(0 <= y - x <= each + 10 for x, y in zip(b, b[1:]))
+    with pytest.raises(_lib.IciktError):
+        _lib.cost_blocks(cost, 4, max_block=10)            # four blocks of ten pairs cannot hold 780
+    # equal costs, lengths that divide evenly: the reference's chunks
+    assert _lib.cost_blocks(np.ones(33, dtype=np.uint32), 4) == [0, 132, 264, 396, 528]
+    with pytest.raises(_lib.IciktError):
+        _lib.cost_blocks(cost, 2, pj=np.array([0, 40], dtype=np.int32))   # a column index outside the matrix

@@ -1941,6 +1941,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
         if (sub == 0) {
           if constexpr (!MIXED) {
+            // (issuing the chain's ds_bpermute in FRONT of the sub-step's reads, so that the chain waits for it alone --
+            //  lgkmcnt(6) -- and runs under the reads' latency, was measured in round 4: no difference at six waves per SIMD)
             inpairs = half_step_count(sw[0], sw[1], lane, partner_addr);
           } else {
             const uint32_t Q = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);    // q of sub-step 0 | q of sub-step 1 << 16

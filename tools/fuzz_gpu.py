@@ -5,7 +5,7 @@ levels, blocks of equal values, constants), a missingness pattern (random, left-
 a K1 launch plan override (pairs per wave, pend placement, half-wave step, joint-tie mode), then compares
 counts bit-exactly and the four doubles within 1e-10 for both perspectives.
 
-    python tools/fuzz_gpu.py [cases] [seed] [big|mid|ext]
+    python tools/fuzz_gpu.py [cases] [seed] [big|mid|ext|r4]
 
 `mid`: 16 000 .. 31 000 rows (both kernel families of 18 337 .. 30 656 rows, the windows of the tie program) with
 two more value models: many small tie groups (n / 2 .. n / 40 distinct values) and a tied region beside a
@@ -25,11 +25,17 @@ ATOL = 1e-10
 BIG = False  # set by main(): argv[3] == 'big'
 MID = False  # set by main(): argv[3] == 'mid'
 EXT = False  # set by main(): argv[3] == 'ext' (the default lengths with the two extra value models)
+R4 = False   # set by main(): argv[3] == 'r4': `ext` + values that collide in the pre-pass's one-word sort (its second pass)
+             # + the pre-pass shape (plan key k0) drawn at random
 
 
 def make_column(rng, n):
-    kind = rng.integers(0, 10 if (MID or EXT) else 8)
-    if kind == 8:  # many small tie groups
+    kind = rng.integers(0, 12 if R4 else 10 if (MID or EXT) else 8)
+    if kind >= 10:  # values that share the top 48 bits of their sortable keys: distinct low bits, ties among them, either sign
+        base = float(rng.choice([1.0, -3.0, 1e-300, 7.5e200]))
+        k = rng.integers(0, int(rng.choice([3, 50, 60000])), n)
+        x = base * (1.0 + k * 2.0 ** -52) if kind == 10 else np.where(rng.random(n) < 0.5, rng.standard_normal(n), base * (1.0 + k * 2.0 ** -50))
+    elif kind == 8:  # many small tie groups
         x = np.round(rng.standard_normal(n) * n / (2.5 * float(rng.choice([2, 4, 8, 24, 40]))))
     elif kind == 9:  # half of the column tied in small groups, half continuous
         x = rng.standard_normal(n)
@@ -95,6 +101,8 @@ def one_case(ctx, rng, case):
         "half": rng.choice(["", "0", "1"]),
         "tgmax": rng.choice(["", "-1", "2", "1000000"]),
     }
+    if R4:
+        env["k0"] = rng.choice(["", "0", "1"])
     ctx.debug_set_plan(env)
     flags = int(rng.random() < 0.25)  # exact int64 sums
     persp = rng.choice(["global", "local"])
@@ -129,7 +137,8 @@ def one_case(ctx, rng, case):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    global BIG, MID, EXT
+    global BIG, MID, EXT, R4
+    R4 = len(sys.argv) > 3 and sys.argv[3] == "r4"
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     MID = len(sys.argv) > 3 and sys.argv[3] == "mid"
     EXT = len(sys.argv) > 3 and sys.argv[3] == "ext"

@@ -399,7 +399,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
-  c->tgroups.release(); c->tprog.release(); c->tmask.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
+  c->tgroups.release(); c->tprog.release(); c->smask.release(); c->srow.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -495,6 +495,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   pv.n_pad = (int)((n_feat + 63) / 64 * 64);
   if (pv.n_pad == 0) pv.n_pad = 64;
   pv.n_ord = pv.n_pad + 256;  // K1 loads rows up to three steps ahead: indices up to n + 191, zero padded
+  pv.rec_rows = pv.n_pad + 8;  // row n_pad: the guard row (PrepView::rec_rows)
   pv.W = (int)((n_feat + 63) / 64);
   pv.Wp = pv.W + 1;
   int np2 = 2;
@@ -519,16 +520,20 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     HIPCHK(c, c->rec.reserve(2));
     HIPCHK(c, c->tgroups.reserve(1));
     HIPCHK(c, c->tprog.reserve(1));
-    HIPCHK(c, c->tmask.reserve(1));
+    HIPCHK(c, c->smask.reserve(1));
+    HIPCHK(c, c->srow.reserve(1));
   } else {
     HIPCHK(c, c->order.reserve(S * pv.n_ord));
-    HIPCHK(c, c->hirow.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // interleaved like rec: [S/2 blocks][n_pad rows][2 columns]
-    HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.n_pad));  // [S/2 blocks][n_pad rows][2 columns]
+    HIPCHK(c, c->hirow.reserve(((S + 1) & ~(size_t)1) * pv.rec_rows));  // interleaved like rec: [S/2 blocks][rec_rows rows][2 columns]
+    HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.rec_rows));  // [S/2 blocks][rec_rows rows][2 columns]
     HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
     // the tie program serves the half-wave kernels only (n <= 18 336); longer columns classify their steps in the pair kernel
     pv.tp_stride = (icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX) ? pv.n_pad + 2 : 0;
     HIPCHK(c, c->tprog.reserve(std::max<size_t>(1, S * (size_t)pv.tp_stride)));
-    HIPCHK(c, c->tmask.reserve(std::max<size_t>(1, pv.tp_stride ? S * (size_t)pv.n_ord : 0)));
+    // a step's record (its rows in lane layout, a MIXED step's same-group masks); + 3 guard steps behind the last one
+    pv.sr_steps = pv.tp_stride ? pv.n_pad / 17 + 8 : 0;
+    HIPCHK(c, c->srow.reserve(std::max<size_t>(1, S * (size_t)pv.sr_steps * 64)));
+    HIPCHK(c, c->smask.reserve(std::max<size_t>(1, S * (size_t)pv.sr_steps * 32)));
   }
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
@@ -539,7 +544,8 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;
   pv.tprog = c->tprog.p;
-  pv.tmask = c->tmask.p;
+  pv.srow = c->srow.p;
+  pv.smask = c->smask.p;
   if (pv.wide) {
     pv.order32 = c->wide32.p;
     pv.q32 = pv.order32 + S * (size_t)pv.n_pad;
@@ -666,8 +672,8 @@ int icikt_prep_arrays(icikt_ctx* c, void** ptrs, int64_t* bytes_per_col) {
   if (c->pv.wide) return fail(c, ICIKT_E_TOO_LONG, std::string("prep_arrays: ") + kNoWide);
   const PrepView& pv = c->pv;
   ptrs[0] = pv.order;    bytes_per_col[0] = (int64_t)pv.n_ord * 2;
-  ptrs[1] = pv.rec;      bytes_per_col[1] = (int64_t)pv.n_pad * 4;
-  ptrs[2] = pv.hirow;    bytes_per_col[2] = (int64_t)pv.n_pad * 2;
+  ptrs[1] = pv.rec;      bytes_per_col[1] = (int64_t)pv.rec_rows * 4;
+  ptrs[2] = pv.hirow;    bytes_per_col[2] = (int64_t)pv.rec_rows * 2;
   ptrs[3] = pv.meta;     bytes_per_col[3] = (int64_t)pv.mstride * 8;
   ptrs[4] = pv.tgroups;  bytes_per_col[4] = (int64_t)pv.tg_stride * 4;
   return ICIKT_SUCCESS;

@@ -76,9 +76,13 @@ struct PrepView {
   int n_samp;
   // per column, stride n_pad
   uint16_t* order;   // [S][n_ord]  row at processing position k (descending value)
-  uint32_t* rec;     // [S/2][n_pad][2]  per row: q | lo << 16  (ascending stable position, group start),
+  int rec_rows;      // rows of a rec / hirow block: n_pad + 8.  Row n_pad is the GUARD ROW of every column: q = n_pad (a
+                     // position in the guard word of a pair kernel's bitset), lo = 0, hi = 0 -- the empty lanes of a step
+                     // of the tie program name it (srow below), so that they gather "a row that never counts, is never
+                     // counted, queries 0 and inserts a bit no query reaches" without an instruction of their own
+  uint32_t* rec;     // [S/2][rec_rows][2]  per row: q | lo << 16  (ascending stable position, group start),
                      // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
-  uint16_t* hirow;   // [S/2][n_pad][2]  per row: last ascending position of its tie group, the columns 2a and 2a+1
+  uint16_t* hirow;   // [S/2][rec_rows][2]  per row: last ascending position of its tie group, the columns 2a and 2a+1
                      // interleaved like rec (a half-wave GROUP step reads both pairs' ends with one 4-byte gather per row)
   // per column, stride Wp
   // per column one record of mstride = 3 * Wp + 9 words (one array: one collective moves it between ranks):
@@ -96,14 +100,22 @@ struct PrepView {
   }
   uint32_t* tgroups;             // [S][tg_stride] tie groups (size >= 2), ascending: lo | hi << 16
   int tg_stride;                 // n_pad / 2 + 1
-  // The tie program of a column as the STREAMED side of a half-wave kernel (n <= 18 336): the steps the pair kernel
+  // The tie program of a column as the STREAMED side of a half-wave kernel (n <= 30 656): the steps the pair kernel
   // takes from where the column's tie groups begin, cut and classified ONCE per column by the pre-pass instead of by
-  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  tmask: per processing position of a row of
-  // a MIXED step, which flags of the pair kernel's in-step compare vectors belong to pairs INSIDE the row's tie group
-  // (x: vector 1, y: vector 2).  Both are functions of gflag: rebuilt, not exchanged, between ranks.
+  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  Round 5: a step comes with its RECORD --
+  //   srow   the rows of the step in the LANE LAYOUT the pair kernel runs it in, 64 entries whatever the step holds
+  //          (HOT / GROUP: lane = row of the step; MIXED: lanes 0..31 the first sub-step, lanes 32..63 the second);
+  //          an empty lane names the guard row (rec_rows above).  The pair kernel reads them three steps ahead like the
+  //          rows of the singleton region: no step re-lays its rows out, rotates its ring or selects guard values;
+  //   smask  MIXED steps: per lane l = 0..31 which flags of the pair kernel's two in-step compare vectors (x: vector 1,
+  //          y: vector 2; both sub-steps of the lane) belong to pairs INSIDE a tie group.
+  // Three guard steps (guard rows only) follow a column's last step: what the pair kernel loads ahead.  All of it is a
+  // function of order and gflag: rebuilt, not exchanged, between ranks.
   uint32_t* tprog;               // [S][tp_stride]; tp_stride = n_pad + 2 (a step takes at least one row; 0 ends the list)
   int tp_stride;
-  uint2* tmask;                  // [S][n_ord]
+  int sr_steps;                  // records per column: n_pad / 17 + 8 (two consecutive steps hold >= 34 rows, see k0_tie_program)
+  uint16_t* srow;                // [S][sr_steps][64]
+  uint2* smask;                  // [S][sr_steps][32]
   // sort scratch (per column of the current chunk)
   unsigned long long* sort_keys;  // [chunk][npow2]
   uint32_t* sort_idx;             // [chunk][npow2]

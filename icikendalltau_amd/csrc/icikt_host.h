@@ -44,11 +44,11 @@ struct icikt_ctx {
   // prepared matrix
   bool prepared = false;
   icikt::PrepView pv{};
-  DevBuf<uint16_t> order, hirow;
+  DevBuf<uint16_t> order, hirow, srow;
   DevBuf<uint32_t> wide32;                 // wide columns: order32 | q32 | lo32 | hi32, S x n_pad each
   DevBuf<unsigned long long> k0_bits;      // wide columns: K0's phase-3 bitsets, per column of a sort chunk
   DevBuf<uint32_t> rec, tgroups, tprog;
-  DevBuf<uint2> tmask;
+  DevBuf<uint2> smask;
   DevBuf<unsigned long long> meta, sort_keys;
   DevBuf<uint32_t> sort_idx;
   int sort_chunk = 0;

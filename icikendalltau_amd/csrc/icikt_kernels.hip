@@ -151,6 +151,7 @@ constexpr int K0_THREADS_SMALL = 256;
 #ifndef ICIKT_K0_WAVES_SMALL
 #define ICIKT_K0_WAVES_SMALL 5    // the small shape is compiled for five waves per SIMD (<= 96 registers): a wave of it fits a SIMD on which ONE pair-kernel wave (80 of 512 registers, six resident) has retired
 #endif
+constexpr int K0_UB = 8;       // iterations of a column pass whose loads a thread issues together
 constexpr int K0_TILE = 4096;  // elements of the LDS-resident sort tile (48 KB) = threads x elements per thread of the standard shapes
 
 
@@ -373,7 +374,7 @@ __device__ __forceinline__ uint32_t k0_step_at(const unsigned long long* gf, int
 // the same-group flag masks of the rows of the MIXED step that starts at pos (entry e): one lane per row
 // (returns the class of the step's largest group, wave-uniform: half_step_flags_near)
 __device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, const uint32_t* crossT, int n, int W, int pos,
-                                                  uint32_t e, uint2* tmask, uint32_t lane) {
+                                                  uint32_t e, uint2& m_out, uint32_t lane) {
   const uint32_t b0 = tprog_n0(e), b1 = tprog_rows(e) - b0;
   const uint32_t sb = lane >> 5, l = lane & 31u;
   const bool vrow = l < (sb ? b1 : b0);          // (every lane of the wave stays: the step's largest group is a wave maximum)
@@ -391,6 +392,7 @@ __device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, 
   // class of the step's largest group: which distances of the pair kernel's second flag chain can hold a pair of one group
   const int gmax = __builtin_amdgcn_readfirstlane(wave_max_i32(vrow ? (int)(idx + fwd + 1u) : 0));
   const uint32_t cls = (gmax <= 3) ? 0u : (gmax <= 5) ? 1u : (gmax <= 9) ? 2u : 3u;
+  m_out = make_uint2(0u, 0u);
   if (!vrow) return cls;
   const uint32_t p = l & 15u;
   const uint32_t c = min(min(idx, p), 15u);                                       // in-row partners inside my group
@@ -400,21 +402,27 @@ __device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, 
   uint2 m;
   m.x = ((b1m | (t & 0x80u)) << sh) | (a1 << (16u + sh));
   m.y = ((t & 0x70u) << sh) | (((t >> 8) & 0x70u) << (16u + sh)) | ((t & 0x10000u) ? (0x8000u << (16u * sb)) : 0u);
-  tmask[(uint32_t)pos + o] = m;
+  m_out = m;
   return cls;
 }
 
 // The whole workgroup builds the program, a WINDOW of TPROG_WIN positions at a time: (A) every position's would-be step,
 // in parallel, into E (u16 per position of the window, LDS); (B) one wave follows the chain from where it stands -- one
 // LDS read per step instead of a hundred dependent scalar operations -- while the step STARTS inside the window, writes
-// the entries and lists the MIXED steps; (C) the waves share out the window's MIXED steps and write their rows' masks.
-// scratch: E (TPROG_WIN u16) | list of MIXED step positions (TPROG_LIST u16: a MIXED step of complete groups that does
-// not reach 33 rows is followed by a longer group, so a window starts at most TPROG_WIN / 17 of them) | crossT (32 x 64
-// u32); `cnt`: four shared ints (MIXED steps of the window; the chain's position and entry count between windows; the
+// the entries and lists the steps; (C) the waves share out the window's steps and write their RECORDS (PrepView::srow,
+// smask): the step's rows in the lane layout the pair kernel runs it in -- an empty lane names the guard row -- and, for
+// a MIXED step, per lane l = 0..31 the same-group masks of its two rows (sub-step 0: lane l, sub-step 1: lane l + 32).
+// Steps per window: a MIXED step that does not reach 33 rows is followed by a group of more than 32 rows, and a closing
+// GROUP step that does not reach 33 rows follows a 64-row piece of its group: any two consecutive steps hold >= 34 rows
+// -- at most TPROG_WIN / 17 + 1 steps start in a window, n / 17 + 2 in a column (PrepView::sr_steps has room for them and
+// for the three guard steps behind the last one: what the pair kernel loads ahead).
+// scratch: E (TPROG_WIN u16) | list of the window's steps (TPROG_LIST pairs of u16: window offset, entry index) | crossT
+// (32 x 64 u32); `cnt`: four shared ints (steps of the window; the chain's position and entry count between windows; the
 // column's streaming cost, see below).
-constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;   // (list: TPROG_LIST pairs of u16 -- window offset, entry index)
+constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;
 __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
-                                      int n, int W, uint32_t* prog, uint2* tmask, int tid, int nthreads) {
+                                      int n, int W, uint32_t* prog, const uint16_t* ord, uint16_t* srow, uint2* smask,
+                                      int sr_steps, uint32_t guard_row, int tid, int nthreads) {
   const uint32_t lane = (uint32_t)tid & 63u;
   const int wave = tid >> 6, nwaves = nthreads >> 6;
   k0_cross_table(crossT, tid, nthreads);
@@ -427,7 +435,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     }
     first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
     const int hot_until = (first_cont < n) ? first_cont - 1 : n;
-    // cnt[3]: what streaming this column costs a pair, in half hot steps (a hot step of 64 rows = 2, a MIXED step = 4, a
+    // cnt[3]: what streaming this column costs a pair, in half hot steps (a hot step of 64 rows = 2, a MIXED step = 3, a
     // GROUP step = 3: their vector instructions): the singleton region now, the program's steps below
     if (lane == 0u) { cnt[1] = (hot_until >> 6) << 6; cnt[2] = 0; cnt[3] = 2 * (hot_until >> 6); }
   }
@@ -437,33 +445,54 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     for (int p = win + tid; p < wend; p += nthreads) E[p - win] = (uint16_t)k0_step_at(gf, n, W, p);
     __syncthreads();
     if (wave == 0) {
-      int pos = cnt[1], ne = cnt[2], nm = 0, cost = cnt[3];
+      int pos = cnt[1], ne = cnt[2], ns = 0, cost = cnt[3];
       while (pos < wend) {
         const uint32_t e = (uint32_t)E[pos - win];
-        cost += (tprog_kind(e) == TPROG_KIND_MIXED) ? 4 : (tprog_kind(e) == TPROG_KIND_GROUP) ? 3 : 2;
+        cost += (tprog_kind(e) == TPROG_KIND_HOT) ? 2 : 3;
         if (lane == 0u) {
           prog[ne] = e;
-          if (tprog_kind(e) == TPROG_KIND_MIXED) { mlist[2 * nm] = (uint16_t)(pos - win); mlist[2 * nm + 1] = (uint16_t)ne; }
+          if (ns < TPROG_LIST) { mlist[2 * ns] = (uint16_t)(pos - win); mlist[2 * ns + 1] = (uint16_t)ne; }
         }
-        nm += (tprog_kind(e) == TPROG_KIND_MIXED) ? 1 : 0;
+        ++ns;
         ++ne;
         pos += (int)tprog_rows(e);
       }
       if (lane == 0u) {
         if (wend == n) prog[ne] = 0u;
-        cnt[0] = nm; cnt[1] = pos; cnt[2] = ne; cnt[3] = cost;
+        cnt[0] = min(ns, TPROG_LIST); cnt[1] = pos; cnt[2] = ne; cnt[3] = cost;
       }
     }
     __syncthreads();
-    const int nm = cnt[0];
-    for (int i = wave; i < nm; i += nwaves) {
+    const int ns = cnt[0];
+    for (int i = wave; i < ns; i += nwaves) {
       const int pos = win + (int)mlist[2 * i];
-      const uint32_t cls = k0_step_masks(gf, crossT, n, W, pos, (uint32_t)E[pos - win], tmask, lane);
-      // the class of the step's largest group rides in the step's entry (bits 16..17), which the pair kernel holds two
-      // steps ahead; the entry was written by wave 0 before the barrier above
-      if (lane == 0u && cls != 0u) prog[mlist[2 * i + 1]] |= cls << 16;
+      const int st = (int)mlist[2 * i + 1];
+      if (st + 3 >= sr_steps) continue;   // (cannot happen: the bound above)
+      const uint32_t e = (uint32_t)E[pos - win];
+      const uint32_t rows = tprog_rows(e);
+      if (tprog_kind(e) == TPROG_KIND_MIXED) {
+        const uint32_t b0 = tprog_n0(e), sb = lane >> 5, l = lane & 31u;
+        const bool vrow = l < (sb ? rows - b0 : b0);
+        srow[st * 64 + (int)lane] = (uint16_t)(vrow ? (uint32_t)ord[(uint32_t)pos + (sb ? b0 + l : l)] : guard_row);
+        uint2 m;
+        const uint32_t cls = k0_step_masks(gf, crossT, n, W, pos, e, m, lane);
+        m.x |= (uint32_t)__shfl_xor((int)m.x, 32, 64);
+        m.y |= (uint32_t)__shfl_xor((int)m.y, 32, 64);
+        if (lane < 32u) smask[st * 32 + (int)lane] = m;
+        // the class of the step's largest group rides in the step's entry (bits 16..17), which the pair kernel holds two
+        // steps ahead; the entry was written by wave 0 before the barrier above
+        if (lane == 0u && cls != 0u) prog[st] |= cls << 16;
+      } else {
+        srow[st * 64 + (int)lane] = (uint16_t)((lane < rows) ? (uint32_t)ord[(uint32_t)pos + lane] : guard_row);
+      }
     }
     __syncthreads();   // (E and the list are rewritten by the next window)
+  }
+  // three guard steps behind the last one (the pair kernel reads its rows three steps ahead)
+  {
+    const int ne = cnt[2];
+    if (ne + 3 <= sr_steps)
+      for (int i = tid; i < 192; i += nthreads) srow[ne * 64 + i] = (uint16_t)guard_row;
   }
 }
 
@@ -500,8 +529,9 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   unsigned long long* fmask = pv.col_fillmask(c);
   unsigned long long* gflag = pv.col_gflag(c);
   uint16_t* order = WIDE ? nullptr : pv.order + (int64_t)c * pv.n_ord;
-  uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);  // [block][row][2]: stride 2
-  uint16_t* hirow = WIDE ? nullptr : pv.hirow + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);            // [block][row][2]: stride 2
+  uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);  // [block][row][2]: stride 2
+  uint16_t* hirow = WIDE ? nullptr : pv.hirow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);            // [block][row][2]: stride 2
+  if (!WIDE && tid == 0) { rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; }   // the guard row (PrepView::rec_rows)
   uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
   uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
@@ -514,17 +544,32 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   double tmin = __longlong_as_double(0x7FF0000000000000ll);  // +Inf
   int nna = 0, nexcl = 0;
   uint8_t* keep_c = keep ? keep + (int64_t)c * n : nullptr;
-  for (int base = 0; base < pv.n_pad; base += NT) {
-    const int i = base + tid;
-    const double v = (i < n) ? col[i] : 0.0;
-    const bool excl = (i < n) && mask_excluded(ms, v);
-    const bool isna = (i < n) && (excl || v != v);
-    nexcl += excl ? 1 : 0;
-    if (keep_c && i < n) keep_c[i] = excl ? 0 : 1;
-    const unsigned long long b = __ballot(isna);
-    if (lane == 0 && (i >> 6) < W) mask[i >> 6] = b;
-    if (i < n && !isna) tmin = (v < tmin) ? v : tmin;
-    nna += isna ? 1 : 0;
+  // (The passes over the column are BLOCKED: a thread issues the loads of K0_UB iterations, then consumes them.  One
+  //  workgroup per CU hides no latency by itself, and with a ballot in the loop body the compiler keeps one load in
+  //  flight per thread: a pass then cost one memory round trip per iteration -- ten for 10 000 rows -- and the passes
+  //  outside the sort were half of the kernel's time.)
+  for (int base0 = 0; base0 < pv.n_pad; base0 += NT * K0_UB) {
+    double vv[K0_UB];
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+      const int i = base0 + u * NT + tid;
+      vv[u] = (i < n) ? col[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+      if (base0 + u * NT < pv.n_pad) {   // (uniform over the workgroup: the ballot runs with every lane)
+        const int i = base0 + u * NT + tid;
+        const double v = vv[u];
+        const bool excl = (i < n) && mask_excluded(ms, v);
+        const bool isna = (i < n) && (excl || v != v);
+        nexcl += excl ? 1 : 0;
+        if (keep_c && i < n) keep_c[i] = excl ? 0 : 1;
+        const unsigned long long b = __ballot(isna);
+        if (lane == 0 && (i >> 6) < W) mask[i >> 6] = b;
+        if (i < n && !isna) tmin = (v < tmin) ? v : tmin;
+        nna += isna ? 1 : 0;
+      }
+    }
   }
   if (tid == 0) { mask[W] = 0ull; }
   // plain double min (no NaN among candidates), the missing and the excluded rows: one batch, two barriers
@@ -550,18 +595,30 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   // ---- phases 1b + 2: sortable keys, sort.  FAST: one word per element (top 48 key bits | row), see kv_gt ------
   auto sort_pass = [&](auto fast_tag) {
   constexpr bool FAST = decltype(fast_tag)::value;
-  for (int i = tid; i < npow2; i += NT) {
-    unsigned long long k = ~0ull;
-    uint32_t id = 0xFFFFFFFFu;
-    if (i < n) {
-      double v = col[i];
-      if (v != v || mask_excluded(ms, v)) v = fill;
-      k = sortable_key(v);
-      if (FAST) k = (k & ~0xFFFFull) | (unsigned long long)i;    // (n <= 65 535: the row fits the low 16 bits)
-      id = (uint32_t)i;
+  for (int base0 = 0; base0 < npow2; base0 += NT * K0_UB) {
+    double vv[K0_UB];
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+      const int i = base0 + u * NT + tid;
+      vv[u] = (i < n) ? col[i] : 0.0;
     }
-    keys[i] = k;
-    if (!FAST) idx[i] = id;
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+      const int i = base0 + u * NT + tid;
+      if (i < npow2) {
+        unsigned long long k = ~0ull;
+        uint32_t id = 0xFFFFFFFFu;
+        if (i < n) {
+          double v = vv[u];
+          if (v != v || mask_excluded(ms, v)) v = fill;
+          k = sortable_key(v);
+          if (FAST) k = (k & ~0xFFFFull) | (unsigned long long)i;    // (n <= 65 535: the row fits the low 16 bits)
+          id = (uint32_t)i;
+        }
+        keys[i] = k;
+        if (!FAST) idx[i] = id;
+      }
+    }
   }
   __syncthreads();
 
@@ -654,26 +711,45 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     // those.  Equal full keys are in row order either way: the row is part of the word.
     sort_pass(std::true_type{});
     int inv = 0;
-    for (int base = 0; base <= ((n >> 6) << 6); base += NT) {
-      const int k = base + tid;
-      unsigned long long fk = 0ull;
-      if (k < n) {
-        const uint32_t row = (uint32_t)keys[k] & 0xFFFFu;
-        double v = col[row];
-        if (v != v || mask_excluded(ms, v)) v = fill;
-        fk = sortable_key(v);
-        idx[k] = row;
+    for (int base0 = 0; base0 <= ((n >> 6) << 6); base0 += NT * K0_UB) {
+      // two dependent loads per position (the sorted word, then the value of its row): issued K0_UB positions at a time
+      uint32_t rowv[K0_UB], rowp[K0_UB];
+      double vv[K0_UB], vp[K0_UB];
+#pragma unroll
+      for (int u = 0; u < K0_UB; ++u) {
+        const int k = base0 + u * NT + tid;
+        rowv[u] = (k < n) ? ((uint32_t)keys[k] & 0xFFFFu) : 0u;
+        rowp[u] = (lane == 0 && k > 0 && k < n) ? ((uint32_t)keys[k - 1] & 0xFFFFu) : 0u;   // a wave's first lane: its predecessor too
       }
-      unsigned long long prev = __shfl_up(fk, 1, 64);
-      if (lane == 0 && k > 0 && k < n) {
-        double v = col[(uint32_t)keys[k - 1] & 0xFFFFu];
-        if (v != v || mask_excluded(ms, v)) v = fill;
-        prev = sortable_key(v);
+#pragma unroll
+      for (int u = 0; u < K0_UB; ++u) {
+        const int k = base0 + u * NT + tid;
+        vv[u] = (k < n) ? col[rowv[u]] : 0.0;
+        vp[u] = (lane == 0 && k > 0 && k < n) ? col[rowp[u]] : 0.0;
       }
-      const bool st = (k <= n) && (k == 0 || k == n || prev != fk);
-      inv |= (k > 0 && k < n && prev > fk) ? 1 : 0;
-      const unsigned long long b = __ballot(st);
-      if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
+#pragma unroll
+      for (int u = 0; u < K0_UB; ++u) {
+        if (base0 + u * NT <= ((n >> 6) << 6)) {   // (uniform over the workgroup)
+          const int k = base0 + u * NT + tid;
+          unsigned long long fk = 0ull;
+          if (k < n) {
+            double v = vv[u];
+            if (v != v || mask_excluded(ms, v)) v = fill;
+            fk = sortable_key(v);
+            idx[k] = rowv[u];
+          }
+          unsigned long long prev = __shfl_up(fk, 1, 64);
+          if (lane == 0 && k > 0 && k < n) {
+            double v = vp[u];
+            if (v != v || mask_excluded(ms, v)) v = fill;
+            prev = sortable_key(v);
+          }
+          const bool st = (k <= n) && (k == 0 || k == n || prev != fk);
+          inv |= (k > 0 && k < n && prev > fk) ? 1 : 0;
+          const unsigned long long b = __ballot(st);
+          if (lane == 0 && (k >> 6) <= (n >> 6)) sh_st[k >> 6] = b;
+        }
+      }
     }
     if (__syncthreads_or(inv)) sort_pass(std::false_type{});
     else starts_done = true;
@@ -726,12 +802,21 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0, oddtie = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
   long long e0 = 0, e1 = 0, e2 = 0;     // exact
-  for (int base = 0; base < n; base += NT) {
-    const int k = base + tid;
+  for (int base0 = 0; base0 < n; base0 += NT * K0_UB) {
+    uint32_t rows[K0_UB];
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+      const int k = base0 + u * NT + tid;
+      rows[u] = (k < n) ? idx[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < K0_UB; ++u) {
+    if (base0 + u * NT >= n) break;   // (uniform over the workgroup)
+    const int k = base0 + u * NT + tid;
     bool big = false;
     if (k < n) {
       const int lo = prev_start(k), hi = next_start(k) - 1;
-      const uint32_t row = idx[k];
+      const uint32_t row = rows[u];
       if (WIDE) {
         hi32[row] = (uint32_t)hi; q32[row] = (uint32_t)k; lo32[row] = (uint32_t)lo;
         order32[n - 1 - k] = row;
@@ -766,6 +851,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     }
     const unsigned long long bb = __ballot(big);
     if (!WIDE && lane == 0 && (k >> 6) < 1024) sh_big[k >> 6] = bb;
+    }
   }
   __syncthreads();
   if (stage_rec) {
@@ -802,8 +888,9 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     uint16_t* Ewin = reinterpret_cast<uint16_t*>(sh_sort);
     uint32_t* crossT = reinterpret_cast<uint32_t*>(Ewin + TPROG_WIN);
     uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
-    k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
-                   pv.tmask + (int64_t)c * pv.n_ord, tid, NT);
+    k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride, order,
+                   pv.srow + (int64_t)c * pv.sr_steps * 64, pv.smask + (int64_t)c * pv.sr_steps * 32, pv.sr_steps,
+                   (uint32_t)pv.n_pad, tid, NT);
     stream_cost = sh_i[3];   // (every thread reads it; thread 0 stores it with the statistics)
     __syncthreads();   // (sh_i is used by the reductions below)
   }
@@ -938,9 +1025,10 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   const int n = pv.n, W = pv.W, Wp = pv.Wp;
   const unsigned long long* gf = pv.col_gflag(c);
   const uint16_t* ord = pv.order + (int64_t)c * pv.n_ord;
-  uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
-  uint16_t* hirow = pv.hirow + ((int64_t)(c >> 1) * pv.n_pad) * 2 + (c & 1);
+  uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);
+  uint16_t* hirow = pv.hirow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);
   uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
+  if (threadIdx.x == 0) { rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; }   // the guard row (PrepView::rec_rows)
 
   // starts of groups of size >= 2: a start whose successor position exists and is not a start
   auto multi = [&](int w) -> unsigned long long {
@@ -1020,8 +1108,9 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     unsigned long long* gfl = reinterpret_cast<unsigned long long*>(prevs);   // the scan arrays are free now: 1032 ints = 516 words
     for (int w = (int)threadIdx.x; w <= W; w += 64 * KX_WAVES) gfl[w] = gf[w];
     __syncthreads();
-    k0_tie_program(gfl, kx_E, kx_list, kx_cross, kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride,
-                   pv.tmask + (int64_t)c * pv.n_ord, (int)threadIdx.x, 64 * KX_WAVES);
+    k0_tie_program(gfl, kx_E, kx_list, kx_cross, kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride, ord,
+                   pv.srow + (int64_t)c * pv.sr_steps * 64, pv.smask + (int64_t)c * pv.sr_steps * 32, pv.sr_steps,
+                   (uint32_t)pv.n_pad, (int)threadIdx.x, 64 * KX_WAVES);
   }
 }
 
@@ -1759,14 +1848,14 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t* hi_blk;   // the block's tie-group ends: hi of column 2a | hi of column 2a + 1 << 16 per row
   {
     const int g0 = __builtin_amdgcn_readfirstlane(pi[pidx[0]]);
-    rec_blk = pv.rec + ((int64_t)(g0 >> 1) * pv.n_pad) * 2;
-    hi_blk = reinterpret_cast<const uint32_t*>(pv.hirow + ((int64_t)(g0 >> 1) * pv.n_pad) * 2);
+    rec_blk = pv.rec + ((int64_t)(g0 >> 1) * pv.rec_rows) * 2;
+    hi_blk = reinterpret_cast<const uint32_t*>(pv.hirow + ((int64_t)(g0 >> 1) * pv.rec_rows) * 2);
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int gcol = __builtin_amdgcn_readfirstlane(pi[pidx[k]]);
     comp[k] = (uint32_t)(gcol & 1);
-    hiG[k] = pv.hirow + ((int64_t)(gcol >> 1) * pv.n_pad) * 2 + (gcol & 1);   // interleaved like rec: index 2 * row
+    hiG[k] = pv.hirow + ((int64_t)(gcol >> 1) * pv.rec_rows) * 2 + (gcol & 1);   // interleaved like rec: index 2 * row
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
     // (a closing group's joint ties are counted with at most four / two listed groups per lane: half-wave / whole-wave kernels)
@@ -1866,11 +1955,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   int fw_word = -1;
   // half-wave kernels: the streamed column's tie program and group offsets (PrepView::tprog / gidx)
   const uint32_t* tprog_col = half_mode ? pv.tprog + (int64_t)scol * pv.tp_stride : nullptr;
-  const uint2* tmask_col = half_mode ? pv.tmask + (int64_t)scol * pv.n_ord : nullptr;
+  // ... and the steps' records: their rows in lane layout (read three steps ahead, like the rows of the singleton region:
+  // from the first program step on the ring r0 r1 r2 holds records, not positions of `ord`) and the MIXED steps' masks
+  const uint16_t* srow_col = half_mode ? pv.srow + (int64_t)scol * pv.sr_steps * 64 : nullptr;
+  const uint2* smask_col = half_mode ? pv.smask + (int64_t)scol * pv.sr_steps * 32 : nullptr;
   uint32_t tp_a = 0u, tp_b = 0u;   // entries of this step and the next, fetched two steps ahead (vector loads: see below)
-  int tp_idx = 0;
+  int tp_step = 0;                 // index of the program step that starts now
   bool tp_ok = false;
-  int pre_n0 = 32;                 // row layout of the prefetched gather: sub-step 1 starts n0 rows in (32: lane = row)
   // the ring moves on by a 64-row step: next step's rows are in r1 already -> gather its rec values now
   // (the gather is issued BEFORE the row load: vector loads return in order, so waiting for the gather at the top of
   //  the next step -- vmcnt(1) -- leaves the three-steps-ahead row load in flight)
@@ -1880,15 +1971,6 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
     r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
     rk_ok = true;
-  };
-  // MIXED steps of a half-wave kernel lay their rows out in two sub-steps: lanes 0..31 take the step's rows 0..31,
-  // lanes 32..63 the rows n0 .. n0 + 31 (n0 = rows of the first sub-step; n0 == 32: lane = row)
-  auto layout_rows = [&](uint32_t rows, int n0) -> uint32_t {
-    if (n0 == 32) return rows;
-    uint32_t lane_t = lane;
-    asm volatile("" : "+v"(lane_t));
-    const uint32_t o = (lane_t < 32u) ? lane_t : (uint32_t)n0 + lane_t - 32u;   // < 64: inside the ring's first register
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o << 2), (int)rows);
   };
   auto take_rk = [&](uint32_t (&rk)[NP]) {   // the prefetched values of the step that starts now
     if (NP == 2) {
@@ -2192,15 +2274,32 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       hi_ok = false;
       continue;
     }
+    if constexpr (half_mode) {
+      // The step comes from the streamed column's TIE PROGRAM (k0_tie_program: cut and classified once per column by
+      // the pre-pass, the list starts where the singleton loop above ends): one dword per step, fetched TWO steps
+      // ahead by vector loads (a scalar load would make every wait for LDS data in the step a full drain), and the
+      // step's RECORD: its rows in the lane layout it runs in (empty lanes: the guard row), three steps ahead.
+      if (!tp_ok) {   // the first program step: the ring turns from positions of `ord` to records (one exposed gather per task)
+        uint32_t off = 0u;
+        asm volatile("" : "+v"(off));
+        tp_a = gload_u32(tprog_col, off);
+        tp_b = gload_u32(tprog_col, off + 1u);
+        r0 = gload_u16(srow_col, lane);
+        r1 = gload_u16(srow_col, 64u + lane);
+        r2 = gload_u16(srow_col, 128u + lane);
+        rv_pre = gload_rec2(rec_blk, r0);
+        tp_step = 0;
+        tp_ok = true;
+        rk_ok = true;
+        hi_ok = false;
+      }
+    }
     const uint32_t row = r0;
     const uint32_t hi_now = hi_pre;
     const bool hi_now_ok = hi_ok;
     uint32_t rk[NP];
     if (rk_ok) {
       take_rk(rk);
-    } else if (half_mode) {   // gathered below, once the step's row layout is known
-#pragma unroll
-      for (int k = 0; k < NP; ++k) rk[k] = 0u;
     } else if (NP == 2) {  // after a short step: gather now, its latency runs behind the window logic
       const uint2 rv = gload_rec2(rec_blk, row);
 #pragma unroll
@@ -2213,47 +2312,24 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     unsigned long long F;
     int kind = 0;          // 0: hot step or the general step (decided below), 1: MIXED, 2: GROUP (fast tie steps)
     bool closes = true;    // GROUP: the step holds the group's last row
-    int n0 = 32;           // MIXED (half-wave kernels): rows of the first sub-step (the second one starts at lane 32)
     uint32_t e_next = 0u;  // half-wave kernels: the next step's program entry
-    uint2 tmx = make_uint2(0u, 0u);   // MIXED (half-wave kernels): the row's same-group flag masks
+    uint2 tmx = make_uint2(0u, 0u);   // MIXED (half-wave kernels): the lane's same-group flag masks
     if constexpr (half_mode) {
-      // The step comes from the streamed column's TIE PROGRAM (k0_tie_program: cut and classified once per column by
-      // the pre-pass, the list starts where the singleton loop above ends): one dword per step, fetched TWO steps
-      // ahead by vector loads (a scalar load would make every wait for LDS data in the step a full drain) -- the next
-      // step's entry is needed now, to lay out and gather its rows during this step.
-      if (!tp_ok) {
-        uint32_t off = 0u;
-        asm volatile("" : "+v"(off));
-        tp_a = gload_u32(tprog_col, off);
-        tp_b = gload_u32(tprog_col, off + 1u);
-        tp_idx = 1;
-        tp_ok = true;
-      }
       const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_a);
       e_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp_b);
       tp_a = tp_b;
       {
-        uint32_t off = (uint32_t)(++tp_idx);
+        uint32_t off = (uint32_t)(tp_step + 2);
         asm volatile("" : "+v"(off));
         tp_b = gload_u32(tprog_col, off);
       }
       nact = (int)tprog_rows(e);
       kind = (int)tprog_kind(e);
       closes = tprog_closes(e);
-      n0 = (kind == 1) ? (int)tprog_n0(e) : 32;
       Fn = (kind == 2) ? closes : true;
       F = (kind == 0) ? ~0ull : 0ull;     // (only `all_fast` below looks at it)
-      if (pre_n0 != n0 || !rk_ok) {       // the first program step only: the singleton loop gathered for lane = row
-        const uint2 rv = gload_rec2(rec_blk, layout_rows(row, n0));
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rk[k] = comp[(NP == 2) ? k : 0] ? rv.y : rv.x;
-      }
       if (kind == 1) {   // which flags of the in-step compare belong to pairs inside a tie group (consumed behind the chains)
-        uint32_t lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        const uint32_t o = (lane_t < 32u) ? lane_t : (uint32_t)n0 + lane_t - 32u;
-        const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
-        tmx = vrow ? tmask_col[(uint32_t)pos + o] : make_uint2(0u, 0u);
+        tmx = smask_col[(uint32_t)tp_step * 32u + (lane & 31u)];
         mix_cls = (int)((e >> 16) & 3u);   // class of the step's largest group (k0_step_masks), carried by the program entry
       }
     } else
@@ -2325,16 +2401,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const bool valid = (int)lane < nact;
     const bool all_fast = (nact == 64) && (F == ~0ull) && Fn;
     pos = pos_next;
-    const int n0_next = (half_mode && tprog_kind(e_next) == TPROG_KIND_MIXED) ? (int)tprog_n0(e_next) : 32;
-    if (nact == 64 && n0_next == 32) {  // the ring stays aligned
-      advance64();
-      pre_n0 = 32;
-    } else if (nact == 64) {
+    if constexpr (half_mode) {
+      // the ring moves on by one record, whatever the step held; the next step's rec values are gathered now
+      ++tp_step;
       r0 = r1; r1 = r2;
-      rv_pre = gload_rec2(rec_blk, layout_rows(r0, n0_next));
-      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+      rv_pre = gload_rec2(rec_blk, r0);
+      r2 = gload_u16(srow_col, (uint32_t)(tp_step + 2) * 64u + lane);
       rk_ok = true;
-      pre_n0 = n0_next;
+    } else if (nact == 64) {  // the ring stays aligned
+      advance64();
     } else {
       // a shorter step: the next step's rows are in the ring already, nact lanes further on -> rotate the ring
       // (three cross-lane moves) instead of reloading it, and gather the rec values of the next step right away:
@@ -2346,11 +2421,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       const bool wrap = lane + (uint32_t)nact >= 64u;
       r0 = wrap ? a1 : a0;
       r1 = wrap ? a2 : a1;
-      if (NP == 2) rv_pre = gload_rec2(rec_blk, layout_rows(r0, n0_next));
+      if (NP == 2) rv_pre = gload_rec2(rec_blk, r0);
       else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
       r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
       rk_ok = true;
-      pre_n0 = n0_next;
     }
     if (!half_mode) {
       // a GROUP step of a pair in row mode needs the last position of every row's tie group in the gathered column ->
@@ -2379,20 +2453,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint32_t lane_t = lane;
       asm volatile("" : "+v"(lane_t));   // keeps the per-lane choices below inside the tie step (see layout_rows)
       if (kind == 1) {
-        // MIXED: the hot step on the step's rows (lanes past them: a position in the guard word, lo = 0), then the
-        // pairs inside the groups
-        const bool vrow = (lane_t & 31u) < (uint32_t)((lane_t < 32u) ? n0 : nact - n0);
-        uint32_t rkm[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) rkm[k] = vrow ? rk[k] : ((uint32_t)W << 6);
-        // row layout -> (pair, row of the sub-step): a lane's two rows are those of lanes l and l + 32
-        {
-          const auto m1 = __builtin_amdgcn_permlane32_swap(tmx.x, tmx.x, false, false);
-          const auto m2 = __builtin_amdgcn_permlane32_swap(tmx.y, tmx.y, false, false);
-          mix_sg1 = m1[0] | m1[1];
-          mix_sg2 = m2[0] | m2[1];
-        }
-        hot_step(rkm, std::true_type{});
+        // MIXED: the hot step on the step's rows (the record's empty lanes gathered the guard row: a position in the guard
+        // word, lo = 0), then the pairs inside the groups
+        mix_sg1 = tmx.x;
+        mix_sg2 = tmx.y;
+        hot_step(rk, std::true_type{});
         ICIKT_ST_MARK(2, nact)
       } else {
         // GROUP: up to 64 rows of ONE tie group of the streamed column (a piece of it, or all of it).  Rows of one
@@ -2985,8 +3050,8 @@ k2_epilogue(PrepView pv, const int32_t* __restrict__ pi, const int32_t* __restri
         const bool fill_fill = (sx.nna > 0 && lbx == 0u) && (sy.nna > 0 && lby == 0u);
         if (mgx >= 46342 && mgy >= 46342 && !fill_fill) {
           const int cx = pi[p], cy = pj[p];
-          const uint32_t* rx = pv.rec + ((int64_t)(cx >> 1) * pv.n_pad) * 2 + (cx & 1);
-          const uint32_t* ry = pv.rec + ((int64_t)(cy >> 1) * pv.n_pad) * 2 + (cy & 1);
+          const uint32_t* rx = pv.rec + ((int64_t)(cx >> 1) * pv.rec_rows) * 2 + (cx & 1);
+          const uint32_t* ry = pv.rec + ((int64_t)(cy >> 1) * pv.rec_rows) * 2 + (cy & 1);
           long long c = 0;
           for (int r = 0; r < pv.n; ++r) c += ((rx[2 * r] >> 16) == lbx && (ry[2 * r] >> 16) == lby) ? 1 : 0;
           if (c >= 46342) {

@@ -560,7 +560,8 @@ def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
         hip_ctx.sync()
         meta = view(3, S).cpu().numpy().view(np.uint32).reshape(S, -1)   # per column: 3 bitsets, then 16 words of stats
         ntg = meta[:, -16 + 7]
-        n_pad = arrays[2][1] // 2
+        n_pad = arrays[2][1] // 2            # rows of a rec / hirow block: the column's rows, padding, and the guard row
+        guard = (n + 63) // 64 * 64        # PrepView::rec_rows: row 64 ceil(n / 64) of every column
         rec_w = want[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
         rec_g = derived[1].cpu().numpy().view(np.uint32).reshape(-1, n_pad, 2)
         hi_w = want[2].cpu().numpy().view(np.uint16).reshape(-1, n_pad, 2)
@@ -570,6 +571,8 @@ def test_expand_cols_rebuilds_rec_hirow_tgroups(hip_ctx):
         for c in range(S):
             assert np.array_equal(rec_g[c >> 1, :n, c & 1], rec_w[c >> 1, :n, c & 1]), (n, c)
             assert np.array_equal(hi_g[c >> 1, :n, c & 1], hi_w[c >> 1, :n, c & 1]), (n, c)
+            assert rec_g[c >> 1, guard, c & 1] == rec_w[c >> 1, guard, c & 1] == guard, (n, c)   # q = 64 W, lo = 0
+            assert hi_g[c >> 1, guard, c & 1] == hi_w[c >> 1, guard, c & 1] == 0, (n, c)
             assert np.array_equal(tg_g[c, :ntg[c]], tg_w[c, :ntg[c]]), (n, c)
 
 

@@ -140,11 +140,16 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
   if (ov.half >= 0 && icikt::k1_half_items(pv.Wp) <= 9) pl.opts = ov.half ? 1 : 0;
-  int tg_max = 128;  // bits 8..: joint ties of a closing group from the gathered column's tie-group list while it has at
-                     // most this many groups (the kernels cap it at 128: two / four listed groups per lane), else row by row
+  int tg_max = 128;  // bits 8..: whole-wave kernels: joint ties of a closing group from the gathered column's tie-group list
+                     // while it has at most this many groups (the kernels cap it at 128: two listed groups per lane), else row
+                     // by row; half-wave kernels: the entries of a pair's counter table (count mode), sized below
   if (ov.has_tgmax) tg_max = std::max(-1, std::min(1 << 20, ov.tgmax));
-  pl.opts |= (tg_max < 0 ? 0 : tg_max) << 8;
-  if (tg_max < 0) pl.opts |= 2;  // bit 1: row mode only
+  const bool row_only = tg_max < 0;
+  if (row_only) { pl.opts |= 2; tg_max = 0; }  // bit 1: row mode only
+  // bits 8..15: list mode (range counts per listed tie group at a group's close: a cost per CLOSE, right for few, long
+  // groups -- and same-address atomics of count mode would serialise there) up to this many tie groups
+  int tg_list = std::min(tg_max, 128);
+  if (ov.list >= 0) tg_list = std::min(tg_list, ov.list);
   // half-wave kernels: a half rebuilds a prefix with half_items words per lane, unpredicated, so the LDS arrays of such
   // a kernel are padded to 32 * half_items words; every other plan runs pairs on the whole wave
   pl.half_items = icikt::k1_half_items(pv.Wp);
@@ -157,8 +162,33 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   if (np == 2 && pl.half_items == 0 && ov.hyb != 0) pl.opts |= 4;
   // final layout: the kernel derives the same stride from (Wp, half_items)
   pl.stride = icikt::k1_lds_stride(pv.Wp, pl.half_items);
-  if (pl.half_items > 0) pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items));  // seen + prefix slots
-  else pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
+  if (pl.half_items > 0) {
+    // seen + prefix slots + the counters of count mode: one u16 per tie group of a gathered column (+ one for the rows
+    // that are their own group), as many as the LDS holds WITHOUT costing the launch a wave it would otherwise run: six
+    // waves per SIMD (five from 11 words per lane on) or, for a short task list, the waves the list fills
+    const size_t base = (size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items);
+    auto pair_bytes = [&](int cap) { return (base + 2 * ((size_t)cap + 2) + 15) & ~(size_t)15; };
+    auto waves_fit = [&](int cap) { return (int)(lds_cap / ((size_t)wpb * np * pair_bytes(cap))) * wpb; };
+    const int waves_max = 4 * (pl.half_items > 9 ? 5 : 6);
+    const int64_t tasks = (n_pairs + 1) / 2;
+    const int waves_needed = (int)std::min<int64_t>(waves_max, std::max<int64_t>(wpb, (tasks + n_cu - 1) / std::max(1, n_cu)));
+    const int waves_target = std::min(waves_needed, std::max(wpb, waves_fit(0)));
+    int cap = 0;
+    if (!row_only) {
+      static const int caps[] = {4094, 3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 64};
+      for (int cc : caps) {
+        if (cc > pv.n / 2 + 64 && cc > 64) continue;              // (a column of n rows has at most n / 2 tie groups)
+        if (waves_fit(cc) >= waves_target) { cap = cc; break; }
+      }
+      if (ov.has_tgmax) cap = std::min(cap, tg_max);
+    }
+    tg_max = cap;
+    pl.perpair_bytes = (int)pair_bytes(cap);
+  } else {
+    pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
+  }
+  pl.opts |= tg_list << 8;
+  if (pl.half_items > 0) pl.opts |= tg_max << 16;   // bits 16..: entries of a pair's counter table (count mode)
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
@@ -332,9 +362,10 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
     }
   }
   if (c->plan_ov.verbose)
-    fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block, %d blocks/CU x %d CUs, grid=%d%s, tasks=%d (from %d)\n",
-            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, per_cu, c->prop.multiProcessorCount, blocks,
-            persistent ? " (persistent)" : "", count, first);
+    fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block (%d B/pair, %d tie-group counters), %d blocks/CU x %d CUs, "
+            "grid=%d%s, tasks=%d (from %d)\n",
+            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.half_items > 0 ? (pl.opts >> 16) : 0, per_cu,
+            c->prop.multiProcessorCount, blocks, persistent ? " (persistent)" : "", count, first);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                              pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes,
                              persistent ? c->d_task_ctr.p : nullptr, pl.opts, c->stream));
@@ -398,7 +429,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-  c->order.release(); c->hirow.release(); c->rec.release(); c->meta.release();
+  c->order.release(); c->hirow.release(); c->girow.release(); c->rec.release(); c->meta.release();
   c->tgroups.release(); c->tprog.release(); c->smask.release(); c->srow.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_task_ctr.release();
@@ -517,6 +548,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     HIPCHK(c, c->k0_bits.reserve(chunk * 2 * (size_t)(pv.Wp + 1)));
     HIPCHK(c, c->order.reserve(1));
     HIPCHK(c, c->hirow.reserve(1));
+    HIPCHK(c, c->girow.reserve(1));
     HIPCHK(c, c->rec.reserve(2));
     HIPCHK(c, c->tgroups.reserve(1));
     HIPCHK(c, c->tprog.reserve(1));
@@ -525,6 +557,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   } else {
     HIPCHK(c, c->order.reserve(S * pv.n_ord));
     HIPCHK(c, c->hirow.reserve(((S + 1) & ~(size_t)1) * pv.rec_rows));  // interleaved like rec: [S/2 blocks][rec_rows rows][2 columns]
+    HIPCHK(c, c->girow.reserve(((S + 1) & ~(size_t)1) * pv.rec_rows));  // likewise
     HIPCHK(c, c->rec.reserve(((S + 1) & ~(size_t)1) * pv.rec_rows));  // [S/2 blocks][rec_rows rows][2 columns]
     HIPCHK(c, c->tgroups.reserve(S * (size_t)pv.tg_stride));
     // the tie program serves the half-wave kernels only (n <= 18 336); longer columns classify their steps in the pair kernel
@@ -539,7 +572,7 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
   c->sort_chunk = (int)chunk;
 
-  pv.order = c->order.p; pv.hirow = c->hirow.p; pv.rec = c->rec.p;
+  pv.order = c->order.p; pv.hirow = c->hirow.p; pv.girow = c->girow.p; pv.rec = c->rec.p;
   pv.meta = c->meta.p;
   pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;
@@ -1638,6 +1671,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "half") ov.half = (val[0] == '1') ? 1 : 0;
     else if (key == "hyb") ov.hyb = (val[0] == '1') ? 1 : 0;
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
+    else if (key == "list") ov.list = atoi(val.c_str());
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());

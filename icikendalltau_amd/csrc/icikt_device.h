@@ -63,6 +63,8 @@ struct PairRaw {
   uint32_t g;               // rows in both fill groups (== c_both unless fl(min-0.1) == min)
 };
 
+constexpr uint16_t GIROW_NONE = 0xFFFFu;   // PrepView::girow: the row is its own tie group
+
 // Device pointers + sizes of the prepared matrix (HBM layout).
 static_assert(sizeof(ColStats) == 72, "ColStats is 9 words of a column's meta record");
 
@@ -84,6 +86,10 @@ struct PrepView {
                      // the columns 2a and 2a+1 interleaved: one 8-byte gather per row serves both
   uint16_t* hirow;   // [S/2][rec_rows][2]  per row: last ascending position of its tie group, the columns 2a and 2a+1
                      // interleaved like rec (a half-wave GROUP step reads both pairs' ends with one 4-byte gather per row)
+  uint16_t* girow;   // [S/2][rec_rows][2]  per row: the place of its tie group in the column's list `tgroups` (groups of
+                     // >= 2 rows, ascending), GIROW_NONE for a row that is its own group; interleaved like hirow.  A half-
+                     // wave GROUP step counts the streamed group's rows per tie group of the gathered column in a table of
+                     // counters indexed by it (count mode, k1_pairs)
   // per column, stride Wp
   // per column one record of mstride = 3 * Wp + 9 words (one array: one collective moves it between ranks):
   //   [Wp] mask      missing rows

@@ -44,7 +44,7 @@ struct icikt_ctx {
   // prepared matrix
   bool prepared = false;
   icikt::PrepView pv{};
-  DevBuf<uint16_t> order, hirow, srow;
+  DevBuf<uint16_t> order, hirow, girow, srow;
   DevBuf<uint32_t> wide32;                 // wide columns: order32 | q32 | lo32 | hi32, S x n_pad each
   DevBuf<unsigned long long> k0_bits;      // wide columns: K0's phase-3 bitsets, per column of a sort chunk
   DevBuf<uint32_t> rec, tgroups, tprog;
@@ -116,6 +116,7 @@ struct icikt_ctx {
     int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1, grid_cap = -1, hyb = -1;
     bool has_tgmax = false;
     int tgmax = 0;
+    int list = -1;      // list mode (range counts per listed tie group) up to this many tie groups: count mode takes over above
     bool verbose = false;
   } plan_ov;
 

@@ -511,6 +511,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   unsigned long long* const sh_bits = WIDE ? pv.k0_bits + (size_t)blockIdx.x * 2 * (size_t)(pv.Wp + 1) : sh_bits_lds;
   unsigned long long* const sh_st = WIDE ? sh_bits + (pv.Wp + 1) : sh_st_lds;
   __shared__ unsigned long long sh_sort[TILE + TILE / 2];  // 48 KB: the sort tile, later the rec staging area
+  __shared__ uint16_t sh_bigpre[1024];              // phase 3: tie groups of >= 2 rows that start in the words before w
   unsigned long long* sh_tk = sh_sort;                                      // sort tile: keys
   uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + TILE);         // sort tile: row indices
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(sh_sort);                   // after the sort: rec by row
@@ -531,7 +532,10 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   uint16_t* order = WIDE ? nullptr : pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = WIDE ? nullptr : pv.rec + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);  // [block][row][2]: stride 2
   uint16_t* hirow = WIDE ? nullptr : pv.hirow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);            // [block][row][2]: stride 2
-  if (!WIDE && tid == 0) { rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; }   // the guard row (PrepView::rec_rows)
+  uint16_t* girow = WIDE ? nullptr : pv.girow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);            // likewise
+  if (!WIDE && tid == 0) {   // the guard row (PrepView::rec_rows)
+    rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; girow[2 * pv.n_pad] = GIROW_NONE;
+  }
   uint32_t* tgl = WIDE ? nullptr : pv.tgroups + (int64_t)c * pv.tg_stride;
   uint32_t* order32 = WIDE ? pv.order32 + (int64_t)c * pv.n_pad : nullptr;
   uint32_t* q32 = WIDE ? pv.q32 + (int64_t)c * pv.n_pad : nullptr;
@@ -773,10 +777,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     }
   }
   unsigned long long* sh_big = reinterpret_cast<unsigned long long*>(sh_ll);  // bit k: a group of >= 2 rows starts at k
-  for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += NT) {
-    sh_bits[w] = 0ull;
-    if (!WIDE) sh_big[w] = 0ull;
-  }
+  for (int w = tid; w < (WIDE ? pv.Wp : 1024); w += NT) sh_bits[w] = 0ull;
   if (WIDE) {
     for (int k = n + tid; k < pv.n_pad; k += NT) order32[k] = 0u;
   } else {
@@ -798,6 +799,39 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     return (w << 6) + (int)__builtin_ctzll(m);
   };
 
+  // bit k of sh_big: a tie group of >= 2 rows starts at ascending position k (a start whose successor is not one);
+  // sh_bigpre[w]: such groups in the words before w.  A group's rank among them is its place in the column's tie-group
+  // list (tgroups, below) and the index every one of its rows carries in girow: the pair kernel counts a streamed
+  // group's rows per tie group of the gathered column in a table of counters indexed by it.
+  if (!WIDE) {
+    const int nw = (n + 63) >> 6;                  // <= 1024 words
+    int gbase = 0;                                 // groups in the blocks before this one (the same in every thread)
+    for (int wb = 0; wb < nw; wb += NT) {
+      const int wi = wb + tid;
+      unsigned long long bg = 0ull;
+      if (wi < nw) {
+        const unsigned long long st = sh_st[wi];
+        bg = st & ~((st >> 1) | (sh_st[wi + 1] << 63));
+        const int last = n - 1 - wi * 64;          // positions up to n - 1 (bit n of sh_st is the end marker)
+        if (last < 63) bg &= (2ull << last) - 1ull;
+        sh_big[wi] = bg;
+      }
+      const int cnt = (int)__popcll(bg);
+      const int incl = (int)wave_incl_scan((uint32_t)cnt);
+      if (lane == 63) sh_i[tid >> 6] = incl;
+      __syncthreads();
+      int wbase = gbase, btot = 0;
+      for (int w = 0; w < NW; ++w) {
+        const int t = sh_i[w];
+        if (w < (tid >> 6)) wbase += t;
+        btot += t;
+      }
+      if (wi < nw) sh_bigpre[wi] = (uint16_t)(wbase + incl - cnt);
+      gbase += btot;
+      __syncthreads();   // (sh_i is rewritten by the next block; the tables are complete for the loop below)
+    }
+  }
+
   // per-thread tie statistics over the groups that START at my positions
   int ngroups = 0, maxgroup = 0, tfill = 0, ntg_local = 0, oddtie = 0;
   uint32_t s0 = 0, s1 = 0, s2 = 0;      // int32 arithmetic of Rcpp sugar, as wrapping uint32
@@ -813,7 +847,6 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     for (int u = 0; u < K0_UB; ++u) {
     if (base0 + u * NT >= n) break;   // (uniform over the workgroup)
     const int k = base0 + u * NT + tid;
-    bool big = false;
     if (k < n) {
       const int lo = prev_start(k), hi = next_start(k) - 1;
       const uint32_t row = rows[u];
@@ -822,6 +855,8 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
         order32[n - 1 - k] = row;
       } else {
       hirow[2 * row] = (uint16_t)hi;
+      girow[2 * row] = (hi > lo) ? (uint16_t)((uint32_t)sh_bigpre[lo >> 6] + (uint32_t)__popcll(sh_big[lo >> 6] & ((1ull << (lo & 63)) - 1ull)))
+                                 : GIROW_NONE;
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
@@ -831,7 +866,6 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
       if (lo == k) {
         const int t = hi - lo + 1;
         ++ngroups;
-        big = t >= 2;
         if (!WIDE) maxgroup = (int)max((uint32_t)maxgroup, ((uint32_t)t << 16) | (uint32_t)lo);  // size << 16 | first position
         if (lo == 0) tfill = t;
         if (t >= 2) {
@@ -849,8 +883,6 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
         }
       }
     }
-    const unsigned long long bb = __ballot(big);
-    if (!WIDE && lane == 0 && (k >> 6) < 1024) sh_big[k >> 6] = bb;
     }
   }
   __syncthreads();
@@ -899,31 +931,15 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   // tie group of the OTHER column that spans several steps once, when that group closes.  A group's place in the
   // list = the groups of >= 2 rows that start before it: a prefix over the words of sh_big.
   if (!WIDE) {
-    const int nw = (n + 63) >> 6;                  // <= 1024 words: one per thread and block of NT words
-    int gbase = 0;                                 // groups listed by the blocks before this one (the same in every thread)
-    for (int wb = 0; wb < nw; wb += NT) {
-      const int wi = wb + tid;
-      const int cnt = (wi < nw) ? (int)__popcll(sh_big[wi]) : 0;
-      const int incl = (int)wave_incl_scan((uint32_t)cnt);           // inside the wave; the waves' totals through LDS
-      if (lane == 63) sh_i[tid >> 6] = incl;
-      __syncthreads();
-      int wbase = gbase, btot = 0;
-      for (int w = 0; w < NW; ++w) {
-        const int t = sh_i[w];
-        if (w < (tid >> 6)) wbase += t;
-        btot += t;
+    const int nw = (n + 63) >> 6;
+    for (int wi = tid; wi < nw; wi += NT) {
+      int off = (int)sh_bigpre[wi];
+      unsigned long long m = sh_big[wi];
+      while (m != 0ull) {
+        const int k = (wi << 6) + (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        tgl[off++] = (uint32_t)k | ((uint32_t)(next_start(k) - 1) << 16);
       }
-      if (wi < nw) {
-        int off = wbase + incl - cnt;
-        unsigned long long m = sh_big[wi];
-        while (m != 0ull) {
-          const int k = (wi << 6) + (int)__builtin_ctzll(m);
-          m &= m - 1ull;
-          tgl[off++] = (uint32_t)k | ((uint32_t)(next_start(k) - 1) << 16);
-        }
-      }
-      gbase += btot;
-      __syncthreads();   // (sh_i is rewritten by the next block)
     }
   }
   // the column's statistics: every value reduced inside its wave, the waves' results combined by thread 0 -- one barrier
@@ -1027,8 +1043,11 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   const uint16_t* ord = pv.order + (int64_t)c * pv.n_ord;
   uint32_t* rec = pv.rec + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);
   uint16_t* hirow = pv.hirow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);
+  uint16_t* girow = pv.girow + ((int64_t)(c >> 1) * pv.rec_rows) * 2 + (c & 1);
   uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
-  if (threadIdx.x == 0) { rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; }   // the guard row (PrepView::rec_rows)
+  if (threadIdx.x == 0) {   // the guard row (PrepView::rec_rows)
+    rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; girow[2 * pv.n_pad] = GIROW_NONE;
+  }
 
   // starts of groups of size >= 2: a start whose successor position exists and is not a start
   auto multi = [&](int w) -> unsigned long long {
@@ -1090,11 +1109,16 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     const uint32_t rv = (uint32_t)(n - 1 - k) | (lo << 16);
     if (staged) { rec_s[row] = rv; hi_s[row] = (uint16_t)hi; }
     else { rec[2 * row] = rv; hirow[2 * row] = (uint16_t)hi; }
-    if (k == s && e > s) {
-      // tgroups is ascending in lo: groups that start after me (descending) come first
-      const int i = msuf[w] + (int)__popcll(multi(w) & ~le);
-      tgl[i] = lo | (hi << 16);
+    // the group's place in tgroups (ascending in lo: groups that start after it -- descending -- come first), which is
+    // the index its rows carry in girow
+    uint32_t gi = GIROW_NONE;
+    if (e > s) {
+      const int sw = s >> 6;
+      const unsigned long long les = ((s & 63) < 63) ? ((2ull << (s & 63)) - 1ull) : ~0ull;   // bits <= s
+      gi = (uint32_t)(msuf[sw] + (int)__popcll(multi(sw) & ~les));
+      if (k == s) tgl[gi] = lo | (hi << 16);
     }
+    girow[2 * row] = (uint16_t)gi;
   }
   if (staged) {
     __syncthreads();
@@ -1761,6 +1785,7 @@ __device__ unsigned long long g_step_stats[24];
 // A task is (pair, pair or -1).  The two pairs of a task share their STREAMED column (pj) and their gathered
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
+template <int NP, int HI> __host__ __device__ constexpr bool half_mode_of() { return (HI > 0) && (NP == 2); }
 template <int NP, int HI>
 __global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : (HI > 9) ? 5 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
                                                                      // Two long-column pairs per wave: the LDS state allows 2-3 waves per SIMD, 3 leave 168 VGPRs
@@ -1790,7 +1815,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint32_t magic = tl_magic(IT);
   static_assert((NP == 1 && HI == 0) || NP == 2, "k1_pairs variants");
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
-  const int tg_max = opts >> 8;                             // list mode up to this many tie groups in B
+  // joint ties of a tie group of more than 32 rows, by the gathered column's tie groups: list mode (range counts per listed
+  // group) up to tg_list of them (<= 128), count mode (half-wave kernels: a counter per tie group) up to tg_max, else row mode
+  const int tg_list = (opts >> 8) & 0xFF;
+  const int tg_max = half_mode_of<NP, HI>() ? (opts >> 16) : tg_list;
 
   // Half-wave kernels: the grid covers the task list and a wave takes exactly one task -- without a task loop the
   // compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used to keep across the loop in scratch
@@ -1841,15 +1869,18 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   const uint16_t* hiG[NP];
   const uint32_t* tgB[NP];     // few tie groups in the gathered column: joint ties of multi-step groups are
   int ntgB[NP];                // counted at group close from this list (-1: row mode)
+  bool cntB[NP];               // half-wave kernels: ... or in the pair's counter table (count mode), one counter per listed group
   PairState S[NP];
   uint32_t cb[NP], gg[NP];
   bool g_oddtie = false;       // a gathered column has a tie group that starts at an odd position
   const uint32_t* rec_blk;
   const uint32_t* hi_blk;   // the block's tie-group ends: hi of column 2a | hi of column 2a + 1 << 16 per row
+  const uint32_t* gi_blk;   // the block's tie-group indices (PrepView::girow), interleaved the same way
   {
     const int g0 = __builtin_amdgcn_readfirstlane(pi[pidx[0]]);
     rec_blk = pv.rec + ((int64_t)(g0 >> 1) * pv.rec_rows) * 2;
     hi_blk = reinterpret_cast<const uint32_t*>(pv.hirow + ((int64_t)(g0 >> 1) * pv.rec_rows) * 2);
+    gi_blk = reinterpret_cast<const uint32_t*>(pv.girow + ((int64_t)(g0 >> 1) * pv.rec_rows) * 2);
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -1858,8 +1889,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     hiG[k] = pv.hirow + ((int64_t)(gcol >> 1) * pv.rec_rows) * 2 + (gcol & 1);   // interleaved like rec: index 2 * row
     tgB[k] = pv.tgroups + (int64_t)gcol * pv.tg_stride;
     const int ntg_raw = __builtin_amdgcn_readfirstlane((int)pv.col_stats(gcol)->ntg);
-    // (a closing group's joint ties are counted with at most four / two listed groups per lane: half-wave / whole-wave kernels)
-    ntgB[k] = (!(opts & 2) && ntg_raw <= min(tg_max, 128)) ? ntg_raw : -1;
+    // half-wave kernels: COUNT MODE while the gathered column's tie groups have a counter each in the pair's table (tg_max =
+    // its entries, sized by the host to what the LDS holds at the launch's occupancy); whole-wave kernels: list mode with
+    // at most two listed groups per lane
+    ntgB[k] = (!(opts & 2) && ntg_raw <= max(tg_list, tg_max)) ? ntg_raw : -1;
+    cntB[k] = half_mode && ntg_raw > tg_list;    // (read where ntgB[k] >= 0)
     g_oddtie = g_oddtie || (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
@@ -1879,6 +1913,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
       for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
+      // ... | the counters of count mode: tg_max + 1 u16 (the last one takes the rows that are their own tie group)
+      uint32_t* cz = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S[k].L.spre) + k1_half_pre_bytes<(HI > 0 ? HI : 1)>());
+      for (int w = lane; w < (tg_max + 2) / 2; w += 64) cz[w] = 0u;
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
@@ -1904,6 +1941,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
   for (int k = 0; k < NP; ++k) rk_pre[k] = 0u;
   uint32_t hi_pre = 0;   // fast tie steps: hirow of the next step's rows, gathered one step ahead in tie regions
+  uint32_t gi_pre = 0;   // half-wave kernels: likewise girow (pairs in count mode)
   bool hi_ok = false;
 
   // The LAST tie group of the streamed column (on data with missing values: the fill group) in closed form.
@@ -2296,6 +2334,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     }
     const uint32_t row = r0;
     const uint32_t hi_now = hi_pre;
+    const uint32_t gi_now = gi_pre;
     const bool hi_now_ok = hi_ok;
     uint32_t rk[NP];
     if (rk_ok) {
@@ -2438,8 +2477,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     if constexpr (half_mode) {
       // the next step is a GROUP step and a pair counts its joint ties row by row: the ends of the rows' tie groups
       // in the gathered column, one step ahead (lane (h, l): rows l and l + 32 of the next step, column of pair h)
-      hi_ok = tprog_kind(e_next) == TPROG_KIND_GROUP && ((ntgB[0] < 0) || (ntgB[NP - 1] < 0));
-      if (hi_ok) hi_pre = gload_u32(hi_blk, r0);   // (lane = row: both columns of the block in one entry)
+      // ... or per tie group of the gathered column (count mode): the rows' tie-group indices
+      hi_ok = tprog_kind(e_next) == TPROG_KIND_GROUP;
+      if (hi_ok) {   // (lane = row: both columns of the block in one entry)
+        if ((ntgB[0] < 0) || (ntgB[NP - 1] < 0)) hi_pre = gload_u32(hi_blk, r0);
+        if ((ntgB[0] >= 0 && cntB[0]) || (ntgB[NP - 1] >= 0 && cntB[NP - 1])) gi_pre = gload_u32(gi_blk, r0);
+      }
     }
 
     if (all_fast) {
@@ -2464,24 +2507,32 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // group are never discordant with each other, so a group needs no all-pairs count at all -- and no second
         // bitset: `seen` does not change while the group's rows are QUERIED (phase A, step by step as the program
         // delivers them), and when the group closes its rows are INSERTED together (phase B: from registers when the
-        // group is one step, else by streaming its positions a second time) and the prefix is rebuilt once.  The
-        // group's joint ties, sum over the gathered column's tie groups g of C(rows of the group in g, 2), come from
-        // range counts of `seen` before and after the insertion:
-        //   list mode (the gathered column has <= 128 tie groups): per listed group, count after - count before;
-        //   row mode: per ROW of the group the rows in its cell [lo, hi], after - before - 1 (every pair twice: tie2);
-        //             "before" is taken in phase A, "after" in a third pass over the group's rows (phase C).
-        // A range count is two prefix queries, whatever the width of the range.
+        // group is one or two steps, else by streaming its positions a second time) and the prefix is rebuilt once.
+        // The group's joint ties, sum over the gathered column's tie groups g of C(rows of the group in g, 2):
+        //   COUNT MODE (round 5; the gathered column's tie groups have a counter each in the pair's table): a row adds one
+        //     to the counter of its tie group (girow) in phase A; at the close every row reads its counter back, c, and
+        //     counts c - 1 -- every pair twice: tie2 -- then clears it (one or two steps, rows still in registers), or the
+        //     lanes read and clear the column's counters, C(c, 2) each (longer groups).  Two LDS operations per row
+        //     instead of the eight prefix queries of a range count before and after;
+        //   row mode (more tie groups than counters): per ROW of the group the rows in its cell [lo, hi], after - before
+        //     - 1; "before" is taken in phase A, "after" in a third pass over the group's rows (phase C).  A range count
+        //     is two prefix queries, whatever the width of the range.
         constexpr int H = (HI > 0 ? HI : 1);
         const bool hi_half = lane_t >= 32u;
         const uint32_t l32 = lane_t & 31u;
         unsigned long long* seenH = hi_half ? S[NP - 1].L.seen : S[0].L.seen;
         uint16_t* spreH = hi_half ? S[NP - 1].L.spre : S[0].L.spre;
+        uint16_t* cntH = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(spreH) + k1_half_pre_bytes<H>());
         const uint32_t* tgH = hi_half ? tgB[NP - 1] : tgB[0];
         const int ntgH = hi_half ? ntgB[NP - 1] : ntgB[0];
         const bool compH = (hi_half ? comp[NP - 1] : comp[0]) != 0u;   // the lane's pair reads column 2a + 1 of the block
         const bool rowmode = ntgH < 0;                              // per lane = per pair
+        const bool cntmode = !rowmode && (hi_half ? cntB[NP - 1] : cntB[0]);
+        const bool listmode = !rowmode && !cntmode;
         const bool any_row = (ntgB[0] < 0) || (ntgB[NP - 1] < 0);   // wave-uniform
-        const int kmax = (max(ntgB[0], ntgB[NP - 1]) + 31) >> 5;    // listed groups per lane (<= 4: tg_max <= 128)
+        const bool any_cnt = (ntgB[0] >= 0 && cntB[0]) || (ntgB[NP - 1] >= 0 && cntB[NP - 1]);
+        // listed groups per lane (<= 4: tg_list <= 128)
+        const int kmax = (max((ntgB[0] >= 0 && !cntB[0]) ? ntgB[0] : 0, (ntgB[NP - 1] >= 0 && !cntB[NP - 1]) ? ntgB[NP - 1] : 0) + 31) >> 5;
         const uint32_t GUARD = (uint32_t)W << 6;                    // q = 64 W, lo = 0: queries 0, inserts into the guard word
         auto Q = [&](uint32_t p) -> uint32_t { return prefix_query_half<H>(seenH, spreH, p); };
         auto range = [&](uint32_t r) -> uint32_t { return Q((r >> 16) + 1u) - Q(r & 0xFFFFu); };   // r = lo | hi << 16
@@ -2493,27 +2544,44 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           v0 = (int)l32 < cnt; v1 = (int)l32 + 32 < cnt;
           x0 = sw[0]; x1 = sw[1];
         };
-        auto two_his = [&](uint32_t hv, uint32_t& x0, uint32_t& x1) {   // hv: the block's hi entry by row
+        auto two_his = [&](uint32_t hv, uint32_t& x0, uint32_t& x1) {   // hv: the block's hi (or tie-group index) entry by row
           const auto sw = __builtin_amdgcn_permlane32_swap(hv, hv, false, false);
           x0 = compH ? (sw[0] >> 16) : (sw[0] & 0xFFFFu);
           x1 = compH ? (sw[1] >> 16) : (sw[1] & 0xFFFFu);
         };
+        // count mode: the counters are u16, two to a dword (LDS atomics are 32 bits wide; a count stays below 2^16)
+        auto cnt_add = [&](uint32_t g) { atomicAdd(reinterpret_cast<uint32_t*>(cntH) + (g >> 1), 1u << ((g & 1u) << 4)); };
+        auto cnt_take = [&](uint32_t g) -> uint32_t {   // rows of the group in tie group g but one; the counter is cleared
+          const uint32_t c = (uint32_t)cntH[g];
+          return (g < (uint32_t)tg_max) ? c - 1u : 0u;
+        };
         if (!grp_open) { grp_start = pos_step; grp_entries = 0; }
         uint32_t k0, k1;
         bool v0, v1;
-        two_rows(rk[0], rk[NP - 1], nact, k0, k1, v0, v1);
-        if (!v0) k0 = GUARD;
-        if (!v1) k1 = GUARD;
+        two_rows(rk[0], rk[NP - 1], nact, k0, k1, v0, v1);   // (the record's empty lanes gathered the guard row: k = GUARD)
+        // h0, h1: row mode: the last position of the row's tie group in the gathered column; count mode: the group's index
+        // (tg_max: the counter of the rows that are their own group -- and of the guard row)
+        // (the cross-half moves run on the whole wave: any_row / any_cnt are wave-uniform, the choice per lane follows)
         uint32_t h0 = 0u, h1 = 0u;
-        if (any_row) two_his(hi_now_ok ? hi_now : gload_u32(hi_blk, row), h0, h1);
+        if (any_row) {
+          uint32_t a0, a1;
+          two_his(hi_now_ok ? hi_now : gload_u32(hi_blk, row), a0, a1);
+          if (rowmode) { h0 = a0; h1 = a1; }
+        }
+        if (any_cnt) {
+          uint32_t a0, a1;
+          two_his(hi_now_ok ? gi_now : gload_u32(gi_blk, row), a0, a1);
+          if (cntmode) { h0 = min(a0, (uint32_t)tg_max); h1 = min(a1, (uint32_t)tg_max); }
+        }
         // phase A: rows of strictly higher groups below each row's tie group
         const uint32_t c0 = Q(k0 >> 16), c1 = Q(k1 >> 16);
         dis_half += c0 + c1;
-        if (any_row) {
-          const uint32_t b0 = (rowmode && v0) ? Q(h0 + 1u) - c0 : 0u;
-          const uint32_t b1 = (rowmode && v1) ? Q(h1 + 1u) - c1 : 0u;
+        if (any_row && rowmode) {
+          const uint32_t b0 = v0 ? Q(h0 + 1u) - c0 : 0u;
+          const uint32_t b1 = v1 ? Q(h1 + 1u) - c1 : 0u;
           seg_tie2 -= b0 + b1;
         }
+        if (any_cnt && cntmode) { cnt_add(h0); cnt_add(h1); }
         ICIKT_ST_MARK(4, 0)   // (diagnostic build: a GROUP step up to the end of phase A)
         if (closes) {
           // the group's rows: this step's alone (kept = 0), this and the previous step's, which are still in
@@ -2526,7 +2594,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           for (int i = 0; i < 4; ++i) {
             if (i < kmax) {
               const int g = (int)l32 + 32 * i;
-              if (g < ntgH) bef[i] = range(tgH[g]);
+              if (listmode && g < ntgH) bef[i] = range(tgH[g]);
             }
           }
           wave_lds_fence();
@@ -2556,18 +2624,36 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           wave_lds_fence();
           rebuild_prefix_half<H>(seenH, spreH, l32);
           wave_lds_fence();
-          ICIKT_ST_MARK(7, 0)   // (diagnostic build: a closing GROUP step's list counts before, insertions and rebuild)
           // list mode: C(rows of the group in the listed tie group, 2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (i < kmax) {
               const int g = (int)l32 + 32 * i;
-              if (g < ntgH) {
+              if (listmode && g < ntgH) {
                 const uint32_t c = range(tgH[g]) - bef[i];
                 seg_tie += c * (c - 1u) / 2u;
               }
             }
           }
+          // count mode: the counters hold, per tie group of the gathered column, the rows of this group
+          if (any_cnt && cntmode) {
+            if (kept <= 1) {
+              uint32_t e = cnt_take(h0) + cnt_take(h1);
+              if (kept == 1) e += cnt_take(sv_h & 0xFFFFu) + cnt_take(sv_h >> 16);
+              seg_tie2 += e;
+              wave_lds_fence();
+              cntH[h0] = 0; cntH[h1] = 0;
+              if (kept == 1) { cntH[sv_h & 0xFFFFu] = 0; cntH[sv_h >> 16] = 0; }
+            } else {
+              for (int g = (int)l32; g < ntgH; g += 32) {
+                const uint32_t c = (uint32_t)cntH[g];
+                seg_tie += c * (c - 1u) / 2u;
+                cntH[g] = 0;
+              }
+            }
+          }
+          wave_lds_fence();
+          ICIKT_ST_MARK(7, 0)   // (diagnostic build: a closing GROUP step's insertions, rebuild and counters)
           // phase C (row mode): rows of the group in each row's cell, the row itself excluded
           if (any_row) {
             if (kept <= 1) {

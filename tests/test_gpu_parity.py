@@ -648,12 +648,16 @@ def test_c_abi_error_contract(hip_ctx):
     assert o.shape == (3, 4) and np.all(r == 1) and np.all(np.isnan(o))
 
 
-@pytest.mark.parametrize("tgmax", ["-1", "3", "1000000"])
-def test_joint_tie_counting_modes(plan_ctx, tgmax):
-    """Joint ties of tie groups that span steps: by tie-group list (few groups in the gathered column) or row
-    by row; forced both ways on columns with 2 ... 1 500 tie groups, long and short."""
+@pytest.mark.parametrize("plan", [{"tgmax": "-1"}, {"tgmax": "3"}, {"tgmax": "40"}, {"tgmax": "1000000"}, {"tgmax": "1000000", "list": "0"},
+                                  {"tgmax": "60", "list": "2"}, None])
+def test_joint_tie_counting_modes(plan_ctx, plan):
+    """Joint ties of tie groups of more than 32 rows, by the tie groups of the gathered column: range counts per listed
+    group (list mode: up to `list` <= 128 groups), a counter per group in the pair's table (count mode: up to tgmax groups,
+    as many as the LDS holds) or row by row; every mode forced on columns with 2 ... 1 500 tie groups, long and short.
+    tgmax = 3 / 40 / 60: the two pairs of a task differ in their mode (columns 0 | 1, 2 | 3, 4 | 5, 6 | 7); list = 0: no
+    list mode, every same-address atomic of count mode on the three-group column; None: the library's own choice."""
     hip_ctx = plan_ctx
-    hip_ctx.debug_set_plan({"tgmax": tgmax})
+    hip_ctx.debug_set_plan(plan)
     rng = np.random.default_rng(71)
     n = 4000
     X = np.empty((n, 8))

@@ -172,7 +172,8 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     const int waves_max = 4 * (pl.half_items > 9 ? 5 : 6);
     const int64_t tasks = (n_pairs + 1) / 2;
     const int waves_needed = (int)std::min<int64_t>(waves_max, std::max<int64_t>(wpb, (tasks + n_cu - 1) / std::max(1, n_cu)));
-    const int waves_target = std::min(waves_needed, std::max(wpb, waves_fit(0)));
+    int waves_target = std::min(waves_needed, std::max(wpb, waves_fit(0)));
+    if (ov.waves > 0) waves_target = std::min(waves_target, std::max(wpb, ov.waves));
     int cap = 0;
     if (!row_only) {
       static const int caps[] = {4094, 3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 64};
@@ -188,6 +189,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
   }
   pl.opts |= tg_list << 8;
+  if (ov.solo == 0) pl.opts |= 8;   // bit 3: no SOLO steps
   if (pl.half_items > 0) pl.opts |= tg_max << 16;   // bits 16..: entries of a pair's counter table (count mode)
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
@@ -1672,6 +1674,8 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "hyb") ov.hyb = (val[0] == '1') ? 1 : 0;
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
     else if (key == "list") ov.list = atoi(val.c_str());
+    else if (key == "solo") ov.solo = atoi(val.c_str());
+    else if (key == "waves") ov.waves = atoi(val.c_str());
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());
     else if (key == "gridcap") ov.grid_cap = atoi(val.c_str());

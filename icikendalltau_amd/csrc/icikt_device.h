@@ -31,7 +31,7 @@ constexpr int COL_ODD_TIE = 1;
 __host__ __device__ inline uint32_t col_stream_cost(const ColStats& st) { return (uint32_t)st.flags >> 8; }
 
 // tie-program entry: rows of the step | kind << 7 | closes << 9 | n0 << 10 (MIXED: rows of its first sub-step)
-constexpr uint32_t TPROG_KIND_HOT = 0u, TPROG_KIND_MIXED = 1u, TPROG_KIND_GROUP = 2u;
+constexpr uint32_t TPROG_KIND_HOT = 0u, TPROG_KIND_MIXED = 1u, TPROG_KIND_GROUP = 2u, TPROG_KIND_SOLO = 3u;
 __host__ __device__ inline uint32_t tprog_rows(uint32_t e) { return e & 127u; }
 __host__ __device__ inline uint32_t tprog_kind(uint32_t e) { return (e >> 7) & 3u; }
 __host__ __device__ inline bool tprog_closes(uint32_t e) { return ((e >> 9) & 1u) != 0u; }

@@ -116,6 +116,8 @@ struct icikt_ctx {
     int np = -1, pend = -1, wpb = -1, half = -1, grid_mult = -1, grid_cap = -1, hyb = -1;
     bool has_tgmax = false;
     int tgmax = 0;
+    int waves = -1;     // half-wave kernels: waves per CU the counter tables may cost the launch down to (default: none)
+    int solo = -1;      // 0: SOLO steps of the tie program run as MIXED steps (with the in-step chains)
     int list = -1;      // list mode (range counts per listed tie group) up to this many tie groups: count mode takes over above
     bool verbose = false;
   } plan_ov;

@@ -368,7 +368,13 @@ __device__ __forceinline__ uint32_t k0_step_at(const unsigned long long* gf, int
   unsigned long long rest = (Fe >> b0) & 0x1FFFFFFFEull;
   if (b0 == 32 && endbit) rest |= 1ull << 32;
   const int b1 = (rest != 0ull) ? (63 - (int)__builtin_clzll(rest)) : 0;
-  return (uint32_t)(b0 + b1) | (TPROG_KIND_MIXED << 7) | (1u << 9) | ((uint32_t)b0 << 10);
+  // SOLO: a MIXED step whose sub-steps hold ONE group each (sub-step 0 = the group at pos, sub-step 1 = the next group or
+  // nothing): no pair of its rows is discordant inside a sub-step, so a pair kernel whose gathered columns have counter
+  // tables runs it without the in-step chains (k1_pairs: hot_step<2>); otherwise it is a MIXED step like any other.
+  const bool one0 = next == b0;
+  const unsigned long long in1 = (Fe >> b0) & ((b1 > 1) ? ((1ull << b1) - 2ull) : 0ull);   // starts strictly inside sub-step 1
+  const bool solo = one0 && in1 == 0ull;
+  return (uint32_t)(b0 + b1) | ((solo ? TPROG_KIND_SOLO : TPROG_KIND_MIXED) << 7) | (1u << 9) | ((uint32_t)b0 << 10);
 }
 
 // the same-group flag masks of the rows of the MIXED step that starts at pos (entry e): one lane per row
@@ -470,7 +476,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
       if (st + 3 >= sr_steps) continue;   // (cannot happen: the bound above)
       const uint32_t e = (uint32_t)E[pos - win];
       const uint32_t rows = tprog_rows(e);
-      if (tprog_kind(e) == TPROG_KIND_MIXED) {
+      if (tprog_kind(e) == TPROG_KIND_MIXED || tprog_kind(e) == TPROG_KIND_SOLO) {
         const uint32_t b0 = tprog_n0(e), sb = lane >> 5, l = lane & 31u;
         const bool vrow = l < (sb ? rows - b0 : b0);
         srow[st * 64 + (int)lane] = (uint16_t)(vrow ? (uint32_t)ord[(uint32_t)pos + (sb ? b0 + l : l)] : guard_row);
@@ -1952,6 +1958,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // the group begins belongs to it, so it has (size of g) - (rows of g in seen) rows in a listed tie group g of the
   // gathered column.  Used when the gathered columns are in list mode and the group is longer than one step: the
   // step loop ends at its first position last_start and a gather-only loop runs the rest.
+  // half-wave kernels: both gathered columns have a counter per tie group in their pair's table
+  bool solo_ok = half_mode && !(opts & 8);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) solo_ok = solo_ok && (ntgB[k] >= 0) && ((int)pv.col_stats(__builtin_amdgcn_readfirstlane(pi[pidx[k]]))->ntg <= tg_max);
   int last_start;
   bool closed_form = true;
 #pragma unroll
@@ -2024,8 +2034,14 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool defer_allpairs = false;
   uint32_t mix_sg1 = 0u, mix_sg2 = 0u;   // MIXED: the lane's same-group flag masks (both sub-steps); 0 in a plain hot step
   int mix_cls = 3;                       // MIXED: class of the step's largest group (half_step_flags_near), wave-uniform
-  auto hot_step = [&](const uint32_t (&rk)[NP], auto mixed_tag) {
-    constexpr bool MIXED = decltype(mixed_tag)::value;
+  uint32_t solo_g0 = 0u, solo_g1 = 0u;   // SOLO: the tie-group indices (girow) of the lane's two rows, tg_max = none
+  // mode_tag: 0 = a hot step; 1 = MIXED; 2 = SOLO: each sub-step is ONE tie group of the streamed column -- no pair of its
+  // rows is discordant, so there is no in-step chain at all, and its joint ties are counted like a GROUP step's in count mode:
+  // a row adds one to the counter of its tie group in the gathered column, reads it back (c: rows of the sub-step in that
+  // group; c - 1 partners, every pair twice) and clears it
+  auto hot_step = [&](const uint32_t (&rk)[NP], auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool MIXED = MODE == 1;
     if constexpr (half_mode) {
       // lanes 0..31 run pair 0, lanes 32..63 pair 1, two 32-row sub-steps.  One 8-byte gather per row;
       // permlane32_swap turns the two 64-row registers (pair 0, pair 1) into the two sub-steps' operands
@@ -2059,7 +2075,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         unsigned long long wv[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
-        if (sub == 0) {
+        uint32_t solo_c = 1u;
+        uint16_t* cntS = nullptr;
+        if constexpr (MODE == 2) {
+          const uint32_t g = sub ? solo_g1 : solo_g0;
+          cntS = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(spreH) + k1_half_pre_bytes<H>());
+          if (g < (uint32_t)tg_max) atomicAdd(reinterpret_cast<uint32_t*>(cntS) + (g >> 1), 1u << ((g & 1u) << 4));
+          wave_lds_fence();
+          solo_c = (g < (uint32_t)tg_max) ? (uint32_t)cntS[g] : 1u;
+        }
+        if (sub == 0 && MODE != 2) {
           if constexpr (!MIXED) {
             // (issuing the chain's ds_bpermute in FRONT of the sub-step's reads, so that the chain waits for it alone --
             //  lgkmcnt(6) -- and runs under the reads' latency, was measured in round 4: no difference at six waves per SIMD)
@@ -2098,6 +2123,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           cw[i] = run;
         }
         half_pre_store<H>(spreH, l32, half_incl_scan(run), cw);
+        if constexpr (MODE == 2) {
+          const uint32_t g = sub ? solo_g1 : solo_g0;
+          seg_tie2 += solo_c - 1u;
+          wave_lds_fence();
+          if (g < (uint32_t)tg_max) cntS[g] = 0;
+        }
         wave_lds_fence();
       }
     } else {
@@ -2304,7 +2335,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
         pos += 64;
         advance64();
-        hot_step(rk, std::false_type{});
+        hot_step(rk, std::integral_constant<int, 0>{});
         ICIKT_ST_MARK(0, 64)
       } while (pos + 64 <= hot_until);
       }
@@ -2367,6 +2398,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       closes = tprog_closes(e);
       Fn = (kind == 2) ? closes : true;
       F = (kind == 0) ? ~0ull : 0ull;     // (only `all_fast` below looks at it)
+      // SOLO (kind 3): without the in-step chains when both gathered columns have their counters, else as a MIXED step
+      if (kind == 3) kind = solo_ok ? 3 : 1;
       if (kind == 1) {   // which flags of the in-step compare belong to pairs inside a tie group (consumed behind the chains)
         tmx = smask_col[(uint32_t)tp_step * 32u + (lane & 31u)];
         mix_cls = (int)((e >> 16) & 3u);   // class of the step's largest group (k0_step_masks), carried by the program entry
@@ -2482,11 +2515,14 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       if (hi_ok) {   // (lane = row: both columns of the block in one entry)
         if ((ntgB[0] < 0) || (ntgB[NP - 1] < 0)) hi_pre = gload_u32(hi_blk, r0);
         if ((ntgB[0] >= 0 && cntB[0]) || (ntgB[NP - 1] >= 0 && cntB[NP - 1])) gi_pre = gload_u32(gi_blk, r0);
+      } else if (solo_ok && tprog_kind(e_next) == TPROG_KIND_SOLO) {
+        gi_pre = gload_u32(gi_blk, r0);   // (sub-step layout: lanes l and l + 32 hold the lane's two rows)
+        hi_ok = true;
       }
     }
 
     if (all_fast) {
-      hot_step(rk, std::false_type{});
+      hot_step(rk, std::integral_constant<int, 0>{});
       ICIKT_ST_MARK(1, 64)
       continue;
     }
@@ -2500,7 +2536,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // word, lo = 0), then the pairs inside the groups
         mix_sg1 = tmx.x;
         mix_sg2 = tmx.y;
-        hot_step(rk, std::true_type{});
+        hot_step(rk, std::integral_constant<int, 1>{});
+        ICIKT_ST_MARK(2, nact)
+      } else if (kind == 3) {
+        // SOLO: the tie-group indices of the lane's two rows, column of the lane's pair
+        const uint32_t gv = hi_now_ok ? gi_now : gload_u32(gi_blk, row);
+        const auto gsw = __builtin_amdgcn_permlane32_swap(gv, gv, false, false);
+        const bool compS = ((lane_t >= 32u) ? comp[NP - 1] : comp[0]) != 0u;
+        solo_g0 = min(compS ? (gsw[0] >> 16) : (gsw[0] & 0xFFFFu), (uint32_t)tg_max);
+        solo_g1 = min(compS ? (gsw[1] >> 16) : (gsw[1] & 0xFFFFu), (uint32_t)tg_max);
+        hot_step(rk, std::integral_constant<int, 2>{});
         ICIKT_ST_MARK(2, nact)
       } else {
         // GROUP: up to 64 rows of ONE tie group of the streamed column (a piece of it, or all of it).  Rows of one
@@ -2550,7 +2595,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           x1 = compH ? (sw[1] >> 16) : (sw[1] & 0xFFFFu);
         };
         // count mode: the counters are u16, two to a dword (LDS atomics are 32 bits wide; a count stays below 2^16)
-        auto cnt_add = [&](uint32_t g) { atomicAdd(reinterpret_cast<uint32_t*>(cntH) + (g >> 1), 1u << ((g & 1u) << 4)); };
+        // (rows that are their own tie group and the guard rows of empty lanes stay out: they would all meet at one counter, and
+        //  same-address atomics are served one lane at a time)
+        auto cnt_add = [&](uint32_t g) {
+          if (g < (uint32_t)tg_max) atomicAdd(reinterpret_cast<uint32_t*>(cntH) + (g >> 1), 1u << ((g & 1u) << 4));
+        };
         auto cnt_take = [&](uint32_t g) -> uint32_t {   // rows of the group in tie group g but one; the counter is cleared
           const uint32_t c = (uint32_t)cntH[g];
           return (g < (uint32_t)tg_max) ? c - 1u : 0u;

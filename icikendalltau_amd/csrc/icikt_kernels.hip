@@ -521,7 +521,13 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   unsigned long long* sh_tk = sh_sort;                                      // sort tile: keys
   uint32_t* sh_ti = reinterpret_cast<uint32_t*>(sh_sort + TILE);         // sort tile: row indices
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(sh_sort);                   // after the sort: rec by row
-  const bool stage_rec = !WIDE && pv.n_pad <= 3 * TILE;                  // 12 288 rows x 4 B fit
+  // The per-row arrays are written by ROW (scattered): through the free sort tile, then out in order, as far as it holds
+  // them -- rec and (hi | tie-group index << 16) for columns of up to 3 TILE / 2 rows (12 288 with the 8 192-element tile),
+  // the latter alone (two scattered 2-byte stores per row otherwise, against one 4-byte store for rec) up to 3 TILE rows
+  const bool stage_hg = !WIDE && pv.n_pad <= 3 * TILE;
+  const bool stage_rec = stage_hg && 2 * pv.n_pad <= 3 * TILE;
+  uint32_t* hg_s = stage_rec ? rec_s + pv.n_pad : rec_s;
+  const bool want_gi = pv.tp_stride > 0;                                 // (only the half-wave pair kernels read girow)
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -860,9 +866,10 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
         hi32[row] = (uint32_t)hi; q32[row] = (uint32_t)k; lo32[row] = (uint32_t)lo;
         order32[n - 1 - k] = row;
       } else {
-      hirow[2 * row] = (uint16_t)hi;
-      girow[2 * row] = (hi > lo) ? (uint16_t)((uint32_t)sh_bigpre[lo >> 6] + (uint32_t)__popcll(sh_big[lo >> 6] & ((1ull << (lo & 63)) - 1ull)))
-                                 : GIROW_NONE;
+      const uint32_t gi = (want_gi && hi > lo) ? ((uint32_t)sh_bigpre[lo >> 6] + (uint32_t)__popcll(sh_big[lo >> 6] & ((1ull << (lo & 63)) - 1ull)))
+                                               : (uint32_t)GIROW_NONE;
+      if (stage_hg) hg_s[row] = (uint32_t)hi | (gi << 16);
+      else { hirow[2 * row] = (uint16_t)hi; if (want_gi) girow[2 * row] = (uint16_t)gi; }
       // rec is written by row (scattered): through the free sort tile when the column fits, then out in order
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
@@ -894,6 +901,13 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   __syncthreads();
   if (stage_rec) {
     for (int r = tid; r < n; r += NT) rec[2 * r] = rec_s[r];
+  }
+  if (stage_hg) {
+    for (int r = tid; r < n; r += NT) {
+      const uint32_t hg = hg_s[r];
+      hirow[2 * r] = (uint16_t)hg;
+      if (want_gi) girow[2 * r] = (uint16_t)(hg >> 16);
+    }
   }
 
   // group-start flags in PROCESSING order k' = n-1-k: a group starts at k' where it ends at k
@@ -1030,10 +1044,11 @@ k0_prepare_small(PrepView pv, const double* __restrict__ X, int64_t ld, int col_
 constexpr int KX_WAVES = 4;
 __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_begin, int ncols, int staged) {
   // staged: the scattered per-row writes go to an LDS copy of the column's rec / hirow first and leave as
-  // sequential stores (dynamic LDS: n_pad * 6 bytes; the host stages columns of up to 16 384 rows)
+  // sequential stores (dynamic LDS: n_pad * 8 bytes; the host stages columns of up to 12 288 rows)
   extern __shared__ __attribute__((aligned(16))) unsigned char kx_stage[];
   uint32_t* rec_s = reinterpret_cast<uint32_t*>(kx_stage);
   uint16_t* hi_s = reinterpret_cast<uint16_t*>(kx_stage + (size_t)pv.n_pad * 4);
+  uint16_t* gi_s = reinterpret_cast<uint16_t*>(kx_stage + (size_t)pv.n_pad * 6);
   __shared__ __attribute__((aligned(8))) int prevs[1032];   // highest group start in the words before w (-1: none)
   __shared__ int nexts[1032];   // lowest group start in the words after w (n: none)
   __shared__ int msuf[1032];    // groups of size >= 2 that start in the words after w
@@ -1124,13 +1139,15 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
       gi = (uint32_t)(msuf[sw] + (int)__popcll(multi(sw) & ~les));
       if (k == s) tgl[gi] = lo | (hi << 16);
     }
-    girow[2 * row] = (uint16_t)gi;
+    if (staged) gi_s[row] = (uint16_t)gi;
+    else girow[2 * row] = (uint16_t)gi;
   }
   if (staged) {
     __syncthreads();
     for (int r = (int)threadIdx.x; r < n; r += 64 * KX_WAVES) {
       rec[2 * r] = rec_s[r];
       hirow[2 * r] = hi_s[r];
+      girow[2 * r] = gi_s[r];
     }
   }
   if (pv.tp_stride > 0) {   // (half-wave kernels only: W <= 287 words)
@@ -3748,8 +3765,8 @@ hipError_t launch_k2(const PrepView& pv, const int32_t* pi, const int32_t* pj, c
 hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s) {
   if (ncols <= 0 || pv.n <= 0) return hipSuccess;
   (void)hipGetLastError();
-  const int staged = (pv.n_pad <= 16384) ? 1 : 0;
-  const size_t lds = staged ? (size_t)pv.n_pad * 6 : 0;
+  const int staged = (pv.n_pad <= 12288) ? 1 : 0;
+  const size_t lds = staged ? (size_t)pv.n_pad * 8 : 0;
   if (staged) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0_expand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -674,6 +674,43 @@ def test_joint_tie_counting_modes(plan_ctx, plan):
         _check(hip_ctx, X, perspective=p)
 
 
+@pytest.mark.parametrize("n", [900, 6887, 10000, 18000, 30000])
+@pytest.mark.parametrize("plan", [None, {"solo": "0"}, {"list": "0", "tgmax": "1000000"}, {"waves": "4"}])
+def test_tie_program_step_kinds(plan_ctx, n, plan):
+    """Every step kind of the tie program against every joint-tie mode: streamed columns whose tie groups have 1, 2-5,
+    6-16, 17-32 (SOLO: one group per 32-row sub-step), 33-64, 65-128 (two steps, rows kept in registers) and several
+    hundred rows (streamed again at their close), in runs and interleaved, against gathered columns with one tie group, a
+    handful, ~100 (list mode), several hundred (count mode) and thousands (row mode, or count mode where the launch is
+    small enough for a large table: `waves`).  Both orders of every pair are in the list: each column streams and is
+    gathered."""
+    rng = np.random.default_rng(n + 17)
+
+    def grouped(sizes):   # a column made of tie groups of the given sizes, values in random row order
+        v = np.repeat(np.arange(len(sizes), dtype=np.float64), sizes)[:n]
+        v = np.concatenate([v, np.arange(n - len(v)) + len(sizes)]) if len(v) < n else v
+        return rng.permutation(v)
+
+    def sizes_of(lo, hi):
+        out, tot = [], 0
+        while tot < n:
+            out.append(int(rng.integers(lo, hi + 1)))
+            tot += out[-1]
+        return out
+
+    cols = [rng.standard_normal(n),                          # continuous: one tie group after masking
+            grouped(sizes_of(1, 5)), grouped(sizes_of(6, 16)), grouped(sizes_of(17, 32)), grouped(sizes_of(33, 64)),
+            grouped(sizes_of(65, 128)), grouped(sizes_of(200, 700)),
+            grouped([int(x) for x in rng.choice([1, 1, 1, 3, 20, 30, 50, 100, 400], size=n)]),   # every kind interleaved
+            np.round(rng.standard_normal(n) * 15), np.round(rng.standard_normal(n) * 60)]       # ~100 / ~400 tie groups
+    X = np.asfortranarray(np.stack(cols, axis=1))
+    X[rng.random(X.shape) < 0.04] = np.nan
+    S = X.shape[1]
+    pi, pj = np.triu_indices(S, k=1)
+    pi, pj = np.concatenate([pi, pj]).astype(np.int32), np.concatenate([pj, pi]).astype(np.int32)
+    plan_ctx.debug_set_plan(plan)
+    _check(plan_ctx, X, pi, pj, perspective="global")
+
+
 @pytest.mark.parametrize("mode", ["staged", "pinned"])
 def test_host_upload_modes(plan_ctx, mode):
     """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; staged through the library's

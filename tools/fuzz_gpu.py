@@ -103,6 +103,11 @@ def one_case(ctx, rng, case):
     }
     if R4:
         env["k0"] = rng.choice(["", "0", "1"])
+        # round 4, second half: the joint-tie modes of long tie groups (list / count / row) and SOLO steps, forced apart
+        env["list"] = rng.choice(["", "", "0", "2", "20"])
+        env["solo"] = rng.choice(["", "", "0"])
+        env["waves"] = rng.choice(["", "", "4", "12"])
+        env["tgmax"] = rng.choice(["", "-1", "2", "40", "300", "1000000"])
     ctx.debug_set_plan(env)
     flags = int(rng.random() < 0.25)  # exact int64 sums
     persp = rng.choice(["global", "local"])

@@ -167,7 +167,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     // that are their own group), as many as the LDS holds WITHOUT costing the launch a wave it would otherwise run: six
     // waves per SIMD (five from 11 words per lane on) or, for a short task list, the waves the list fills
     const size_t base = (size_t)pl.stride * 8 + icikt::k1_half_pre(pl.half_items);
-    auto pair_bytes = [&](int cap) { return (base + 2 * ((size_t)cap + 2) + 15) & ~(size_t)15; };
+    auto pair_bytes = [&](int cap) { return (base + ICIKT_CNT_BYTES * ((size_t)cap + 2) + 15) & ~(size_t)15; };
     auto waves_fit = [&](int cap) { return (int)(lds_cap / ((size_t)wpb * np * pair_bytes(cap))) * wpb; };
     const int waves_max = 4 * (pl.half_items > 9 ? 5 : 6);
     const int64_t tasks = (n_pairs + 1) / 2;

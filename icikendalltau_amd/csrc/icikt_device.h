@@ -64,6 +64,12 @@ struct PairRaw {
 };
 
 constexpr uint16_t GIROW_NONE = 0xFFFFu;   // PrepView::girow: the row is its own tie group
+// bytes of a counter of count mode (k1_pairs): 2 -- two to a dword, twice the tie groups per LDS byte -- or 4 (a build
+// option for measurements: -DICIKT_CNT_BYTES=4)
+#ifndef ICIKT_CNT_BYTES
+#define ICIKT_CNT_BYTES 2
+#endif
+static_assert(ICIKT_CNT_BYTES == 2 || ICIKT_CNT_BYTES == 4, "counter width");
 
 // Device pointers + sizes of the prepared matrix (HBM layout).
 static_assert(sizeof(ColStats) == 72, "ColStats is 9 words of a column's meta record");

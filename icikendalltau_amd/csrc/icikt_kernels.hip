@@ -1809,6 +1809,15 @@ __device__ unsigned long long g_step_stats[24];
 // columns (pi) are the two columns of one rec block, so one 8-byte gather per row serves both (host:
 // build_units).
 template <int NP, int HI> __host__ __device__ constexpr bool half_mode_of() { return (HI > 0) && (NP == 2); }
+// a pair's counter table (count mode): LDS atomics are 32 bits wide, so 2-byte counters are added to as halves of a dword (a
+// count stays below 2^16: n <= 30 656)
+#if ICIKT_CNT_BYTES == 2
+typedef uint16_t cnt_t;
+__device__ __forceinline__ void cnt_inc(cnt_t* t, uint32_t g) { atomicAdd(reinterpret_cast<uint32_t*>(t) + (g >> 1), 1u << ((g & 1u) << 4)); }
+#else
+typedef uint32_t cnt_t;
+__device__ __forceinline__ void cnt_inc(cnt_t* t, uint32_t g) { atomicAdd(t + g, 1u); }
+#endif
 template <int NP, int HI>
 __global__ void __launch_bounds__(512, (NP == 2 && HI == 0) ? 3 : (HI > 9) ? 5 : 6)  // 6 waves per SIMD (<= 80 VGPRs); the LDS state of a pair (seen + prefix slots) allows that up to HI = 9.
                                                                      // Two long-column pairs per wave: the LDS state allows 2-3 waves per SIMD, 3 leave 168 VGPRs
@@ -1938,7 +1947,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
       // ... | the counters of count mode: tg_max + 1 u16 (the last one takes the rows that are their own tie group)
       uint32_t* cz = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S[k].L.spre) + k1_half_pre_bytes<(HI > 0 ? HI : 1)>());
-      for (int w = lane; w < (tg_max + 2) / 2; w += 64) cz[w] = 0u;
+      for (int w = lane; w < (tg_max + 2) * ICIKT_CNT_BYTES / 4; w += 64) cz[w] = 0u;
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
@@ -1976,9 +1985,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // gathered column.  Used when the gathered columns are in list mode and the group is longer than one step: the
   // step loop ends at its first position last_start and a gather-only loop runs the rest.
   // half-wave kernels: both gathered columns have a counter per tie group in their pair's table
-  bool solo_ok = half_mode && !(opts & 8);
+  // (SOLO steps read the table as bytes: solo_cap counters)
+  const uint32_t solo_cap = (uint32_t)max(0, (tg_max + 1) * ICIKT_CNT_BYTES);
+  bool solo_ok = half_mode && !(opts & 2) && !(opts & 8);
 #pragma unroll
-  for (int k = 0; k < NP; ++k) solo_ok = solo_ok && (ntgB[k] >= 0) && ((int)pv.col_stats(__builtin_amdgcn_readfirstlane(pi[pidx[k]]))->ntg <= tg_max);
+  for (int k = 0; k < NP; ++k) solo_ok = solo_ok && (pv.col_stats(__builtin_amdgcn_readfirstlane(pi[pidx[k]]))->ntg <= solo_cap);
   int last_start;
   bool closed_form = true;
 #pragma unroll
@@ -2051,7 +2062,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool defer_allpairs = false;
   uint32_t mix_sg1 = 0u, mix_sg2 = 0u;   // MIXED: the lane's same-group flag masks (both sub-steps); 0 in a plain hot step
   int mix_cls = 3;                       // MIXED: class of the step's largest group (half_step_flags_near), wave-uniform
-  uint32_t solo_g0 = 0u, solo_g1 = 0u;   // SOLO: the tie-group indices (girow) of the lane's two rows, tg_max = none
+  uint32_t solo_g0 = 0u, solo_g1 = 0u;   // SOLO: the tie-group indices (girow) of the lane's two rows
   // mode_tag: 0 = a hot step; 1 = MIXED; 2 = SOLO: each sub-step is ONE tie group of the streamed column -- no pair of its
   // rows is discordant, so there is no in-step chain at all, and its joint ties are counted like a GROUP step's in count mode:
   // a row adds one to the counter of its tie group in the gathered column, reads it back (c: rows of the sub-step in that
@@ -2092,14 +2103,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         unsigned long long wv[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) wv[i] = seenH[l32 * (uint32_t)H + (uint32_t)i];
+        // SOLO: the pair's counter table read as BYTES -- a sub-step holds at most 32 rows, and the table is all zeros
+        // between its uses -- so that it serves columns of ICIKT_CNT_BYTES times the tie groups a GROUP step's counters do
         uint32_t solo_c = 1u;
-        uint16_t* cntS = nullptr;
+        uint8_t* cntS = nullptr;
         if constexpr (MODE == 2) {
           const uint32_t g = sub ? solo_g1 : solo_g0;
-          cntS = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(spreH) + k1_half_pre_bytes<H>());
-          if (g < (uint32_t)tg_max) atomicAdd(reinterpret_cast<uint32_t*>(cntS) + (g >> 1), 1u << ((g & 1u) << 4));
+          cntS = reinterpret_cast<uint8_t*>(spreH) + k1_half_pre_bytes<H>();
+          if (g < solo_cap) atomicAdd(reinterpret_cast<uint32_t*>(cntS) + (g >> 2), 1u << ((g & 3u) << 3));
           wave_lds_fence();
-          solo_c = (g < (uint32_t)tg_max) ? (uint32_t)cntS[g] : 1u;
+          solo_c = (g < solo_cap) ? (uint32_t)cntS[g] : 1u;
         }
         if (sub == 0 && MODE != 2) {
           if constexpr (!MIXED) {
@@ -2144,7 +2157,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           const uint32_t g = sub ? solo_g1 : solo_g0;
           seg_tie2 += solo_c - 1u;
           wave_lds_fence();
-          if (g < (uint32_t)tg_max) cntS[g] = 0;
+          if (g < solo_cap) cntS[g] = 0;
         }
         wave_lds_fence();
       }
@@ -2560,8 +2573,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         const uint32_t gv = hi_now_ok ? gi_now : gload_u32(gi_blk, row);
         const auto gsw = __builtin_amdgcn_permlane32_swap(gv, gv, false, false);
         const bool compS = ((lane_t >= 32u) ? comp[NP - 1] : comp[0]) != 0u;
-        solo_g0 = min(compS ? (gsw[0] >> 16) : (gsw[0] & 0xFFFFu), (uint32_t)tg_max);
-        solo_g1 = min(compS ? (gsw[1] >> 16) : (gsw[1] & 0xFFFFu), (uint32_t)tg_max);
+        solo_g0 = compS ? (gsw[0] >> 16) : (gsw[0] & 0xFFFFu);   // (GIROW_NONE: beyond any table)
+        solo_g1 = compS ? (gsw[1] >> 16) : (gsw[1] & 0xFFFFu);
         hot_step(rk, std::integral_constant<int, 2>{});
         ICIKT_ST_MARK(2, nact)
       } else {
@@ -2584,7 +2597,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         const uint32_t l32 = lane_t & 31u;
         unsigned long long* seenH = hi_half ? S[NP - 1].L.seen : S[0].L.seen;
         uint16_t* spreH = hi_half ? S[NP - 1].L.spre : S[0].L.spre;
-        uint16_t* cntH = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(spreH) + k1_half_pre_bytes<H>());
+        cnt_t* cntH = reinterpret_cast<cnt_t*>(reinterpret_cast<unsigned char*>(spreH) + k1_half_pre_bytes<H>());
         const uint32_t* tgH = hi_half ? tgB[NP - 1] : tgB[0];
         const int ntgH = hi_half ? ntgB[NP - 1] : ntgB[0];
         const bool compH = (hi_half ? comp[NP - 1] : comp[0]) != 0u;   // the lane's pair reads column 2a + 1 of the block
@@ -2615,7 +2628,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // (rows that are their own tie group and the guard rows of empty lanes stay out: they would all meet at one counter, and
         //  same-address atomics are served one lane at a time)
         auto cnt_add = [&](uint32_t g) {
-          if (g < (uint32_t)tg_max) atomicAdd(reinterpret_cast<uint32_t*>(cntH) + (g >> 1), 1u << ((g & 1u) << 4));
+          if (g < (uint32_t)tg_max) cnt_inc(cntH, g);
         };
         auto cnt_take = [&](uint32_t g) -> uint32_t {   // rows of the group in tie group g but one; the counter is cleared
           const uint32_t c = (uint32_t)cntH[g];

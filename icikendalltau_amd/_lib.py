@@ -314,7 +314,7 @@ class Context:
         """Diagnostic builds only (-DICIKT_STEP_STATS): {kind: (steps, rows, wave cycles)} of the pair kernel."""
         buf = np.zeros(24, dtype=np.uint64)
         self._chk(lib().icikt_debug_step_stats(self._h, _ptr(buf), int(reset)), "icikt_debug_step_stats")
-        kinds = ("hot_loop", "hot_in_main", "mixed", "group_rest", "group_top_phaseA", "tail", "setup", "group_close_insert_rebuild")
+        kinds = ("hot_loop", "hot_in_main_or_solo", "mixed", "group_rest", "group_top_phaseA", "tail", "setup", "group_close_insert_rebuild")
         return {k: (int(buf[i]), int(buf[8 + i]), int(buf[16 + i])) for i, k in enumerate(kinds)}
 
     def debug_set_plan(self, spec: str | dict | None = None):

@@ -2576,7 +2576,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         solo_g0 = compS ? (gsw[0] >> 16) : (gsw[0] & 0xFFFFu);   // (GIROW_NONE: beyond any table)
         solo_g1 = compS ? (gsw[1] >> 16) : (gsw[1] & 0xFFFFu);
         hot_step(rk, std::integral_constant<int, 2>{});
-        ICIKT_ST_MARK(2, nact)
+        ICIKT_ST_MARK(1, nact)   // (diagnostic build: counted with the hot steps met in the main loop)
       } else {
         // GROUP: up to 64 rows of ONE tie group of the streamed column (a piece of it, or all of it).  Rows of one
         // group are never discordant with each other, so a group needs no all-pairs count at all -- and no second
@@ -2979,12 +2979,22 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       uint16_t* spreH = hi_half ? S[NP - 1].L.spre : S[0].L.spre;
       const uint32_t* tgH = hi_half ? tgB[NP - 1] : tgB[0];
       const int ntgH = hi_half ? ntgB[NP - 1] : ntgB[0];
+      // (four listed groups per lane at a time: their list entries are loaded together -- a column of a thousand tie groups
+      //  would otherwise pay a memory round trip per 32 of them, one after the other)
       uint32_t tl = 0;
-      for (int g = (int)l32; g < ntgH; g += 32) {
-        const uint32_t r = tgH[g];
-        const uint32_t in_seen = prefix_query_half<H>(seenH, spreH, (r >> 16) + 1u) - prefix_query_half<H>(seenH, spreH, r & 0xFFFFu);
-        const uint32_t c = (r >> 16) - (r & 0xFFFFu) + 1u - in_seen;
-        tl += c * (c - 1u) / 2u;
+      for (int g0 = (int)l32; g0 < ntgH; g0 += 128) {
+        uint32_t rr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = (g0 + 32 * i < ntgH) ? tgH[g0 + 32 * i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (g0 + 32 * i < ntgH) {
+            const uint32_t r = rr[i];
+            const uint32_t in_seen = prefix_query_half<H>(seenH, spreH, (r >> 16) + 1u) - prefix_query_half<H>(seenH, spreH, r & 0xFFFFu);
+            const uint32_t c = (r >> 16) - (r & 0xFFFFu) + 1u - in_seen;
+            tl += c * (c - 1u) / 2u;
+          }
+        }
       }
       seg_tie += tl;
       uint32_t row_next = r0;

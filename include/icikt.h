@@ -304,10 +304,12 @@ int icikt_selftest(icikt_ctx *ctx);
 /* Development / test hook (the product path reads no environment variable): "key=value,key=value" overrides of
  * the pair kernel's launch plan and of the host path's H2D mode on this context; NULL or "" restores the library's
  * choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g: open-group bitset in LDS | global memory), wpb (waves
- * per workgroup), half (0 | 1), tgmax (tie-group list limit; -1 = per-row mode), gridmult / gridcap (persistent grid
- * of the long-column kernel: a multiple of the resident workgroups / at most this many), pipe (0 | 1: the host entries'
- * chunk pipeline), k0 (0 | 1: the pre-pass always in its 1 024-thread / 256-thread shape), verbose (0 | 1: print the
- * chosen plan to stderr). */
+ * per workgroup), half (0 | 1), tgmax (joint ties of long tie groups by the gathered column's tie groups -- list or count
+ * mode -- up to this many of them; -1 = per-row mode), list (list mode up to this many tie groups, <= 128: count mode
+ * takes over above), solo (0: SOLO steps run as MIXED steps), waves (half-wave kernels: waves per CU down to which the
+ * pairs' counter tables may cost the launch occupancy), gridmult / gridcap (persistent grid of the long-column kernel: a
+ * multiple of the resident workgroups / at most this many), pipe (0 | 1: the host entries' chunk pipeline), k0 (0 | 1: the
+ * pre-pass always in its 1 024-thread / 256-thread shape), verbose (0 | 1: print the chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);
 /* Development hook: per step kind of the pair kernel (hot loop, hot step in the main loop, MIXED, GROUP, general,
  * closed-form tail, set-up) the steps taken, their rows and the wave cycles spent, as out24 = [steps x 8 | rows x 8 |

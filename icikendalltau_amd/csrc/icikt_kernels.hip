@@ -294,18 +294,21 @@ __device__ __forceinline__ void k0_mem_stages(KP tk, IP ti, int count, int dbase
   }
 }
 
-// ---- the tie program of a column (PrepView::tprog, tmask) ---------------------------------------------------------
+// ---- the tie program of a column (PrepView::tprog, srow, smask) ---------------------------------------------------
 // From where a column's tie groups begin, the half-wave pair kernels walk it in steps cut at group boundaries:
 //   HOT    64 singleton rows;
 //   MIXED  two SUB-STEPS of up to 32 rows each, every one made of COMPLETE groups of at most 32 rows: no group
 //          straddles the two, so rows of one group only ever meet inside a sub-step, in registers;
+//   SOLO   a MIXED step whose sub-steps hold ONE group each (k0_step_at);
 //   GROUP  up to 64 rows of ONE longer group (`closes`: the step holds the group's last row).
 // The cut depends on the streamed column alone, so it is made here, once per column, by one wave (the step sequence is
 // scalar code: every lane computes the same values, lane 0 stores) instead of by every pair that streams the column --
 // S - 1 times, on the scalar unit of the pair kernel, with the flag words fetched from memory inside its step loop.
-// For the rows of a MIXED step the wave also writes, one lane per row, WHICH FLAGS of the pair kernel's in-step compare
-// vectors (half_step_flags: bit layout below) belong to pairs inside the row's own tie group: the pair kernel masks them
-// out of the discordance count and counts the joint ties among them, whatever the sizes of the groups.
+// Every step gets its RECORD (PrepView::srow): its rows in the lane layout the pair kernel runs it in, the guard row in
+// the empty lanes.  For a MIXED / SOLO step the record also says, per lane, WHICH FLAGS of the pair kernel's in-step compare
+// vectors (half_step_flags: bit layout below) belong to pairs inside a tie group (PrepView::smask: the masks of the lane's
+// two rows, one per sub-step, combined): the pair kernel masks them out of the discordance count and counts the joint
+// ties among them, whatever the sizes of the groups.
 // gf: the column's group-start flags in PROCESSING order, W words + a zero guard word (in LDS).  The program starts at
 // pos0 = 64 floor(hot_until / 64), where the pair kernel's singleton loop ends, and runs to n.
 //

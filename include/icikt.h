@@ -138,10 +138,10 @@ int icikt_prepare_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t 
 
 /* Column-sharded pre-pass for multi-rank use: the prepared state is allocated for alloc_cols >= n_samp
  * columns (so that every rank's slice has the same size) but only columns [col_begin, col_end) are computed.
-  * The caller then all-gathers the column slices of the arrays returned by icikt_prep_arrays() (all of them, or
- * the two that carry the information, see below) across ranks (RCCL all-gather) before icikt_run_dev().  Array i is
- * alloc_cols * bytes_per_col[i] bytes; a rank's columns are one contiguous slice of it provided col_begin is
- * even and col_end is even or n_samp (one array interleaves column pairs; other ranges are refused), so give
+  * The caller then all-gathers the column slices of the two arrays of icikt_prep_arrays() that carry the information
+ * (see below) across ranks (RCCL all-gather) and rebuilds the rest for the received columns before icikt_run_dev().
+ * Array i is alloc_cols * bytes_per_col[i] bytes; a rank's columns are one contiguous slice of it provided col_begin is
+ * even and col_end is even or n_samp (some arrays interleave column pairs; other ranges are refused), so give
  * every rank an even number of columns. */
 #define ICIKT_PREP_ARRAYS 5
 int icikt_prepare_cols_dev(icikt_ctx *ctx, const double *dX, int64_t n_feat, int64_t n_samp, int64_t ld,
@@ -153,9 +153,10 @@ int icikt_prepare_cols_f64(icikt_ctx *ctx, const double *X, int64_t n_feat, int6
 int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);
 /* ICIKT_PREP_ORDER (the descending permutation) and ICIKT_PREP_META (per column: missing-row, fill-group and
  * group-start bitsets + the column's statistics) carry the information: 24 KB per column of 10 000 rows, two
- * collectives.  ICIKT_PREP_REC, ICIKT_PREP_HIROW and ICIKT_PREP_TGROUPS (80 KB per column) are functions of a
- * column's order and group starts: exchange them too, or rebuild them for the received columns
- * [col_begin, col_end) with icikt_expand_cols_dev(). */
+ * collectives.  Everything else -- ICIKT_PREP_REC, ICIKT_PREP_HIROW, ICIKT_PREP_TGROUPS (exposed for inspection: 80 KB
+ * per column; a rec / hirow block has n_pad + 8 rows, row n_pad the guard row of the step records) and the state that is
+ * not exposed (per-row tie-group indices, the tie program and its step records) -- is a function of a column's order
+ * and group starts: icikt_expand_cols_dev() rebuilds it for the received columns [col_begin, col_end). */
 #define ICIKT_PREP_ORDER 0
 #define ICIKT_PREP_REC 1
 #define ICIKT_PREP_HIROW 2

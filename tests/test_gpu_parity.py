@@ -711,6 +711,29 @@ def test_tie_program_step_kinds(plan_ctx, n, plan):
     _check(plan_ctx, X, pi, pj, perspective="global")
 
 
+@pytest.mark.parametrize("n", [3400, 10000, 18336, 30600])
+def test_tie_program_most_steps_per_row(hip_ctx, n):
+    """The step records of a column are sized for the most steps its tie program can have, n / 17 + a few: a MIXED step of
+    fewer than 33 rows is followed by a group of more than 32 rows, and a closing GROUP step of fewer than 33 rows follows a
+    64-row piece of its group.  The patterns that come closest: tie groups of 1 and 33 rows in turn (two steps per 34
+    rows), 1 / 65 (three per 66), 1 / 33 / 65 mixed -- as streamed columns of every pair, against each other and a
+    continuous column."""
+    rng = np.random.default_rng(n)
+
+    def pattern(sizes):
+        reps = n // sum(sizes) + 1
+        v = np.repeat(np.arange(reps * len(sizes), dtype=np.float64), np.tile(sizes, reps))[:n]
+        return rng.permutation(v)
+
+    X = np.asfortranarray(np.stack([pattern([1, 33]), pattern([33, 1]), pattern([1, 65]), pattern([1, 33, 1, 65, 1, 34, 2, 64]),
+                                    rng.standard_normal(n)], axis=1))
+    X[rng.random(X.shape) < 0.01] = np.nan
+    S = X.shape[1]
+    pi, pj = np.triu_indices(S, k=1)
+    pi, pj = np.concatenate([pi, pj]).astype(np.int32), np.concatenate([pj, pi]).astype(np.int32)
+    _check(hip_ctx, X, pi, pj, perspective="global")
+
+
 @pytest.mark.parametrize("mode", ["staged", "pinned"])
 def test_host_upload_modes(plan_ctx, mode):
     """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; staged through the library's

@@ -1950,7 +1950,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       for (int w = lane; w < k1_half_pre_bytes<(HI > 0 ? HI : 1)>() / 2; w += 64) S[k].L.spre[w] = 0;
       // ... | the counters of count mode: tg_max + 1 u16 (the last one takes the rows that are their own tie group)
       uint32_t* cz = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(S[k].L.spre) + k1_half_pre_bytes<(HI > 0 ? HI : 1)>());
-      for (int w = lane; w < (tg_max + 2) * ICIKT_CNT_BYTES / 4; w += 64) cz[w] = 0u;
+      for (int w = lane; w < ((tg_max + 2) * ICIKT_CNT_BYTES + 3) / 4; w += 64) cz[w] = 0u;   // (the host rounds a pair's bytes up to 16)
     }
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount

@@ -276,7 +276,8 @@ class Context:
         return [(int(ptrs[i] or 0), int(bpc[i])) for i in range(PREP_ARRAYS)]
 
     def expand_cols_dev(self, col_begin: int, col_end: int, flags: int = 0):
-        """Rebuild rec / hirow / tgroups of columns [col_begin, col_end) from their (received) order and gflag."""
+        """Rebuild rec / hirow / girow / tgroups and the tie program with its step records of columns [col_begin, col_end)
+        from their (received) order and gflag."""
         self._chk(lib().icikt_expand_cols_dev(self._h, col_begin, col_end, flags), "icikt_expand_cols_dev")
 
     def set_pairs(self, pi, pj):

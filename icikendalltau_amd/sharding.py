@@ -5,8 +5,8 @@ The reference spreads `core` chunks of the pair list over furrr workers and ship
 
   * the pair list is cut into `world` consecutive blocks of ceiling(P / world) pairs (= the `core` chunks);
   * the per-column pre-pass is sharded too: rank r sorts columns [c0, c1) only, then the two prepared-state arrays
-    that carry the information (`order`, `meta`) are all-gathered in place and the rest (`rec`, `hirow`,
-    `tgroups`) is rebuilt locally for the received columns (icikt_expand_cols_dev);
+    that carry the information (`order`, `meta`) are all-gathered in place and the rest (`rec`, `hirow`, `girow`,
+    `tgroups`, the tie program and its step records) is rebuilt locally for the received columns (icikt_expand_cols_dev);
   * results are gathered to rank 0 (bench) or all-gathered (api: every rank returns the full result).
 
 bench.py and api.HipEngine both drive this module, and tests/test_distributed_gloo.py runs it with world_size 2
@@ -127,7 +127,7 @@ class ShardedPrepass:
                 full.copy_(torch.cat(parts))
 
     def run(self, flags: int = 0, on_phase=None):
-        """K0 on this rank's columns, exchange, rebuild of rec / hirow / tgroups for the columns received.
+        """K0 on this rank's columns, exchange, rebuild of rec / hirow / girow / tgroups / the tie program for the columns received.
         on_phase(name): called after "k0" and after "exchange" (all-gather + rebuild) have been enqueued -- bench.py
         records an event on the launch stream there (per-rank phase times)."""
         self.prepare_local(self.c0, self.c1, self.alloc_cols, flags)

@@ -55,13 +55,19 @@ CONFIGS = {
     "c3": dict(n_feat=10000, n_samp=256, n_na=500, seed=3, steps=20, warmup=5, cpu_sample=6000, pre_warm=8),
     "c4": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, steps=20, warmup=5, cpu_sample=12000, pre_warm=5),
     "c5": dict(n_feat=50000, n_samp=2048, n_na=1000, seed=5, steps=3, warmup=1, cpu_sample=1200),
+    # not a BASELINE configuration: c4's shape with TIED data (values rounded to ~1 000 distinct levels per column, central tie
+    # groups of ~23 rows), the regime the package's count data live in -- every step of the pair kernel is a tie step
+    "c4t": dict(n_feat=10000, n_samp=1024, n_na=1000, seed=4, levels=1000, steps=10, warmup=3, cpu_sample=6000, pre_warm=5),
 }
 
 
-def make_matrix(n_feat: int, n_samp: int, n_na: int, seed: int) -> np.ndarray:
-    """BASELINE.md synthetic config: column-major float64, per column the n_na smallest -> NaN."""
+def make_matrix(n_feat: int, n_samp: int, n_na: int, seed: int, levels: int = 0) -> np.ndarray:
+    """BASELINE.md synthetic config: column-major float64, per column the n_na smallest -> NaN.  levels > 0: the values
+    rounded to about that many distinct levels per column (tools/tie_sweep.py's tied data)."""
     rng = np.random.default_rng(seed)
     X = np.asfortranarray(rng.standard_normal((n_feat, n_samp)))
+    if levels:
+        X = np.asfortranarray(np.round(X * (levels / 6.0)))
     if n_na:
         idx = np.argpartition(X, n_na, axis=0)[:n_na]
         np.put_along_axis(X, idx, np.nan, axis=0)
@@ -79,7 +85,7 @@ def workload_matrix(config: str, cfg: dict) -> np.ndarray:
         X = np.asfortranarray(z["X"].astype(np.float64))
         X[(X == 0) | ~np.isfinite(X)] = np.nan
         return X
-    return make_matrix(cfg["n_feat"], cfg["n_samp"], cfg["n_na"], cfg["seed"])
+    return make_matrix(cfg["n_feat"], cfg["n_samp"], cfg["n_na"], cfg["seed"], cfg.get("levels", 0))
 
 
 # ---- self-launch: `python bench.py --gpus N` as typed ----------------------------------------------------------------
@@ -439,7 +445,8 @@ def workload_text(config, cfg, P_total, both):
     if CONFIGS[config].get("fixture"):
         return (f"{config}: yeast_missing (the reference's data/yeast_missing.rda), {n} features x {S} samples, zeros -> missing, "
                 f"perspective=global, {P_total} column pairs")
-    return (f"{config}: {n} features x {S} samples, {cfg['n_na']} smallest per column missing, "
+    tied = f"values rounded to ~{cfg['levels']} distinct levels per column (tied data), " if cfg.get("levels") else ""
+    return (f"{config}: {n} features x {S} samples, {tied}{cfg['n_na']} smallest per column missing, "
             f"perspective={'global + local' if both else 'global'}, {P_total} column pairs")
 
 
@@ -695,6 +702,10 @@ def main(argv=None):
             pmc_note = "counters are kept for the standard single-GPU workloads only"
         roof = build_roofline(pmc, pmc_source, pmc_note, k1_avg_s, P_local, n)
         roof["kernel_launches_per_step"] = k1_n / args.steps
+        if cfg.get("levels"):
+            roof["tied_data_note"] = ("tied data: every step of the pair kernel is a tie step (MIXED / SOLO / GROUP, DESIGN.md section 2), "
+                                      "not the hot loop whose instruction mix `frac` is priced against; frac_of_4_cycle_slots and "
+                                      "frac_of_2_cycle_slots need no mix")
         line = {
             "metric": "column-pairs/s (+ full-matrix wall time) at 10k feat x 1k samp",
             "value": value, "unit": "column-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -16,7 +16,7 @@ if CONFIGS[os.environ.get("CONFIG", "c4")].get("fixture"):
     X = workload_matrix(os.environ["CONFIG"], cfg)       # c2: the yeast matrix (no generator parameters)
     n, S = X.shape
 else:
-    X = make_matrix(n, S, na, seed)
+    X = make_matrix(n, S, na, seed, int(os.environ.get("LEVELS", cfg.get("levels", 0))))
 ctx = _lib.Context(0)
 ctx.debug_set_plan(os.environ.get("PLAN", ""))  # e.g. PLAN="np=1,wpb=4"
 dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()

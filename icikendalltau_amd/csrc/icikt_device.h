@@ -25,7 +25,7 @@ struct ColStats {
                          // == nna unless the data hold NaN and NaN is not in global_na
   int32_t flags;         // bit 0 COL_ODD_TIE: some tie group of >= 2 rows starts at an ODD ascending position;
                          // bits 8..31: what STREAMING the column costs a pair kernel task, in half hot steps (2 per 64-row hot
-                         // step, 4 per MIXED, 3 per GROUP step): the cost-weighted pair blocks of the multi-device driver
+                         // step, 3 per MIXED / SOLO / GROUP step): the cost-weighted pair blocks of the multi-device driver
 };
 constexpr int COL_ODD_TIE = 1;
 __host__ __device__ inline uint32_t col_stream_cost(const ColStats& st) { return (uint32_t)st.flags >> 8; }

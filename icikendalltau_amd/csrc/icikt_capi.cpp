@@ -148,8 +148,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   if (row_only) { pl.opts |= 2; tg_max = 0; }  // bit 1: row mode only
   // bits 8..15: list mode (range counts per listed tie group at a group's close: a cost per CLOSE, right for few, long
   // groups -- and same-address atomics of count mode would serialise there) up to this many tie groups
-  int tg_list = std::min(tg_max, 128);
-  if (ov.list >= 0) tg_list = std::min(tg_list, ov.list);
+  int tg_list = std::min(tg_max, 128);   // (raised to 256 below for the half-wave kernels of 11 .. 15 words per lane)
   // half-wave kernels: a half rebuilds a prefix with half_items words per lane, unpredicated, so the LDS arrays of such
   // a kernel are padded to 32 * half_items words; every other plan runs pairs on the whole wave
   pl.half_items = icikt::k1_half_items(pv.Wp);
@@ -188,9 +187,13 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   } else {
     pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
   }
-  pl.opts |= tg_list << 8;
+  // (eight listed groups per lane in the kernels that have the registers: list mode up to 256 tie groups there -- count
+  //  mode has 64 counters beside their 4.9 KB of LDS state per pair, and row mode streams a long group three times)
+  if (pl.half_items > 9 && !row_only) tg_list = std::min(ov.has_tgmax ? std::max(0, ov.tgmax) : 256, 256);
+  if (ov.list >= 0) tg_list = std::min(tg_list, ov.list);
+  pl.opts |= tg_list << 8;          // bits 8..17
   if (ov.solo == 0) pl.opts |= 8;   // bit 3: no SOLO steps
-  if (pl.half_items > 0) pl.opts |= tg_max << 16;   // bits 16..: entries of a pair's counter table (count mode)
+  if (pl.half_items > 0) pl.opts |= tg_max << 18;   // bits 18..: entries of a pair's counter table (count mode)
   const int fit = std::max(1, (int)(lds_cap / ((size_t)pl.perpair_bytes * np)));
   pl.np = np;
   pl.wpb = std::min(wpb, fit);
@@ -366,7 +369,7 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   if (c->plan_ov.verbose)
     fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block (%d B/pair, %d tie-group counters), %d blocks/CU x %d CUs, "
             "grid=%d%s, tasks=%d (from %d)\n",
-            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.half_items > 0 ? (pl.opts >> 16) : 0, per_cu,
+            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.half_items > 0 ? (pl.opts >> 18) : 0, per_cu,
             c->prop.multiProcessorCount, blocks, persistent ? " (persistent)" : "", count, first);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                              pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes,

@@ -1852,8 +1852,12 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   constexpr bool half_mode = (HI > 0) && (NP == 2);         // HI = words per lane when a half rebuilds a prefix
   // joint ties of a tie group of more than 32 rows, by the gathered column's tie groups: list mode (range counts per listed
   // group) up to tg_list of them (<= 128), count mode (half-wave kernels: a counter per tie group) up to tg_max, else row mode
-  const int tg_list = (opts >> 8) & 0xFF;
-  const int tg_max = half_mode_of<NP, HI>() ? (opts >> 16) : tg_list;
+  const int tg_list = (opts >> 8) & 0x3FF;
+  const int tg_max = half_mode_of<NP, HI>() ? (opts >> 18) : tg_list;
+  // listed tie groups per lane of a half in list mode: 4 (tg_list <= 128), 8 in the kernels of 11 .. 15 words per lane
+  // (tg_list <= 256: they have the registers -- five waves per SIMD -- and the LDS beside their 4.9 KB of state per pair
+  // leaves count mode 64 counters)
+  constexpr int LISTK = (HI > 9) ? 8 : 4;
 
   // Half-wave kernels: the grid covers the task list and a wave takes exactly one task -- without a task loop the
   // compiler has nothing to hoist out of it, and the ~20 per-lane addresses it used to keep across the loop in scratch
@@ -2609,7 +2613,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         const bool listmode = !rowmode && !cntmode;
         const bool any_row = (ntgB[0] < 0) || (ntgB[NP - 1] < 0);   // wave-uniform
         const bool any_cnt = (ntgB[0] >= 0 && cntB[0]) || (ntgB[NP - 1] >= 0 && cntB[NP - 1]);
-        // listed groups per lane (<= 4: tg_list <= 128)
+        // listed groups per lane (<= LISTK)
         const int kmax = (max((ntgB[0] >= 0 && !cntB[0]) ? ntgB[0] : 0, (ntgB[NP - 1] >= 0 && !cntB[NP - 1]) ? ntgB[NP - 1] : 0) + 31) >> 5;
         const uint32_t GUARD = (uint32_t)W << 6;                    // q = 64 W, lo = 0: queries 0, inserts into the guard word
         auto Q = [&](uint32_t p) -> uint32_t { return prefix_query_half<H>(seenH, spreH, p); };
@@ -2671,9 +2675,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           const int kept = grp_entries;
           const int grp_end = pos;                                  // (pos has moved on to the next step)
           // list mode: rows of earlier groups inside each listed tie group of the gathered column
-          uint32_t bef[4] = {0u, 0u, 0u, 0u};
+          uint32_t bef[LISTK];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < LISTK; ++i) {
+            bef[i] = 0u;
             if (i < kmax) {
               const int g = (int)l32 + 32 * i;
               if (listmode && g < ntgH) bef[i] = range(tgH[g]);
@@ -2708,7 +2713,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           wave_lds_fence();
           // list mode: C(rows of the group in the listed tie group, 2)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < LISTK; ++i) {
             if (i < kmax) {
               const int g = (int)l32 + 32 * i;
               if (listmode && g < ntgH) {

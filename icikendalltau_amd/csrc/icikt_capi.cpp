@@ -98,6 +98,7 @@ struct K1Plan {
   int opts;          // bit 0: half-wave hot step (one pair per 32-lane half, 32-row sub-steps)
   int half_items;    // words per lane of a half-wave prefix rebuild (0: no half-wave step)
   int stride;        // 64-bit words between a pair's LDS / pend arrays (k1_lds_stride)
+  int split;         // half-wave kernels: segments a task is cut in (1 | 2 | 4) when the task list leaves the chip half empty
 };
 
 K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov, bool tied) {
@@ -129,7 +130,10 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // few pairs: twice the waves hide the latency of a step better than two pairs per wave share their loads while
   // the chip is nearly empty (measured on the yeast matrix cut to 24 .. 96 columns: one pair per wave wins up to
   // 780 pairs, 0.209 vs 0.230 ms, two pairs per wave from 1 128 pairs on, 0.231 vs 0.242 ms)
-  if (n_pairs <= (int64_t)4 * n_cu) np = 1;
+  // (round 4, last change: that held for the tie steps of round 3.  With step records, count mode and SOLO steps the
+  //  half-wave kernels win at every size on tied data -- yeast cut to 4 .. 32 columns: 0.13 against 0.22 ms -- and draw level
+  //  on continuous data, 0.08 against 0.07 ms at 10 000 x 8 .. 32: only the whole-wave family still drops to one pair per wave)
+  if (n_pairs <= (int64_t)4 * n_cu && !half_ok) np = 1;
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable)
   if (ov.np == 1 || ov.np == 2) np = ov.np;
   int wpb = 4;
@@ -170,7 +174,15 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     auto waves_fit = [&](int cap) { return (int)(lds_cap / ((size_t)wpb * np * pair_bytes(cap))) * wpb; };
     const int waves_max = 4 * (pl.half_items > 9 ? 5 : 6);
     const int64_t tasks = (n_pairs + 1) / 2;
-    const int waves_needed = (int)std::min<int64_t>(waves_max, std::max<int64_t>(wpb, (tasks + n_cu - 1) / std::max(1, n_cu)));
+    // a task list that leaves the chip half empty: every task is cut in 2 or 4 segments, a wave each (k1_pairs) -- such a
+    // launch lasts as long as ONE task otherwise; the counter tables are then sized for the waves of the segments
+    // (measured on yeast columns and 10 000-row synthetic ones, 4 .. 96 columns: four segments pay while the segments' waves
+    //  number at most the chip's SIMDs, two up to 2.5 tasks per CU; beyond, the launch is bound by the SIMDs that hold three waves,
+    //  not by a wave's latency, and the rows inserted twice only add work -- the full yeast matrix: 0.208 -> 0.237 ms)
+    pl.split = 1;
+    if (pv.n >= 2048) pl.split = (tasks <= (int64_t)n_cu) ? 4 : (2 * tasks <= (int64_t)5 * n_cu) ? 2 : 1;
+    if (ov.split == 1 || ov.split == 2 || ov.split == 4) pl.split = ov.split;
+    const int waves_needed = (int)std::min<int64_t>(waves_max, std::max<int64_t>(wpb, (tasks * pl.split + n_cu - 1) / std::max(1, n_cu)));
     int waves_target = std::min(waves_needed, std::max(wpb, waves_fit(0)));
     if (ov.waves > 0) waves_target = std::min(waves_target, std::max(wpb, ov.waves));
     int cap = 0;
@@ -346,7 +358,16 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   // tasks per CU): when the task list is longer than what the chip holds, the grid is what the chip holds and the waves
   // FETCH their tasks, in order, from one counter per XCD group (k1_pairs: why the order matters for the L2) -- a wave
   // that has finished goes on at once instead of waiting for the other waves of its workgroup to retire (c5: +2.4 %).
-  const int want = (count + pl.wpb - 1) / pl.wpb;
+  // Half-wave kernels, a task list that leaves the chip half empty: every task is cut in 2 or 4 segments (k1_pairs), a wave
+  // each -- such a launch lasts as long as ONE task otherwise.  The segments add their counts up: the pairs' records are
+  // cleared first.
+  int split = 1, opts = pl.opts;
+  if (pl.half_items > 0 && pl.np == 2 && pl.split > 1) {
+    split = pl.split;
+    opts |= (split == 2 ? 1 : 2) << 4;
+    HIPCHK(c, icikt::launch_zero_raw(c->d_unit_start.p + 2 * (size_t)first, count, c->d_raw.p, c->stream));
+  }
+  const int want = (int)(((int64_t)count * split + pl.wpb - 1) / pl.wpb);
   int blocks = std::max(1, want);
   int per_cu = 0;
   bool persistent = false;
@@ -368,12 +389,12 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   }
   if (c->plan_ov.verbose)
     fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block (%d B/pair, %d tie-group counters), %d blocks/CU x %d CUs, "
-            "grid=%d%s, tasks=%d (from %d)\n",
+            "grid=%d%s, tasks=%d (from %d), %d segment(s) per task\n",
             pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.half_items > 0 ? (pl.opts >> 18) : 0, per_cu,
-            c->prop.multiProcessorCount, blocks, persistent ? " (persistent)" : "", count, first);
+            c->prop.multiProcessorCount, blocks, persistent ? " (persistent)" : "", count, first, split);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                              pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes,
-                             persistent ? c->d_task_ctr.p : nullptr, pl.opts, c->stream));
+                             persistent ? c->d_task_ctr.p : nullptr, opts, c->stream));
   return ICIKT_SUCCESS;
 }
 
@@ -1680,6 +1701,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "tgmax") { ov.has_tgmax = true; ov.tgmax = atoi(val.c_str()); }
     else if (key == "list") ov.list = atoi(val.c_str());
     else if (key == "solo") ov.solo = atoi(val.c_str());
+    else if (key == "split") ov.split = atoi(val.c_str());
     else if (key == "waves") ov.waves = atoi(val.c_str());
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());

@@ -193,6 +193,7 @@ hipError_t k1_wide_blocks_per_cu(size_t lds_bytes, int* out);
 inline size_t k1_wide_lds_bytes(int Wp) { return (size_t)(Wp + 1) * (8 + 8 + 4 + 4); }
 hipError_t launch_k0_expand(const PrepView& pv, int col_begin, int ncols, hipStream_t s);
 // task_ctr: nullptr = the grid covers the task list; else 8 zeroed counters, the waves fetch their tasks (whole-wave kernels)
+hipError_t launch_zero_raw(const int32_t* tasks, int n_tasks, PairRaw* raw, hipStream_t s);
 hipError_t launch_k1(const PrepView& pv, const int32_t* tasks, int n_tasks, const int32_t* pi,
                      const int32_t* pj, PairRaw* raw, int np, int half_items, int wpb, int blocks,
                      size_t lds_bytes, int perpair_bytes, int* task_ctr, int opts, hipStream_t s);

@@ -429,24 +429,47 @@ __device__ __forceinline__ uint32_t k0_step_masks(const unsigned long long* gf, 
 // (32 x 64 u32); `cnt`: four shared ints (steps of the window; the chain's position and entry count between windows; the
 // column's streaming cost, see below).
 constexpr int TPROG_WIN = 16384, TPROG_LIST = 1024;
+// SEGMENT MARKS (round 4, last change): four positions of the walk at which a pair kernel task may be CUT when a launch has
+// fewer tasks than the chip has waves -- the wave that takes the part behind a mark first inserts the rows in front of it
+// without counting them (k1_pairs).  A mark is the start of a step that starts a tie group (or a multiple of 64 inside the
+// singleton region); marks 1 cuts the walk in two parts of equal cost, marks 0, 2, 3 in four (inserting a row costs about
+// an eighth of counting it; the closed-form tail costs next to nothing).  Written behind the program: prog_tail[0..3] =
+// positions (0xFFFFFFFF: none), prog_tail[4..7] = their program steps (0xFFFFFFFF: in the singleton region).
+constexpr int TPROG_MARKS = 4;
 __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E, uint16_t* mlist, uint32_t* crossT, int* cnt,
-                                      int n, int W, uint32_t* prog, const uint16_t* ord, uint16_t* srow, uint2* smask,
-                                      int sr_steps, uint32_t guard_row, int tid, int nthreads) {
+                                      int n, int W, uint32_t* prog, uint32_t* prog_tail, const uint16_t* ord, uint16_t* srow,
+                                      uint2* smask, int sr_steps, uint32_t guard_row, int tid, int nthreads) {
   const uint32_t lane = (uint32_t)tid & 63u;
   const int wave = tid >> 6, nwaves = nthreads >> 6;
   k0_cross_table(crossT, tid, nthreads);
   if (wave == 0) {
-    int first_cont = n;   // first position that continues a group
+    int first_cont = n, best = 0;   // first position that continues a group; highest group start
     for (int w = (int)lane; w < W; w += 64) {
-      unsigned long long z = ~gf[w];
-      if (w == W - 1 && (n & 63)) z &= (1ull << (n & 63)) - 1ull;
+      unsigned long long f = gf[w], z = ~gf[w];
+      if (w == W - 1 && (n & 63)) { f &= (1ull << (n & 63)) - 1ull; z &= (1ull << (n & 63)) - 1ull; }
       if (z != 0ull) first_cont = min(first_cont, w * 64 + (int)__builtin_ctzll(z));
+      if (f != 0ull) best = max(best, w * 64 + 63 - (int)__builtin_clzll(f));
     }
     first_cont = -__builtin_amdgcn_readfirstlane(wave_max_i32(-first_cont));
+    const int last_start = __builtin_amdgcn_readfirstlane(wave_max_i32(best));
     const int hot_until = (first_cont < n) ? first_cont - 1 : n;
+    const int pos0 = (hot_until >> 6) << 6;
     // cnt[3]: what streaming this column costs a pair, in half hot steps (a hot step of 64 rows = 2, a MIXED step = 3, a
     // GROUP step = 3: their vector instructions): the singleton region now, the program's steps below
-    if (lane == 0u) { cnt[1] = (hot_until >> 6) << 6; cnt[2] = 0; cnt[3] = 2 * (hot_until >> 6); }
+    if (lane == 0u) {
+      cnt[1] = pos0; cnt[2] = 0; cnt[3] = 2 * (hot_until >> 6);
+      // the segment marks: targets as shares of the rows in front of the last tie group (it runs in closed form when it is
+      // longer than a step); those inside the singleton region are known now, the others are met by the walk below
+      const int n_eff = (n - last_start > 64) ? last_start : n;
+      const int share[TPROG_MARKS] = {300, 532, 564, 796};
+      for (int j = 0; j < TPROG_MARKS; ++j) {
+        const int T = (int)(((long long)n_eff * share[j]) / 1000);
+        cnt[12 + j] = T;
+        if (T < pos0) { cnt[4 + j] = (T >> 6) << 6; cnt[8 + j] = -1; }   // (step -1: in the singleton region)
+        else { cnt[4 + j] = -1; cnt[8 + j] = -1; }                         // (position -1: not met yet)
+      }
+      cnt[16] = 0;   // the walk stands inside a group of several GROUP steps
+    }
   }
   __syncthreads();
   for (int win = (cnt[1] / TPROG_WIN) * TPROG_WIN; win < n; win += TPROG_WIN) {
@@ -455,8 +478,16 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     __syncthreads();
     if (wave == 0) {
       int pos = cnt[1], ne = cnt[2], ns = 0, cost = cnt[3];
+      int mpos[TPROG_MARKS], mstep[TPROG_MARKS], mT[TPROG_MARKS];
+      for (int j = 0; j < TPROG_MARKS; ++j) { mpos[j] = cnt[4 + j]; mstep[j] = cnt[8 + j]; mT[j] = cnt[12 + j]; }
+      bool open = cnt[16] != 0;
       while (pos < wend) {
         const uint32_t e = (uint32_t)E[pos - win];
+        if (!open) {
+          for (int j = 0; j < TPROG_MARKS; ++j)
+            if (mpos[j] < 0 && pos >= mT[j]) { mpos[j] = pos; mstep[j] = ne; }
+        }
+        open = tprog_kind(e) == TPROG_KIND_GROUP && !tprog_closes(e);
         cost += (tprog_kind(e) == TPROG_KIND_HOT) ? 2 : 3;
         if (lane == 0u) {
           prog[ne] = e;
@@ -469,6 +500,8 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
       if (lane == 0u) {
         if (wend == n) prog[ne] = 0u;
         cnt[0] = min(ns, TPROG_LIST); cnt[1] = pos; cnt[2] = ne; cnt[3] = cost;
+        for (int j = 0; j < TPROG_MARKS; ++j) { cnt[4 + j] = mpos[j]; cnt[8 + j] = mstep[j]; }
+        cnt[16] = open ? 1 : 0;
       }
     }
     __syncthreads();
@@ -503,6 +536,7 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
     if (ne + 3 <= sr_steps)
       for (int i = tid; i < 192; i += nthreads) srow[ne * 64 + i] = (uint16_t)guard_row;
   }
+  if (tid < 2 * TPROG_MARKS) prog_tail[tid] = (uint32_t)cnt[4 + tid];   // (-1 -> 0xFFFFFFFF)
 }
 
 // WIDE (65 535 < n): 32-bit positions in separate arrays (order32, q32, lo32, hi32), the phase-3 bitsets in global
@@ -943,7 +977,8 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     uint16_t* Ewin = reinterpret_cast<uint16_t*>(sh_sort);
     uint32_t* crossT = reinterpret_cast<uint32_t*>(Ewin + TPROG_WIN);
     uint16_t* mlist = reinterpret_cast<uint16_t*>(crossT + 2048);
-    k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride, order,
+    k0_tie_program(sh_bits_lds, Ewin, mlist, crossT, &sh_i[0], n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+                   pv.tprog + (int64_t)c * pv.tp_stride + (pv.tp_stride - 2 * TPROG_MARKS), order,
                    pv.srow + (int64_t)c * pv.sr_steps * 64, pv.smask + (int64_t)c * pv.sr_steps * 32, pv.sr_steps,
                    (uint32_t)pv.n_pad, tid, NT);
     stream_cost = sh_i[3];   // (every thread reads it; thread 0 stores it with the statistics)
@@ -1058,7 +1093,7 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   __shared__ uint32_t kx_cross[32 * 64];   // k0_tie_program's scratch: cross table, would-be steps, MIXED step list
   __shared__ uint16_t kx_E[TPROG_WIN];
   __shared__ uint16_t kx_list[2 * TPROG_LIST];
-  __shared__ int kx_cnt[4];
+  __shared__ int kx_cnt[24];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   const int c = col_begin + (int)blockIdx.x;
@@ -1158,7 +1193,8 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
     unsigned long long* gfl = reinterpret_cast<unsigned long long*>(prevs);   // the scan arrays are free now: 1032 ints = 516 words
     for (int w = (int)threadIdx.x; w <= W; w += 64 * KX_WAVES) gfl[w] = gf[w];
     __syncthreads();
-    k0_tie_program(gfl, kx_E, kx_list, kx_cross, kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride, ord,
+    k0_tie_program(gfl, kx_E, kx_list, kx_cross, kx_cnt, n, W, pv.tprog + (int64_t)c * pv.tp_stride,
+                   pv.tprog + (int64_t)c * pv.tp_stride + (pv.tp_stride - 2 * TPROG_MARKS), ord,
                    pv.srow + (int64_t)c * pv.sr_steps * 64, pv.smask + (int64_t)c * pv.sr_steps * 32, pv.sr_steps,
                    (uint32_t)pv.n_pad, (int)threadIdx.x, 64 * KX_WAVES);
   }
@@ -1886,6 +1922,18 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     if (lane == 0u) t = atomicAdd(my_ctr, 1);
     task = t_lo + __builtin_amdgcn_readfirstlane(t);
   }
+  // Half-wave kernels, a task list that leaves the chip half empty (the host decides: opts bits 4..5): every task is CUT in
+  // 2 or 4 SEGMENTS at the streamed column's segment marks (k0_tie_program) and a wave takes one segment -- it first inserts
+  // the rows in front of its segment into `seen` without counting them (an eighth of a step's work per 64 rows), then walks
+  // its part; the segments' counts are added up in `raw` (zeroed by the host).  A launch of 2 280 tasks on 1 024 SIMDs lasts
+  // as long as ONE task, whatever else is done to the steps: two segments halve that.
+  const int split = half_mode_of<NP, HI>() ? (1 << ((opts >> 4) & 3)) : 1;
+  int seg = 0;
+  if (split > 1) {
+    seg = gwave / n_tasks;
+    task = gwave - seg * n_tasks;
+    if (seg >= split) return;
+  }
   if (task >= t_hi) return;
   do {
   ICIKT_ST_DECL
@@ -1959,9 +2007,11 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     S[k].dis = 0; S[k].tie = 0; S[k].tie2 = 0;
     // both-missing count and the (fill group, fill group) cell: bitset AND + popcount
     cb[k] = 0; gg[k] = 0;
-    for (int w = lane; w < W; w += 64) {
-      cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
-      gg[k] += (uint32_t)__popcll(fa[w] & fb[w]);
+    if (seg == 0) {
+      for (int w = lane; w < W; w += 64) {
+        cb[k] += (uint32_t)__popcll(ma[w] & mb[w]);
+        gg[k] += (uint32_t)__popcll(fa[w] & fb[w]);
+      }
     }
   }
   wave_lds_fence();
@@ -2016,7 +2066,30 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     hot_until = (first_cont < n) ? first_cont - 1 : n;
     closed_form = closed_form && (n - last_start > 64);
   }
-  const int end_main = closed_form ? last_start : n;
+  // the wave's segment of the walk: [seg_begin, seg_end), seg_step = the program step at seg_begin (-1: the segment begins
+  // in the singleton region, or at the program's first step)
+  int seg_begin = 0, seg_end = n, seg_step = -1;
+  if constexpr (half_mode) {
+    if (split > 1) {
+      const uint32_t* tail = pv.tprog + (int64_t)scol * pv.tp_stride + (pv.tp_stride - 2 * TPROG_MARKS);
+      const uint32_t mv = gload_u32(tail, lane & 7u);
+      // split 2: mark 1; split 4: marks 0, 2, 3 (a missing mark, 0xFFFFFFFF: the walk ends before it -> n)
+      auto mark = [&](int j, int& mp, int& ms) {
+        mp = (int)min((uint32_t)__builtin_amdgcn_readlane((int)mv, j), (uint32_t)n);
+        ms = __builtin_amdgcn_readlane((int)mv, 4 + j);
+      };
+      int b1 = n, b2 = n, b3 = n, s1 = -1, s2 = -1, s3 = -1;
+      if (split == 2) mark(1, b1, s1);
+      else { mark(0, b1, s1); mark(2, b2, s2); mark(3, b3, s3); }
+      seg_begin = (seg == 0) ? 0 : (seg == 1) ? b1 : (seg == 2) ? b2 : b3;
+      seg_end = (seg == 0) ? b1 : (seg == 1) ? b2 : (seg == 2) ? b3 : n;
+      seg_step = (seg == 0) ? -1 : (seg == 1) ? s1 : (seg == 2) ? s2 : s3;
+      if (seg > 0 && seg_begin >= seg_end) return;   // an empty segment (segment 0 also writes the pair's missing-row counts)
+      closed_form = closed_form && (seg_end >= n);
+      hot_until = min(hot_until, seg_end);           // (a mark inside the singleton region is a multiple of 64)
+    }
+  }
+  const int end_main = min(closed_form ? last_start : n, seg_end);
 
   // Steps are cut at tie-group boundaries of the streamed column: a step holds up to 64 rows of COMPLETE
   // groups (HOT / MIXED), or a piece of ONE longer group (GROUP).  pos = first position of the step, nact = its
@@ -2033,6 +2106,36 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
   for (int k = 0; k < NP; ++k) { sv_kw[k] = 0u; sv_hw[k] = 0u; sneg[k] = 0u; }
   int pos = 0;
+  if constexpr (half_mode) {
+    if (seg_begin > 0) {
+      // a later segment of a cut task: the rows in front of it enter `seen` uncounted -- a gather and two insertions per lane
+      // and 64 rows -- and the prefix is built once
+      constexpr int HP = (HI > 0 ? HI : 1);
+      const bool hiP = lane >= 32u;
+      const uint32_t l32p = lane & 31u;
+      unsigned long long* seenP = hiP ? S[NP - 1].L.seen : S[0].L.seen;
+      uint16_t* spreP = hiP ? S[NP - 1].L.spre : S[0].L.spre;
+      const uint32_t GUARDP = (uint32_t)W << 6;
+      uint2 rv = gload_rec2(rec_blk, r0);
+      uint32_t rw_n = r1;
+      for (int p = 0; p < seg_begin; p += 64) {
+        const uint2 rv_n = gload_rec2(rec_blk, rw_n);
+        rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
+        const auto sw = __builtin_amdgcn_permlane32_swap(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, false, false);
+        const bool w0 = p + (int)l32p < seg_begin, w1 = p + 32 + (int)l32p < seg_begin;
+        seen_insert(seenP, w0 ? (sw[0] & 0xFFFFu) : GUARDP);
+        seen_insert(seenP, w1 ? (sw[1] & 0xFFFFu) : GUARDP);
+        rv = rv_n;
+      }
+      wave_lds_fence();
+      rebuild_prefix_half<HP>(seenP, spreP, l32p);
+      wave_lds_fence();
+      pos = seg_begin;
+      r0 = gload_u16(ord, (uint32_t)pos + lane);
+      r1 = gload_u16(ord, (uint32_t)pos + 64u + lane);
+      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+    }
+  }
   ICIKT_ST_MARK(6, 0)
   unsigned long long fw0 = 0ull, fw1 = 0ull;  // flag words fw_word, fw_word + 1 of the window (gf[W] is a zero guard)
   int fw_word = -1;
@@ -2386,15 +2489,16 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       // ahead by vector loads (a scalar load would make every wait for LDS data in the step a full drain), and the
       // step's RECORD: its rows in the lane layout it runs in (empty lanes: the guard row), three steps ahead.
       if (!tp_ok) {   // the first program step: the ring turns from positions of `ord` to records (one exposed gather per task)
-        uint32_t off = 0u;
+        const int tp_base = (seg_step > 0) ? seg_step : 0;   // (a later segment of a cut task may begin inside the program)
+        uint32_t off = (uint32_t)tp_base;
         asm volatile("" : "+v"(off));
         tp_a = gload_u32(tprog_col, off);
         tp_b = gload_u32(tprog_col, off + 1u);
-        r0 = gload_u16(srow_col, lane);
-        r1 = gload_u16(srow_col, 64u + lane);
-        r2 = gload_u16(srow_col, 128u + lane);
+        r0 = gload_u16(srow_col, (uint32_t)tp_base * 64u + lane);
+        r1 = gload_u16(srow_col, (uint32_t)tp_base * 64u + 64u + lane);
+        r2 = gload_u16(srow_col, (uint32_t)tp_base * 64u + 128u + lane);
         rv_pre = gload_rec2(rec_blk, r0);
-        tp_step = 0;
+        tp_step = tp_base;
         tp_ok = true;
         rk_ok = true;
         hi_ok = false;
@@ -3072,12 +3176,18 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     const unsigned long long cbs = wave_sum_u64(cb[k]);
     const unsigned long long ggs = wave_sum_u64(gg[k]);
     if (lane == 0 && k < np) {
-      PairRaw o;
-      o.dis = dis;
-      o.ntie = ntie;
-      o.c_both = (uint32_t)cbs;
-      o.g = (uint32_t)ggs;
-      raw[pidx[k]] = o;
+      if (split > 1) {   // a segment of a cut task: the host has zeroed the pair's record
+        atomicAdd(&raw[pidx[k]].dis, dis);
+        atomicAdd(&raw[pidx[k]].ntie, ntie);
+        if (seg == 0) { raw[pidx[k]].c_both = (uint32_t)cbs; raw[pidx[k]].g = (uint32_t)ggs; }
+      } else {
+        PairRaw o;
+        o.dis = dis;
+        o.ntie = ntie;
+        o.c_both = (uint32_t)cbs;
+        o.g = (uint32_t)ggs;
+        raw[pidx[k]] = o;
+      }
     }
   }
   wave_lds_fence();
@@ -3728,6 +3838,23 @@ hipError_t k1_wide_blocks_per_cu(size_t lds_bytes, int* out) {
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, reinterpret_cast<const void*>(k1_wide), 64, lds_bytes);
+}
+
+// the records of the pairs of a task range cleared: a launch whose tasks are cut in segments ADDS its counts up
+__global__ void __launch_bounds__(256) k_zero_raw(const int32_t* __restrict__ tasks, int n_tasks, PairRaw* __restrict__ raw) {
+  const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (t >= n_tasks) return;
+  PairRaw z;
+  z.dis = 0ull; z.ntie = 0ull; z.c_both = 0u; z.g = 0u;
+  const int p0 = tasks[2 * t], p1 = tasks[2 * t + 1];
+  raw[p0] = z;
+  if (p1 >= 0) raw[p1] = z;
+}
+hipError_t launch_zero_raw(const int32_t* tasks, int n_tasks, PairRaw* raw, hipStream_t s) {
+  if (n_tasks <= 0) return hipSuccess;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_zero_raw, dim3((n_tasks + 255) / 256), dim3(256), 0, s, tasks, n_tasks, raw);
+  return hipGetLastError();
 }
 
 typedef void (*k1_fn_t)(PrepView, const int32_t*, int, const int32_t*, const int32_t*, PairRaw*, int, int*, int);

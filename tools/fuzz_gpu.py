@@ -107,6 +107,7 @@ def one_case(ctx, rng, case):
         env["list"] = rng.choice(["", "", "0", "2", "20"])
         env["solo"] = rng.choice(["", "", "0"])
         env["waves"] = rng.choice(["", "", "4", "12"])
+        env["split"] = rng.choice(["", "", "1", "2", "4"])   # tasks cut in segments whatever the launch's size
         env["tgmax"] = rng.choice(["", "-1", "2", "40", "300", "1000000"])
     ctx.debug_set_plan(env)
     flags = int(rng.random() < 0.25)  # exact int64 sums

@@ -1671,7 +1671,7 @@ int icikt_missingness_f64(icikt_ctx* c, const double* X, int64_t n_feat, int64_t
 // path's H2D mode; NULL or "" restores the library's choices.  Keys: np (pairs per wave: 1 | 2), pend (l | g),
 // wpb (waves per workgroup), half (0 | 1), tgmax (list / count mode up to this many tie groups of the gathered column; -1 =
 // row mode), list (list mode up to this many, <= 128), solo (0: no SOLO steps), waves (waves per CU the counter tables may
-// cost the launch down to), gridmult (persistent grid as a multiple of the resident waves, always), gridcap (persistent
+// cost the launch down to), split (1 | 2 | 4 segments per half-wave task), gridmult (persistent grid as a multiple of the resident waves, always), gridcap (persistent
 // grid: at most this many workgroups),
 // pipe (0 | 1: the host entries' chunk pipeline off / on whenever possible), k0 (0 | 1: the pre-pass always in its
 // 1 024-thread / 256-thread shape), verbose (0 | 1: print the plan to stderr).

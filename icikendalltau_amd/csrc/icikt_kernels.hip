@@ -2116,16 +2116,26 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       unsigned long long* seenP = hiP ? S[NP - 1].L.seen : S[0].L.seen;
       uint16_t* spreP = hiP ? S[NP - 1].L.spre : S[0].L.spre;
       const uint32_t GUARDP = (uint32_t)W << 6;
-      uint2 rv = gload_rec2(rec_blk, r0);
-      uint32_t rw_n = r1;
-      for (int p = 0; p < seg_begin; p += 64) {
-        const uint2 rv_n = gload_rec2(rec_blk, rw_n);
-        rw_n = gload_u16(ord, (uint32_t)p + 128u + lane);
-        const auto sw = __builtin_amdgcn_permlane32_swap(comp[0] ? rv.y : rv.x, comp[NP - 1] ? rv.y : rv.x, false, false);
-        const bool w0 = p + (int)l32p < seg_begin, w1 = p + 32 + (int)l32p < seg_begin;
-        seen_insert(seenP, w0 ? (sw[0] & 0xFFFFu) : GUARDP);
-        seen_insert(seenP, w1 ? (sw[1] & 0xFFFFu) : GUARDP);
-        rv = rv_n;
+      // (256 rows per turn: four gathers in flight, the next turn's rows loaded behind them -- the wave is alone on its SIMD,
+      //  that is why it was cut, and one gather per turn made the insertions as slow as a counted walk)
+      const uint32_t ord_last = (uint32_t)pv.n_ord - 1u;   // (the run-ahead stays inside the column's zero padding)
+      uint32_t rw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rw[u] = gload_u16(ord, min((uint32_t)u * 64u + lane, ord_last));
+      for (int p = 0; p < seg_begin; p += 256) {
+        uint2 rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rv[u] = gload_rec2(rec_blk, rw[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rw[u] = gload_u16(ord, min((uint32_t)p + 256u + (uint32_t)u * 64u + lane, ord_last));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pu = p + 64 * u;
+          const auto sw = __builtin_amdgcn_permlane32_swap(comp[0] ? rv[u].y : rv[u].x, comp[NP - 1] ? rv[u].y : rv[u].x, false, false);
+          const bool w0 = pu + (int)l32p < seg_begin, w1 = pu + 32 + (int)l32p < seg_begin;
+          seen_insert(seenP, w0 ? (sw[0] & 0xFFFFu) : GUARDP);
+          seen_insert(seenP, w1 ? (sw[1] & 0xFFFFu) : GUARDP);
+        }
       }
       wave_lds_fence();
       rebuild_prefix_half<HP>(seenP, spreP, l32p);

@@ -42,7 +42,8 @@ def hot_loops(want, verbose=False):
                         os.path.join(ROOT, "icikendalltau_amd", "csrc", "icikt_kernels.hip")], check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if want in l and re.match(r"^_Z\w+:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    # (the function's end label, not its first s_endpgm: a kernel with early returns -- a wave whose segment is empty -- has several)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end + 1]
     labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
     loops = []

@@ -461,9 +461,9 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
       // the segment marks: targets as shares of the rows in front of the last tie group (it runs in closed form when it is
       // longer than a step); those inside the singleton region are known now, the others are met by the walk below
       const int n_eff = (n - last_start > 64) ? last_start : n;
-      const int share[TPROG_MARKS] = {300, 532, 564, 796};
+      const int share[TPROG_MARKS] = {307, 545, 578, 815};   // (in 1 / 1024: 0.300, 0.532, 0.564, 0.796 of the rows)
       for (int j = 0; j < TPROG_MARKS; ++j) {
-        const int T = (int)(((long long)n_eff * share[j]) / 1000);
+        const int T = (int)(((uint32_t)n_eff * (uint32_t)share[j]) >> 10);   // (n <= 65 535: fits 32 bits)
         cnt[12 + j] = T;
         if (T < pos0) { cnt[4 + j] = (T >> 6) << 6; cnt[8 + j] = -1; }   // (step -1: in the singleton region)
         else { cnt[4 + j] = -1; cnt[8 + j] = -1; }                         // (position -1: not met yet)
@@ -481,11 +481,15 @@ __device__ inline void k0_tie_program(const unsigned long long* gf, uint16_t* E,
       int mpos[TPROG_MARKS], mstep[TPROG_MARKS], mT[TPROG_MARKS];
       for (int j = 0; j < TPROG_MARKS; ++j) { mpos[j] = cnt[4 + j]; mstep[j] = cnt[8 + j]; mT[j] = cnt[12 + j]; }
       bool open = cnt[16] != 0;
+      int mj = 0;   // marks met so far (those inside the singleton region were set before the walk)
+      while (mj < TPROG_MARKS && mpos[mj] >= 0) ++mj;
+      int nextT = (mj < TPROG_MARKS) ? mT[mj] : 0x7FFFFFFF;   // the next mark's target: one compare per step of the walk
       while (pos < wend) {
         const uint32_t e = (uint32_t)E[pos - win];
-        if (!open) {
-          for (int j = 0; j < TPROG_MARKS; ++j)
-            if (mpos[j] < 0 && pos >= mT[j]) { mpos[j] = pos; mstep[j] = ne; }
+        // (the targets ascend: the marks are met in turn, one compare per step)
+        if (!open && pos >= nextT) {   // (rare: four times per column)
+          while (mj < TPROG_MARKS && pos >= mT[mj]) { mpos[mj] = pos; mstep[mj] = ne; ++mj; }
+          nextT = (mj < TPROG_MARKS) ? mT[mj] : 0x7FFFFFFF;
         }
         open = tprog_kind(e) == TPROG_KIND_GROUP && !tprog_closes(e);
         cost += (tprog_kind(e) == TPROG_KIND_HOT) ? 2 : 3;

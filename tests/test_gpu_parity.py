@@ -734,6 +734,32 @@ def test_tie_program_most_steps_per_row(hip_ctx, n):
     _check(hip_ctx, X, pi, pj, perspective="global")
 
 
+@pytest.mark.parametrize("split", ["1", "2", "4", None])
+@pytest.mark.parametrize("n", [70, 900, 2500, 6887, 17000, 30000])
+def test_task_segments(plan_ctx, n, split):
+    """A task list that leaves the chip half empty is cut in segments (a wave per segment: it inserts the rows in front of
+    its segment uncounted, walks its part, the segments add their counts up).  1 / 2 / 4 segments forced, and the library's
+    own choice, on columns whose segment marks fall in the singleton region (continuous data: the only tie group is the
+    missing rows'), inside the tie program (tied data), behind a long first tie group (a mark cannot cut a group: marks
+    coincide, segments are empty), on one group only, and on columns too short for any mark."""
+    rng = np.random.default_rng(n + 5)
+    cols = [rng.standard_normal(n), rng.standard_normal(n),                       # continuous
+            np.round(rng.standard_normal(n) * 40), np.round(rng.standard_normal(n) * 3),   # tied, many / few groups
+            np.where(np.arange(n) < n // 2, 7.0, rng.standard_normal(n) - 9.0),   # the LARGEST value ties half the rows: the walk starts inside a long group
+            np.full(n, 1.5),                                                        # one group
+            np.repeat(np.arange((n + 39) // 40, dtype=np.float64), 40)[:n],         # groups of 40 rows, in row order
+            rng.permutation(np.repeat(np.arange((n + 69) // 70, dtype=np.float64), 70)[:n])]
+    X = np.asfortranarray(np.stack(cols, axis=1))
+    X[rng.random(X.shape) < 0.08] = np.nan
+    X[: n // 3, 1] = np.nan                                                          # a long closed-form tail
+    S = X.shape[1]
+    pi, pj = np.triu_indices(S, k=1)
+    pi, pj = np.concatenate([pi, pj]).astype(np.int32), np.concatenate([pj, pi]).astype(np.int32)
+    plan_ctx.debug_set_plan({"split": split, "np": "2"} if split is not None else None)
+    for persp in ("global", "local"):
+        _check(plan_ctx, X, pi, pj, perspective=persp)
+
+
 @pytest.mark.parametrize("mode", ["staged", "pinned"])
 def test_host_upload_modes(plan_ctx, mode):
     """The host-buffer entry copies the matrix in column chunks that overlap the pre-pass; staged through the library's

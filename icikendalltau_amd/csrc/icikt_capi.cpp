@@ -1130,6 +1130,10 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   const size_t span = (n_samp > 0 && n_feat > 0) ? ((size_t)(n_samp - 1) * (size_t)ld + (size_t)n_feat) * sizeof(double) : 0;
   const bool can = !c->pv.wide && n_feat > 0 && c->n_pairs > 0;
   const bool want = c->pipe_mode < 0 ? (span >= ((size_t)24 << 20)) : (c->pipe_mode == 1 && (size_t)n_samp * col_bytes > ((size_t)8 << 20));
+  // A pair list that does not fill the chip several times: copies and pre-pass stay pipelined by chunks, but the pairs run in
+  // ONE launch behind the last chunk's pre-pass -- a launch of a few thousand tasks lasts as long as one task whatever its
+  // size, and a launch per chunk puts those latencies one behind the other (50 000 x 96 tied columns: 15.5 -> 9.5 ms)
+  const bool merge_launches = c->plan_ov.merge >= 0 ? c->plan_ov.merge != 0 : c->n_pairs < (int64_t)4 * 48 * c->prop.multiProcessorCount;
   if (!(can && want)) {
     int rc = upload_and_prepare(c, X, n_feat, n_samp, ld, 0, n_samp, flags);
     if (rc) return rc;
@@ -1168,7 +1172,7 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
     const std::function<int(size_t, int64_t)> on_chunk = [&](size_t q, int64_t ce) -> int {
       // (18 337 .. 30 656 rows: the first chunk's columns say which kernel family runs; both take two pairs per task)
       if (q == 0 && matrix_tied(c, ce, c->ev_chunk[0])) pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, true);
-      const size_t first = nt;
+      const size_t first_q = nt;
       if (pl.np == 2) {
         for (int64_t a2 = 0; a2 < ce; a2 += 2) {          // gathered block: columns a2, a2 + 1
           const int64_t c1 = a2 + 1;
@@ -1183,6 +1187,8 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
           for (int64_t j = std::max(cb, i + 1); j < ce; ++j) { u[2 * nt] = pidx(i, j); u[2 * nt + 1] = -1; ++nt; }
       }
       cb = ce;
+      if (merge_launches && ce < n_samp) return ICIKT_SUCCESS;   // (the whole list in one launch, behind the last chunk)
+      const size_t first = merge_launches ? 0 : first_q;
       const size_t cnt = nt - first;
       if (cnt == 0) return ICIKT_SUCCESS;
       // (the launches stay on ONE stream: alternating consecutive chunks' launches between two streams, so that one starts
@@ -1249,9 +1255,11 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   t_up = ms_since();
   rc = timer_begin(c, ICIKT_K_PAIRS, flags);
   for (size_t q = 0; q < nchunks && rc == 0; ++q) {
+    if (merge_launches && q + 1 < nchunks) continue;   // (one launch behind the last chunk: see above)
     const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_chunk[q], 0);
     if (e != hipSuccess) { rc = fail(c, ICIKT_E_HIP, std::string("pipelined pairs: ") + hipGetErrorString(e)); break; }
-    rc = launch_pair_tasks(c, pl, first[q], first[q + 1] - first[q]);
+    if (merge_launches) rc = launch_pair_tasks(c, pl, first[0], first[nchunks] - first[0]);
+    else rc = launch_pair_tasks(c, pl, first[q], first[q + 1] - first[q]);
   }
   }
   if (rc) { (void)hipStreamSynchronize(c->prep_stream); return rc; }
@@ -1702,6 +1710,7 @@ int icikt_debug_set_plan(icikt_ctx* c, const char* spec) {
     else if (key == "list") ov.list = atoi(val.c_str());
     else if (key == "solo") ov.solo = atoi(val.c_str());
     else if (key == "split") ov.split = atoi(val.c_str());
+    else if (key == "merge") ov.merge = atoi(val.c_str());
     else if (key == "waves") ov.waves = atoi(val.c_str());
     else if (key == "verbose") ov.verbose = (val[0] == '1');
     else if (key == "gridmult") ov.grid_mult = atoi(val.c_str());

@@ -117,6 +117,7 @@ struct icikt_ctx {
     bool has_tgmax = false;
     int tgmax = 0;
     int waves = -1;     // half-wave kernels: waves per CU the counter tables may cost the launch down to (default: none)
+    int merge = -1;     // pipelined host entries: 1 = the pairs in ONE launch behind the last chunk, 0 = a launch per chunk, whatever the pair count
     int split = -1;     // half-wave kernels: segments per task (1 | 2 | 4), whatever the launch's size
     int solo = -1;      // 0: SOLO steps of the tie program run as MIXED steps (with the in-step chains)
     int list = -1;      // list mode (range counts per listed tie group) up to this many tie groups: count mode takes over above

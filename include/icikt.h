@@ -309,7 +309,7 @@ int icikt_selftest(icikt_ctx *ctx);
  * mode -- up to this many of them; -1 = per-row mode), list (list mode up to this many tie groups, <= 128: count mode
  * takes over above), solo (0: SOLO steps run as MIXED steps), waves (half-wave kernels: waves per CU down to which the
  * pairs' counter tables may cost the launch occupancy), split (1 | 2 | 4: segments a half-wave task is cut in, whatever the
- * launch's size), gridmult / gridcap (persistent grid of the long-column kernel: a
+ * launch's size), merge (0 | 1: the pipelined host entries' pairs in a launch per chunk | in one launch behind the last chunk), gridmult / gridcap (persistent grid of the long-column kernel: a
  * multiple of the resident workgroups / at most this many), pipe (0 | 1: the host entries' chunk pipeline), k0 (0 | 1: the
  * pre-pass always in its 1 024-thread / 256-thread shape), verbose (0 | 1: print the chosen plan to stderr). */
 int icikt_debug_set_plan(icikt_ctx *ctx, const char *spec);

@@ -134,6 +134,8 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   //  half-wave kernels win at every size on tied data -- yeast cut to 4 .. 32 columns: 0.13 against 0.22 ms -- and draw level
   //  on continuous data, 0.08 against 0.07 ms at 10 000 x 8 .. 32: only the whole-wave family still drops to one pair per wave)
   if (n_pairs <= (int64_t)4 * n_cu && !half_ok) np = 1;
+  // columns too long for the half-wave kernels whose tie groups are many and short (matrix_tied): one pair per wave
+  if (tied && !half_fits) np = 1;
   // overrides for experiments and tests (icikt_debug_set_plan; the product path reads no environment variable)
   if (ov.np == 1 || ov.np == 2) np = ov.np;
   int wpb = 4;
@@ -213,13 +215,18 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   return pl;
 }
 
-// Do the prepared columns hold tie groups beyond a fill group or so?  Only asked where the answer chooses the kernel
-// family (18 337 .. 30 656 rows): the statistics of up to 64 columns are read back once per prepared matrix -- after
-// `ready` (an event behind their pre-pass; nullptr: the context's stream) -- and the verdict is kept.
+// Do the prepared columns hold tie groups beyond a fill group or so?  Only asked where the answer chooses the kernel:
+// 18 337 .. 30 656 rows (the kernel family), and longer columns (pairs per wave: columns of many SHORT tie groups -- on
+// average fewer than 32 rows per group -- run their tie steps one pair after the other whatever shares the wave, and one
+// pair per wave then has twice the waves to hide a step's latency: 50 000 x 512 columns of ~10-row groups 123 -> 88 ms;
+// columns of long groups share their gathers and keep two pairs per wave, 75 against 113 ms).  The statistics of up to 64
+// columns are read back once per prepared matrix -- after `ready` (an event behind their pre-pass; nullptr: the context's
+// stream) -- and the verdict is kept.
 bool matrix_tied(icikt_ctx* c, int64_t ncols_ready, hipEvent_t ready) {
   const PrepView& pv = c->pv;
   const int hi = icikt::k1_half_items(pv.Wp);
-  if (pv.wide || hi <= 9 || hi > icikt::ICIKT_HALF_ITEMS_MAX || pv.n <= 0 || c->plan_ov.half >= 0) return false;
+  const bool long_cols = hi > icikt::ICIKT_HALF_ITEMS_MAX;
+  if (pv.wide || hi <= 9 || pv.n <= 0 || (!long_cols && c->plan_ov.half >= 0) || (long_cols && c->plan_ov.np > 0)) return false;
   if (c->tied_state >= 0) return c->tied_state != 0;
   const int64_t m = std::min<int64_t>(std::min<int64_t>(ncols_ready, pv.n_samp), 64);
   if (m <= 0) return false;
@@ -231,11 +238,17 @@ bool matrix_tied(icikt_ctx* c, int64_t ncols_ready, hipEvent_t ready) {
     (void)hipGetLastError();
     return false;
   }
-  unsigned long long groups = 0;
-  for (const auto& t : st) groups += t.ntg;
-  c->tied_state = (groups > 8ull * (unsigned long long)m) ? 1 : 0;
-  if (c->plan_ov.verbose) fprintf(stderr, "[icikt] %lld columns read back: %.1f tie groups per column -> %s kernels\n", (long long)m,
-                                  (double)groups / (double)m, c->tied_state ? "half-wave" : "whole-wave");
+  unsigned long long groups = 0, all_groups = 0, rows = 0;
+  for (const auto& t : st) {
+    groups += t.ntg;
+    all_groups += (unsigned long long)std::max(t.ngroups, 1);
+    rows += (unsigned long long)std::max(0, pv.n - t.nna);
+  }
+  const bool tied = groups > 8ull * (unsigned long long)m;
+  c->tied_state = (tied && (!long_cols || rows < 32ull * all_groups)) ? 1 : 0;
+  if (c->plan_ov.verbose) fprintf(stderr, "[icikt] %lld columns read back: %.1f tie groups per column, %.1f rows per group -> %s\n", (long long)m,
+                                  (double)groups / (double)m, (double)rows / (double)all_groups,
+                                  long_cols ? (c->tied_state ? "one pair per wave" : "two pairs per wave") : (c->tied_state ? "half-wave kernels" : "whole-wave kernels"));
   return c->tied_state != 0;
 }
 
@@ -1112,7 +1125,7 @@ int upload_and_prepare(icikt_ctx* c, const double* X, int64_t n_feat, int64_t n_
 // copies and the pre-pass run) instead of inside icikt_run_dev, which then only uploads it.
 void prebuild_units(icikt_ctx* c) {
   if (c->n_pairs <= 0 || c->pv.wide) return;
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, false);   // (np does not depend on `tied`)
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, false);   // (icikt_run_dev rebuilds the list if the columns' tie structure asks for another np)
   if (c->wpb != pl.np) {
     build_units(c, pl.np);
     c->units_dirty = true;

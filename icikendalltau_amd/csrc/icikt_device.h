@@ -114,7 +114,7 @@ struct PrepView {
   int tg_stride;                 // n_pad / 2 + 1
   // The tie program of a column as the STREAMED side of a half-wave kernel (n <= 30 656): the steps the pair kernel
   // takes from where the column's tie groups begin, cut and classified ONCE per column by the pre-pass instead of by
-  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  Round 5: a step comes with its RECORD --
+  // every one of its S - 1 pairs (k0_tie_program; entry layout: TPROG_*).  Round 4, second half: a step comes with its RECORD --
   //   srow   the rows of the step in the LANE LAYOUT the pair kernel runs it in, 64 entries whatever the step holds
   //          (HOT / GROUP: lane = row of the step; MIXED: lanes 0..31 the first sub-step, lanes 32..63 the second);
   //          an empty lane names the guard row (rec_rows above).  The pair kernel reads them three steps ahead like the

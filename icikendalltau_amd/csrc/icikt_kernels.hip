@@ -2709,7 +2709,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // delivers them), and when the group closes its rows are INSERTED together (phase B: from registers when the
         // group is one or two steps, else by streaming its positions a second time) and the prefix is rebuilt once.
         // The group's joint ties, sum over the gathered column's tie groups g of C(rows of the group in g, 2):
-        //   COUNT MODE (round 5; the gathered column's tie groups have a counter each in the pair's table): a row adds one
+        //   COUNT MODE (round 4, second half; the gathered column's tie groups have a counter each in the pair's table): a row adds one
         //     to the counter of its tie group (girow) in phase A; at the close every row reads its counter back, c, and
         //     counts c - 1 -- every pair twice: tie2 -- then clears it (one or two steps, rows still in registers), or the
         //     lanes read and clear the column's counters, C(c, 2) each (longer groups).  Two LDS operations per row

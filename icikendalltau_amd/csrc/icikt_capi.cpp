@@ -101,7 +101,7 @@ struct K1Plan {
   int split;         // half-wave kernels: segments a task is cut in (1 | 2 | 4) when the task list leaves the chip half empty
 };
 
-K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov, bool tied) {
+K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::PlanOverride& ov, bool tied, int ntg_hint = -1, int group_hint = 0) {
   K1Plan pl{};
   const size_t lds_cap = 160 * 1024;
   // n <= 18 336 (a half wave rebuilds a prefix with <= 9 words per lane): two pairs per wave, one per 32-lane half.
@@ -187,12 +187,28 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     const int waves_needed = (int)std::min<int64_t>(waves_max, std::max<int64_t>(wpb, (tasks * pl.split + n_cu - 1) / std::max(1, n_cu)));
     int waves_target = std::min(waves_needed, std::max(wpb, waves_fit(0)));
     if (ov.waves > 0) waves_target = std::min(waves_target, std::max(wpb, ov.waves));
+    const int tg_list_max = row_only ? 0 : (pl.half_items > 9 ? 256 : 128);   // (list mode's reach in this kernel, below)
     int cap = 0;
     if (!row_only) {
       static const int caps[] = {4094, 3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 64};
       for (int cc : caps) {
         if (cc > pv.n / 2 + 64 && cc > 64) continue;              // (a column of n rows has at most n / 2 tie groups)
         if (waves_fit(cc) >= waves_target) { cap = cc; break; }
+      }
+      // Columns of 14 273 rows and more leave the tables next to nothing at that occupancy (15 words per lane: 64 counters
+      // beside 4.9 KB of state per pair).  When the prepared columns' statistics (matrix_tied: read back once per matrix at
+      // these lengths) say that their tie groups would fit a table at three waves per SIMD, the table is worth the waves:
+      // count data -- negative binomial, ~700 tie groups per column, nine rows in ten in groups of more than 32 -- 20 000 x
+      // 256: 4.2 -> 3.2 ms, 30 000 x 256: 6.8 -> 4.7 (row mode streams a long group three times).
+      // (... when list mode cannot serve them and a tied pair of rows sits, on average, in a group of 256 rows or more -- from the
+      //  columns' tie sums, fill group apart: 30 000-row columns of 600 tie groups of ~100 rows run 1.61 ms in row mode at four waves
+      //  per SIMD, 1.98 in count mode at three)
+      if (ntg_hint > std::max(cap, tg_list_max) && group_hint >= 256 && ov.waves <= 0 && pl.half_items >= 9) {
+        for (int i = (int)(sizeof(caps) / sizeof(caps[0])) - 1; i >= 0; --i) {
+          if (caps[i] < ntg_hint) continue;
+          if (waves_fit(caps[i]) >= 12) cap = caps[i];
+          break;
+        }
       }
       if (ov.has_tgmax) cap = std::min(cap, tg_max);
     }
@@ -226,7 +242,8 @@ bool matrix_tied(icikt_ctx* c, int64_t ncols_ready, hipEvent_t ready) {
   const PrepView& pv = c->pv;
   const int hi = icikt::k1_half_items(pv.Wp);
   const bool long_cols = hi > icikt::ICIKT_HALF_ITEMS_MAX;
-  if (pv.wide || hi <= 9 || pv.n <= 0 || (!long_cols && c->plan_ov.half >= 0) || (long_cols && c->plan_ov.np > 0)) return false;
+  // (9 words per lane: the family is the half-wave one anyway; the read-back serves the size of the counter tables, plan_k1)
+  if (pv.wide || hi < 9 || pv.n <= 0 || (!long_cols && c->plan_ov.half >= 0) || (long_cols && c->plan_ov.np > 0)) return false;
   if (c->tied_state >= 0) return c->tied_state != 0;
   const int64_t m = std::min<int64_t>(std::min<int64_t>(ncols_ready, pv.n_samp), 64);
   if (m <= 0) return false;
@@ -239,15 +256,26 @@ bool matrix_tied(icikt_ctx* c, int64_t ncols_ready, hipEvent_t ready) {
     return false;
   }
   unsigned long long groups = 0, all_groups = 0, rows = 0;
+  c->ntg_hint = 0;
+  c->group_hint = 0;
+  double g0 = 0.0, g1 = 0.0;
   for (const auto& t : st) {
     groups += t.ntg;
+    c->ntg_hint = std::max(c->ntg_hint, (int)std::min<uint32_t>(t.ntg, 1u << 20));
+    // the size of the tie group a random tied PAIR of rows sits in, fill group apart: sum t (t-1) (t-2) / sum t (t-1) + 2
+    {
+      const long long f = t.tfill;
+      g0 += (double)(t.e0 - f * (f - 1));
+      g1 += (double)(t.e1 - f * (f - 1) * (f - 2));
+    }
     all_groups += (unsigned long long)std::max(t.ngroups, 1);
     rows += (unsigned long long)std::max(0, pv.n - t.nna);
   }
+  c->group_hint = (g0 > 0.0) ? (int)std::min(1.0e6, g1 / g0 + 2.0) : 0;
   const bool tied = groups > 8ull * (unsigned long long)m;
   c->tied_state = (tied && (!long_cols || rows < 32ull * all_groups)) ? 1 : 0;
-  if (c->plan_ov.verbose) fprintf(stderr, "[icikt] %lld columns read back: %.1f tie groups per column, %.1f rows per group -> %s\n", (long long)m,
-                                  (double)groups / (double)m, (double)rows / (double)all_groups,
+  if (c->plan_ov.verbose) fprintf(stderr, "[icikt] %lld columns read back: %.1f tie groups per column (at most %d), %.1f rows per group, a tied pair's group %d rows -> %s\n", (long long)m,
+                                  (double)groups / (double)m, c->ntg_hint, (double)rows / (double)all_groups, c->group_hint,
                                   long_cols ? (c->tied_state ? "one pair per wave" : "two pairs per wave") : (c->tied_state ? "half-wave kernels" : "whole-wave kernels"));
   return c->tied_state != 0;
 }
@@ -651,6 +679,8 @@ int prepare_launch(icikt_ctx* c, const double* dX, int64_t ld, int64_t col_begin
   if (!stream) stream = c->stream;
   c->raw_valid = false;
   c->tied_state = -1;
+  c->ntg_hint = -1;
+  c->group_hint = 0;
   if (col_end > col_begin)
     HIPCHK(c, hipMemsetAsync(c->meta.p + (size_t)col_begin * pv.mstride, 0,
                              (size_t)(col_end - col_begin) * pv.mstride * sizeof(unsigned long long), stream));
@@ -850,8 +880,8 @@ int icikt_run_dev(icikt_ctx* c, int perspective, int alternative, int continuity
   // continuity: with ICIKT_FLAG_REUSE_COUNTS a second run over the same prepared matrix and pair list (the other
   // perspective of BASELINE config 5, another alternative) is the epilogue alone.
   const bool reuse = (flags & ICIKT_FLAG_REUSE_COUNTS) && c->raw_valid;
-  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov,
-                           reuse ? false : matrix_tied(c, c->pv.n_samp, nullptr));
+  const bool tied = reuse ? false : matrix_tied(c, c->pv.n_samp, nullptr);
+  const K1Plan pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, tied, c->ntg_hint, c->group_hint);
   if (c->pv.n > 0 && !reuse) {
     if (c->wpb != pl.np) {
       build_units(c, pl.np);
@@ -1184,7 +1214,10 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
     int64_t cb = 0;
     const std::function<int(size_t, int64_t)> on_chunk = [&](size_t q, int64_t ce) -> int {
       // (18 337 .. 30 656 rows: the first chunk's columns say which kernel family runs; both take two pairs per task)
-      if (q == 0 && matrix_tied(c, ce, c->ev_chunk[0])) pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, true);
+      if (q == 0) {
+        const bool tied = matrix_tied(c, ce, c->ev_chunk[0]);
+        if (tied || c->ntg_hint >= 0) pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, tied, c->ntg_hint, c->group_hint);
+      }
       const size_t first_q = nt;
       if (pl.np == 2) {
         for (int64_t a2 = 0; a2 < ce; a2 += 2) {          // gathered block: columns a2, a2 + 1
@@ -1227,8 +1260,10 @@ int upload_prepare_pairs(icikt_ctx* c, const double* X, int64_t n_feat, int64_t 
   c->prepared = true;
   t_enq = ms_since();
   nchunks = c->chunk_col_end.size();
-  if (nchunks > 0 && matrix_tied(c, c->chunk_col_end[0], c->ev_chunk[0]))
-    pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, true);
+  if (nchunks > 0) {
+    const bool tied = matrix_tied(c, c->chunk_col_end[0], c->ev_chunk[0]);
+    if (tied || c->ntg_hint >= 0) pl = plan_k1(c->pv, c->n_pairs, c->prop.multiProcessorCount, c->plan_ov, tied, c->ntg_hint, c->group_hint);
+  }
   build_units(c, pl.np);
   // tasks by the chunk of their last column (a stable counting sort: inside a chunk the cache-friendly order stays)
   const int T = c->n_units;

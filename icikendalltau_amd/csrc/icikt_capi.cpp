@@ -121,7 +121,11 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   // masks; n = 30 000, ~15 000 / 3 000 / 600 distinct values: 1.48 / 1.95 / 1.74 ms vs 2.46 / 4.12 / 2.83): `tied` (the
   // prepared columns average more than eight tie groups: matrix_tied below) chooses.
   const bool half_fits = icikt::k1_half_items(pv.Wp) <= icikt::ICIKT_HALF_ITEMS_MAX;
-  const bool half_ok = half_fits && (icikt::k1_half_items(pv.Wp) <= 9 || (ov.half < 0 ? tied : ov.half != 0));
+  // (15 200 .. 18 336 rows, the upper part of nine words per lane: the same choice, for less -- continuous columns 3-5 % faster in
+  //  the long-column kernel, n = 16 000: 2.48e7 vs 2.38e7 pairs/s, 18 336: 2.07e7 vs 1.97e7; level at 14 400)
+  const int hi_words = icikt::k1_half_items(pv.Wp);
+  const bool both_fit = hi_words > 9 || (hi_words == 9 && pv.n >= 15200 && n_pairs > (int64_t)4 * n_cu);   // (a short task list: the half-wave kernels, cut in segments)
+  const bool half_ok = half_fits && (!both_fit || (ov.half < 0 ? tied : ov.half != 0));
   int np = half_ok ? 2 : 1;
   {
     const size_t two = 2 * ((size_t)icikt::k1_lds_stride(pv.Wp, 0) * 8 + icikt::K1_TL_BYTES);
@@ -145,7 +149,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
   }
   if (ov.wpb > 0) wpb = std::max(1, std::min(8, ov.wpb));
   pl.opts = 1;
-  if (ov.half >= 0 && icikt::k1_half_items(pv.Wp) <= 9) pl.opts = ov.half ? 1 : 0;
+  if (ov.half >= 0 && !both_fit) pl.opts = ov.half ? 1 : 0;
   int tg_max = 128;  // bits 8..: whole-wave kernels: joint ties of a closing group from the gathered column's tie-group list
                      // while it has at most this many groups (the kernels cap it at 128: two listed groups per lane), else row
                      // by row; half-wave kernels: the entries of a pair's counter table (count mode), sized below
@@ -232,7 +236,7 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
 }
 
 // Do the prepared columns hold tie groups beyond a fill group or so?  Only asked where the answer chooses the kernel:
-// 18 337 .. 30 656 rows (the kernel family), and longer columns (pairs per wave: columns of many SHORT tie groups -- on
+// 15 200 .. 30 656 rows (the kernel family), and longer columns (pairs per wave: columns of many SHORT tie groups -- on
 // average fewer than 32 rows per group -- run their tie steps one pair after the other whatever shares the wave, and one
 // pair per wave then has twice the waves to hide a step's latency: 50 000 x 512 columns of ~10-row groups 123 -> 88 ms;
 // columns of long groups share their gathers and keep two pairs per wave, 75 against 113 ms).  The statistics of up to 64

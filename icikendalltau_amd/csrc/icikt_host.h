@@ -61,7 +61,7 @@ struct icikt_ctx {
   int wpb = 0;  // pairs per wave (np) the tasks were built for; 0 = not built
   int group_hint = 0;      // ... and the size of the tie group a random tied pair of their rows sits in (fill groups apart)
   int ntg_hint = -1;       // the most tie groups among the columns whose statistics matrix_tied() read back (-1: not read)
-  int tied_state = -1;     // 18 337 .. 30 656 rows: do the prepared columns hold many tie groups (1), not (0), not asked yet (-1)
+  int tied_state = -1;     // 15 200 .. 30 656 rows (and longer columns: pairs per wave): do the prepared columns hold many tie groups (1), not (0), not asked yet (-1)
   bool raw_valid = false;  // d_raw holds the pair kernel's counts for the current prepared matrix and pair list
   DevBuf<int32_t> d_pi, d_pj, d_unit_start;
   DevBuf<icikt::PairRaw> d_raw;

@@ -383,6 +383,23 @@ def test_one_pair_per_wave_plans(hip_ctx, n):
         _check(hip_ctx, X, perspective=p)
 
 
+@pytest.mark.parametrize("n", [15200, 17000])
+@pytest.mark.parametrize("tied", [False, True])
+def test_kernel_family_by_tie_structure_nine_words(plan_ctx, n, tied):
+    """15 200 .. 18 336 rows with a task list that fills the chip: continuous columns take the long-column kernel, tied
+    ones the half-wave kernels (plan_k1 / matrix_tied) -- both against the oracle, and against either family forced."""
+    rng = np.random.default_rng(n + int(tied))
+    X = rng.standard_normal((n, 48))                   # 1 128 pairs: more than four per CU
+    if tied:
+        X = np.round(X * 150)                          # ~900 distinct values
+    X[rng.random(X.shape) < 0.03] = np.nan
+    auto = _check(plan_ctx, X, perspective="global")
+    for half in ("0", "1"):
+        plan_ctx.debug_set_plan({"half": half})
+        forced = plan_ctx.pairs(X, perspective="global")
+        assert np.array_equal(forced[1], auto[1]) and np.array_equal(forced[0], auto[0], equal_nan=True)
+
+
 def test_max_length_65535(hip_ctx):
     rng = np.random.default_rng(47)
     n = 65535

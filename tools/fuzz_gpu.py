@@ -5,11 +5,12 @@ levels, blocks of equal values, constants), a missingness pattern (random, left-
 a K1 launch plan override (pairs per wave, pend placement, half-wave step, joint-tie mode), then compares
 counts bit-exactly and the four doubles within 1e-10 for both perspectives.
 
-    python tools/fuzz_gpu.py [cases] [seed] [big|mid|ext|r4]
+    python tools/fuzz_gpu.py [cases] [seed] [big|mid|ext|r4|fam]
 
 `mid`: 16 000 .. 31 000 rows (both kernel families of 18 337 .. 30 656 rows, the windows of the tie program) with
 two more value models: many small tie groups (n / 2 .. n / 40 distinct values) and a tied region beside a
-continuous one.  `ext`: the default lengths with those two models.
+continuous one.  `ext`: the default lengths with those two models.  `fam`: 15 200 .. 31 000 rows x 48 columns (a task list
+that fills the chip: the library chooses the kernel family from the columns' tie structure), half of the matrices continuous.
 """
 import os
 import sys
@@ -25,6 +26,7 @@ ATOL = 1e-10
 BIG = False  # set by main(): argv[3] == 'big'
 MID = False  # set by main(): argv[3] == 'mid'
 EXT = False  # set by main(): argv[3] == 'ext' (the default lengths with the two extra value models)
+FAM = False  # set by main(): argv[3] == 'fam'
 R4 = False   # set by main(): argv[3] == 'r4': `ext` + values that collide in the pre-pass's one-word sort (its second pass)
              # + the pre-pass shape (plan key k0) drawn at random
 
@@ -79,7 +81,9 @@ def make_column(rng, n):
 
 def one_case(ctx, rng, case):
     r = rng.random()
-    if BIG:  # long columns only: the one-pair-per-wave kernels, pend in LDS and in global memory
+    if FAM:
+        n = int(rng.integers(15200, 18337)) if rng.random() < 0.7 else int(rng.integers(18337, 31000))
+    elif BIG:  # long columns only: the one-pair-per-wave kernels, pend in LDS and in global memory
         n = int(rng.integers(10000, 65536))
     elif MID:
         n = int(rng.integers(16000, 31000))
@@ -92,7 +96,18 @@ def one_case(ctx, rng, case):
     S = int(rng.integers(2, 9)) if n < 6000 else int(rng.integers(2, 5))
     if BIG or MID:
         S = int(rng.integers(2, 4))
-    X = np.asfortranarray(np.stack([make_column(rng, n) for _ in range(S)], axis=1))
+    if FAM:
+        S = 48
+        if rng.random() < 0.5:   # continuous columns (a few ties at most), missing values at random
+            X = rng.standard_normal((n, S))
+            X[rng.random(X.shape) < rng.choice([0.0, 0.02, 0.3])] = np.nan
+            if rng.random() < 0.5:
+                X[:, int(rng.integers(0, S))] = np.round(X[:, 0] * 3)
+            X = np.asfortranarray(X)
+        else:
+            X = np.asfortranarray(np.stack([make_column(rng, n) for _ in range(S)], axis=1))
+    else:
+        X = np.asfortranarray(np.stack([make_column(rng, n) for _ in range(S)], axis=1))
     if rng.random() < 0.3 and S > 2:  # correlated columns: shared rows missing, shared ties
         X[:, 1] = np.where(rng.random(n) < 0.7, X[:, 0], X[:, 1])
     env = {  # launch-plan overrides (icikt_debug_set_plan); "" = the library's choice
@@ -101,6 +116,8 @@ def one_case(ctx, rng, case):
         "half": rng.choice(["", "0", "1"]),
         "tgmax": rng.choice(["", "-1", "2", "1000000"]),
     }
+    if FAM:
+        env = {"np": "", "pend": "", "half": rng.choice(["", "", "", "0", "1"]), "tgmax": rng.choice(["", "", "-1", "300"])}
     if R4:
         env["k0"] = rng.choice(["", "0", "1"])
         # round 4, second half: the joint-tie modes of long tie groups (list / count / row) and SOLO steps, forced apart
@@ -143,7 +160,8 @@ def one_case(ctx, rng, case):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    global BIG, MID, EXT, R4
+    global BIG, MID, EXT, R4, FAM
+    FAM = len(sys.argv) > 3 and sys.argv[3] == "fam"
     R4 = len(sys.argv) > 3 and sys.argv[3] == "r4"
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     MID = len(sys.argv) > 3 and sys.argv[3] == "mid"

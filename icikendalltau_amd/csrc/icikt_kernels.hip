@@ -1794,20 +1794,37 @@ __device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st,
   // 64 - (group number 1 .. 64); the first half of a half-wave kernel is tagged above it, so that what the shifts
   // carry from pair 0's lanes into pair 1's compares as greater too
   const uint32_t gdown = ((64u - (uint32_t)__popcll(upto)) << 16) | ((SEG == 32 && lane < 32u) ? 0x00800000u : 0u);
-  const uint32_t kq = valid ? (gdown | q) : 0xFFFFFFFFu, klo = valid ? (gdown | lo) : 0u;
+  const uint32_t klo = valid ? (gdown | lo) : 0u;
   // longest run of rows that continue a group = largest group - 1 (wave-uniform, from the flags)
+  // (without a loop: runs of 2, 4, .. 32 by doubling, then the longest run bit by bit from the top -- R(a + b) = R(a) & R(b) >> a)
   int dmax = 0;
   {
-    unsigned long long z = ~Fs & ((nact >= 64) ? ~0ull : ((1ull << nact) - 1ull));
-    while (z != 0ull) { z &= z >> 1; ++dmax; }
+    const unsigned long long z = ~Fs & ((nact >= 64) ? ~0ull : ((1ull << nact) - 1ull));
+    const unsigned long long p2 = z & (z >> 1), p4 = p2 & (p2 >> 2), p8 = p4 & (p4 >> 4), p16 = p8 & (p8 >> 8), p32 = p16 & (p16 >> 16);
+    unsigned long long cur = ~0ull, t;
+    t = cur & p32;             if (t != 0ull) { cur = t; dmax = 32; }
+    t = cur & (p16 >> dmax);   if (t != 0ull) { cur = t; dmax += 16; }
+    t = cur & (p8 >> dmax);    if (t != 0ull) { cur = t; dmax += 8; }
+    t = cur & (p4 >> dmax);    if (t != 0ull) { cur = t; dmax += 4; }
+    t = cur & (p2 >> dmax);    if (t != 0ull) { cur = t; dmax += 2; }
+    t = cur & (z >> dmax);     if (t != 0ull) { cur = t; dmax += 1; }
   }
-  uint32_t sq = kq, slo = valid ? klo : 0xFFFFFFFFu, spur = 0, tie = 0;
-  for (int d = 0; d < dmax; ++d) {
-    sq = dpp_wave_shr1(0xFFFFFFFFu, sq);    // lane l now holds lane l - (d + 1)
-    slo = dpp_wave_shr1(0xFFFFFFFFu, slo);
-    spur += (sq < klo) ? 1u : 0u;           // same group (equal upper halves) and q_prev < lo_me
-    tie += (slo == klo) ? 1u : 0u;          // same group and same tie group of the gathered column
+  // (round 4: the tie groups of the gathered column are disjoint ranges of positions and lo is the start of a row's range, so
+  //  q_prev < lo_me <=> lo_prev < lo_me: ONE shifted operand serves both counts.  The shift runs in place -- lane 0 is never
+  //  written and keeps the "greater than anything" of the first shift, which the later shifts carry upwards -- and the loop is
+  //  five vector instructions per distance; the compiler's version of the two-operand loop took ten, four of them copies.)
+  uint32_t slo = dpp_wave_shr1(0xFFFFFFFFu, valid ? klo : 0xFFFFFFFFu);   // lane l holds lane l - 1
+  uint32_t spur = 0, tie = 0;
+  asm volatile("s_nop 1" : "+v"(slo));      // (a DPP operand written by the previous vector instruction: two wait states)
+  // (four distances per turn: a distance beyond the step's largest group counts nothing -- only lanes of earlier groups arrive)
+#define ICIKT_SHIFT_DIST "v_cmp_lt_u32_e32 vcc, %0, %3\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t" /* same group (equal upper halves), the earlier row's tie group below mine */ \
+                         "v_cmp_eq_u32_e32 vcc, %0, %3\n\tv_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t" /* same group, same tie group of the gathered column */ \
+                         "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"               /* the next distance */
+  for (int d = 0; d < dmax; d += 4) {
+    asm volatile(ICIKT_SHIFT_DIST ICIKT_SHIFT_DIST ICIKT_SHIFT_DIST ICIKT_SHIFT_DIST
+                 : "+v"(slo), "+v"(spur), "+v"(tie) : "v"(klo) : "vcc");
   }
+#undef ICIKT_SHIFT_DIST
   if (!valid) { spur = 0; tie = 0; }
   c.neg = spur;
   c.tie = tie;

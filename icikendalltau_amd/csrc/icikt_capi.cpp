@@ -219,7 +219,40 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
     tg_max = cap;
     pl.perpair_bytes = (int)pair_bytes(cap);
   } else {
-    pl.perpair_bytes = (int)((size_t)pl.stride * 8 + icikt::K1_TL_BYTES);                                   // seen + the two-level counts
+    // seen + the two-level counts + the counters of count mode (round 4: the whole-wave kernels too): as many as the LDS holds
+    // beside the waves the launch runs anyway -- 50 000 rows: 512 counters per pair at eight waves of two pairs (or sixteen of one)
+    const size_t base = (size_t)pl.stride * 8 + icikt::K1_TL_BYTES;
+    auto pair_bytes = [&](int cap) { return cap > 0 ? ((base + ICIKT_CNT_BYTES * ((size_t)cap + 2) + 15) & ~(size_t)15) : base; };
+    auto waves_of = [&](size_t pb, int w0) {   // waves a CU holds with pb bytes per pair in workgroups of up to w0 waves
+      const int w = std::max(1, std::min(w0, (int)(lds_cap / (pb * np))));
+      return (int)(lds_cap / ((size_t)w * np * pb)) * w;
+    };
+    auto waves_any = [&](size_t pb) { return std::max(waves_of(pb, wpb), waves_of(pb, 1)); };   // (single-wave workgroups pack the LDS best)
+    int cap = 0;
+    if (!row_only && !ov.has_tgmax) {
+      static const int caps[] = {4094, 3072, 2048, 1536, 1024, 768, 512, 384, 256};
+      const int target = std::min(waves_of(base, wpb), np == 2 ? 12 : 24);   // (the registers' limit: 3 / 6 waves per SIMD)
+      for (int cc : caps) {
+        if (cc > pv.n / 2 + 64) continue;                     // (a column of n rows has at most n / 2 tie groups)
+        if (waves_any(pair_bytes(cc)) >= target) { cap = cc; break; }
+      }
+      // the prepared columns hold more tie groups than that (matrix_tied's read-back): a table that covers them is worth one wave
+      // of eight -- count-like data, 50 000 x 96, ~630 tie groups per column (at most 940): 2.76 ms with 512 counters at eight
+      // waves per CU, 2.48 with 1 024 at seven
+      if (ntg_hint > cap && target >= 6) {
+        for (int i = (int)(sizeof(caps) / sizeof(caps[0])) - 1; i >= 0; --i) {
+          if (caps[i] < ntg_hint) continue;
+          if (waves_any(pair_bytes(caps[i])) >= target - 1) cap = caps[i];
+          break;
+        }
+      }
+      if (cap > 0 && ov.wpb <= 0 && waves_of(pair_bytes(cap), 1) > waves_of(pair_bytes(cap), wpb)) wpb = 1;
+    } else if (!row_only && ov.tgmax > 128) {
+      cap = std::min(ov.tgmax, 4094);   // (tests: a table whatever it costs in waves)
+      while (cap > 0 && pair_bytes(cap) * np > lds_cap) cap /= 2;
+    }
+    pl.perpair_bytes = (int)pair_bytes(cap);
+    pl.opts |= cap << 18;   // bits 18..: entries of a pair's counter table (count mode); 0: none
   }
   // (eight listed groups per lane in the kernels that have the registers: list mode up to 256 tie groups there -- count
   //  mode has 64 counters beside their 4.9 KB of LDS state per pair, and row mode streams a long group three times)
@@ -435,7 +468,7 @@ int launch_pair_tasks(icikt_ctx* c, const K1Plan& pl, int first, int count) {
   if (c->plan_ov.verbose)
     fprintf(stderr, "[icikt] K1 plan: np=%d half_items=%d wpb=%d lds=%zu B/block (%d B/pair, %d tie-group counters), %d blocks/CU x %d CUs, "
             "grid=%d%s, tasks=%d (from %d), %d segment(s) per task\n",
-            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.half_items > 0 ? (pl.opts >> 18) : 0, per_cu,
+            pl.np, pl.half_items, pl.wpb, pl.lds_bytes, pl.perpair_bytes, pl.opts >> 18, per_cu,
             c->prop.multiProcessorCount, blocks, persistent ? " (persistent)" : "", count, first, split);
   HIPCHK(c, icikt::launch_k1(c->pv, c->d_unit_start.p + 2 * (size_t)first, count, c->d_pi.p, c->d_pj.p, c->d_raw.p, pl.np,
                              pl.half_items, pl.wpb, blocks, pl.lds_bytes, pl.perpair_bytes,

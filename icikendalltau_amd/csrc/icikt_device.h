@@ -63,6 +63,7 @@ struct PairRaw {
   uint32_t g;               // rows in both fill groups (== c_both unless fl(min-0.1) == min)
 };
 
+constexpr int K1_CNT_MIN_GROUPS = 8;        // columns too long for the half-wave kernels: girow is written, and count mode used, above this many tie groups
 constexpr uint16_t GIROW_NONE = 0xFFFFu;   // PrepView::girow: the row is its own tie group
 // bytes of a counter of count mode (k1_pairs): 2 -- two to a dword, twice the tie groups per LDS byte -- or 4 (a build
 // option for measurements: -DICIKT_CNT_BYTES=4)

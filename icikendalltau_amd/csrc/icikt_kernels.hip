@@ -568,7 +568,9 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
   const bool stage_hg = !WIDE && pv.n_pad <= 3 * TILE;
   const bool stage_rec = stage_hg && 2 * pv.n_pad <= 3 * TILE;
   uint32_t* hg_s = stage_rec ? rec_s + pv.n_pad : rec_s;
-  const bool want_gi = pv.tp_stride > 0;                                 // (only the half-wave pair kernels read girow)
+  // girow: every column the half-wave pair kernels can run on; longer columns when they hold more than K1_CNT_MIN_GROUPS tie
+  // groups (the whole-wave kernels' count mode asks for nothing less: decided per column below, once its groups are counted)
+  bool want_gi = pv.tp_stride > 0;
 
   const int c = col_begin + blockIdx.x;
   const int tid = threadIdx.x;
@@ -883,6 +885,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
       gbase += btot;
       __syncthreads();   // (sh_i is rewritten by the next block; the tables are complete for the loop below)
     }
+    want_gi = want_gi || gbase > K1_CNT_MIN_GROUPS;
   }
 
   // per-thread tie statistics over the groups that START at my positions
@@ -1910,7 +1913,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // joint ties of a tie group of more than 32 rows, by the gathered column's tie groups: list mode (range counts per listed
   // group) up to tg_list of them (<= 128), count mode (half-wave kernels: a counter per tie group) up to tg_max, else row mode
   const int tg_list = (opts >> 8) & 0x3FF;
-  const int tg_max = half_mode_of<NP, HI>() ? (opts >> 18) : tg_list;
+  // (whole-wave kernels, round 4: a counter table too -- count mode for gathered columns of more than tg_list and more than
+  //  K1_CNT_MIN_GROUPS tie groups, up to the table's entries; the pre-pass writes girow for exactly those long columns)
+  const int tg_max = half_mode_of<NP, HI>() ? (opts >> 18) : max(tg_list, opts >> 18);
+  const int cnt_cap = opts >> 18;   // entries of a pair's counter table (0: none)
   // listed tie groups per lane of a half in list mode: 4 (tg_list <= 128), 8 in the kernels of 11 .. 15 words per lane
   // (tg_list <= 256: they have the registers -- five waves per SIMD -- and the LDS beside their 4.9 KB of state per pair
   // leaves count mode 64 counters)
@@ -2000,8 +2006,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     // half-wave kernels: COUNT MODE while the gathered column's tie groups have a counter each in the pair's table (tg_max =
     // its entries, sized by the host to what the LDS holds at the launch's occupancy); whole-wave kernels: list mode with
     // at most two listed groups per lane
-    ntgB[k] = (!(opts & 2) && ntg_raw <= max(tg_list, tg_max)) ? ntg_raw : -1;
-    cntB[k] = half_mode && ntg_raw > tg_list;    // (read where ntgB[k] >= 0)
+    cntB[k] = half_mode ? (ntg_raw > tg_list) : (ntg_raw > max(tg_list, K1_CNT_MIN_GROUPS));    // (read where ntgB[k] >= 0)
+    ntgB[k] = (!(opts & 2) && ntg_raw <= ((half_mode || cntB[k]) ? max(tg_list, tg_max) : tg_list)) ? ntg_raw : -1;
     g_oddtie = g_oddtie || (__builtin_amdgcn_readfirstlane(pv.col_stats(gcol)->flags) & COL_ODD_TIE) != 0;
     const unsigned long long* mb = pv.col_mask(gcol);
     const unsigned long long* fb = pv.col_fillmask(gcol);
@@ -2014,7 +2020,8 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       S[k].L.spre = reinterpret_cast<uint16_t*>(S[k].L.seen + Wp4);
       for (int w = lane; w < Wp4; w += 64) S[k].L.seen[w] = 0ull;
       uint32_t* tl32 = reinterpret_cast<uint32_t*>(S[k].L.spre);
-      for (int w = lane; w < TL_BYTES / 4; w += 64) tl32[w] = 0u;
+      // (... | the counters of count mode, as in the half-wave kernels: cnt_cap + 2 entries, all zero between groups)
+      for (int w = lane; w < (TL_BYTES + (cnt_cap > 0 ? (cnt_cap + 2) * ICIKT_CNT_BYTES + 3 : 0)) / 4; w += 64) tl32[w] = 0u;
     } else {
       // half-wave kernels: seen | prefix slots of seen (32 lanes x 16 B).  No `pend`: the rows of a tie group of the
       // streamed column are queried first and inserted when the group closes (GROUP steps below)
@@ -2123,9 +2130,9 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   bool grp_open = false;   // half-wave kernels: likewise; grp_start = first position of the open group
   int grp_start = 0, grp_entries = 0;   // grp_entries: steps of the open group so far
   uint32_t sv_k0 = 0, sv_k1 = 0, sv_h = 0;   // the open group's first step: its rows' values, still in registers when the second step closes it
-  uint32_t sv_kw[NP], sv_hw[NP], sneg[NP];     // whole-wave kernels: the same per pair (lane = row); sneg: what is subtracted from a pair's dis
+  uint32_t sv_kw[NP], sv_hw[NP], sv_gw[NP], sneg[NP];     // whole-wave kernels: the same per pair (lane = row; sv_gw: the rows' counters); sneg: what is subtracted from a pair's dis
 #pragma unroll
-  for (int k = 0; k < NP; ++k) { sv_kw[k] = 0u; sv_hw[k] = 0u; sneg[k] = 0u; }
+  for (int k = 0; k < NP; ++k) { sv_kw[k] = 0u; sv_hw[k] = 0u; sv_gw[k] = 0u; sneg[k] = 0u; }
   int pos = 0;
   if constexpr (half_mode) {
     if (seg_begin > 0) {
@@ -2673,11 +2680,13 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
     if (!half_mode) {
       // a GROUP step of a pair in row mode needs the last position of every row's tie group in the gathered column ->
       // gathered one step ahead, beside the rec values (both columns of the block in one entry)
-      bool any_row = false;
+      // (a pair in count mode: the rows' tie-group indices likewise)
+      bool any_row = false, any_cnt = false;
 #pragma unroll
-      for (int k = 0; k < NP; ++k) any_row = any_row || (ntgB[k] < 0);
-      hi_ok = kind == 2 && any_row;   // after a GROUP step the next one is most likely a GROUP step too
-      if (hi_ok) hi_pre = gload_u32(hi_blk, r0);
+      for (int k = 0; k < NP; ++k) { any_row = any_row || (ntgB[k] < 0); any_cnt = any_cnt || (ntgB[k] >= 0 && cntB[k]); }
+      hi_ok = kind == 2 && (any_row || any_cnt);   // after a GROUP step the next one is most likely a GROUP step too
+      if (hi_ok && any_row) hi_pre = gload_u32(hi_blk, r0);
+      if (hi_ok && any_cnt) gi_pre = gload_u32(gi_blk, r0);
     }
     if constexpr (half_mode) {
       // the next step is a GROUP step and a pair counts its joint ties row by row: the ends of the rows' tie groups
@@ -2928,13 +2937,21 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         // `seen` stands still, the group's rows enter `seen` when it closes (one or two steps: from registers, each step's
         // rows with an incremental update of the counts; longer: streamed again, the counts rebuilt once), joint ties from
         // range counts before / after (list mode: <= 2 listed groups per lane; row mode: per row, phase C)
-        bool any_row = false;
+        // count mode (round 4; gathered columns of more than 128 tie groups, while a pair's counter table covers them): a
+        // row adds one to the counter of its tie group (girow) in phase A, the close reads the counters back -- no third pass
+        bool any_row = false, any_cnt = false;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) any_row = any_row || (ntgB[k] < 0);
+        for (int k = 0; k < NP; ++k) { any_row = any_row || (ntgB[k] < 0); any_cnt = any_cnt || (ntgB[k] >= 0 && cntB[k]); }
         if (!grp_open) { grp_start = pos_step; grp_entries = 0; }
         TwoLevel T[NP];
-        uint32_t hk[NP];
+        uint32_t hk[NP], gk[NP];
+        cnt_t* cntT[NP];
         const uint32_t hv = any_row ? (hi_now_ok ? hi_now : gload_u32(hi_blk, row)) : 0u;
+        const uint32_t gv = any_cnt ? (hi_now_ok ? gi_now : gload_u32(gi_blk, row)) : 0u;
+        auto cnt_take = [&](cnt_t* t, uint32_t g) -> uint32_t {   // rows of the group in tie group g but one
+          const uint32_t c = (uint32_t)t[min(g, (uint32_t)cnt_cap)];
+          return (g < (uint32_t)cnt_cap) ? c - 1u : 0u;
+        };
         auto rangeT = [&](const TwoLevel& Tk, uint32_t r) -> uint32_t {   // r = lo | hi << 16
           return tl_query(Tk, (r >> 16) + 1u, IT, magic) - tl_query(Tk, r & 0xFFFFu, IT, magic);
         };
@@ -2944,11 +2961,15 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
           T[k] = tl_view(S[k].L.seen, S[k].L.spre);
+          cntT[k] = reinterpret_cast<cnt_t*>(reinterpret_cast<unsigned char*>(S[k].L.spre) + TL_BYTES);
           hk[k] = comp[k] ? (hv >> 16) : (hv & 0xFFFFu);
+          // (GIROW_NONE, a row that is its own tie group, and the rows beyond the step: no counter)
+          gk[k] = valid ? min(comp[k] ? (gv >> 16) : (gv & 0xFFFFu), (uint32_t)cnt_cap) : (uint32_t)cnt_cap;
           // phase A: rows of strictly higher groups below each row's tie group
           const uint32_t c = valid ? tl_query(T[k], rk[k] >> 16, IT, magic) : 0u;
           S[k].dis += c;
           if (ntgB[k] < 0) S[k].tie2 -= valid ? (tl_query(T[k], hk[k] + 1u, IT, magic) - c) : 0u;
+          else if (cntB[k] && gk[k] < (uint32_t)cnt_cap) cnt_inc(cntT[k], gk[k]);
         }
         if (closes) {
           const int kept = grp_entries;
@@ -2960,7 +2981,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
             for (int i = 0; i < 2; ++i) {
               bef[k][i] = 0u;
               const int g = (int)lane + 64 * i;
-              if (g < ntgB[k]) bef[k][i] = rangeT(T[k], tgB[k][g]);
+              if (!cntB[k] && g < ntgB[k]) bef[k][i] = rangeT(T[k], tgB[k][g]);
             }
           }
           wave_lds_fence();
@@ -3007,11 +3028,42 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const int g = (int)lane + 64 * i;
-              if (g < ntgB[k]) {
+              if (!cntB[k] && g < ntgB[k]) {
                 const uint32_t c = rangeT(T[k], tgB[k][g]) - bef[k][i];
                 S[k].tie += c * (c - 1u) / 2u;
               }
             }
+          }
+          // count mode: the counters hold, per tie group of the gathered column, the rows of this group: a group of one or two
+          // steps reads them back by row (c - 1 each: every pair twice, tie2) and clears what it touched, a longer one by tie group
+          if (any_cnt) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              if (ntgB[k] >= 0 && cntB[k]) {
+                if (kept <= 1) {
+                  uint32_t e = cnt_take(cntT[k], gk[k]);
+                  if (kept == 1) e += cnt_take(cntT[k], sv_gw[k]);
+                  S[k].tie2 += e;
+                } else {
+                  for (int g = (int)lane; g < ntgB[k]; g += 64) {
+                    const uint32_t c = (uint32_t)cntT[k][g];
+                    S[k].tie += c * (c - 1u) / 2u;
+                    cntT[k][g] = 0;
+                  }
+                }
+              }
+            }
+            if (kept <= 1) {
+              wave_lds_fence();
+#pragma unroll
+              for (int k = 0; k < NP; ++k) {
+                if (ntgB[k] >= 0 && cntB[k]) {
+                  cntT[k][gk[k]] = 0;                          // (entry cnt_cap: the scratch entry of the rows without a counter)
+                  if (kept == 1) cntT[k][sv_gw[k]] = 0;
+                }
+              }
+            }
+            wave_lds_fence();
           }
           // phase C (row mode): rows of the group in each row's cell, the row itself excluded
           if (any_row) {
@@ -3050,7 +3102,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         } else {
           if (grp_entries == 0) {   // (a step that does not close has 64 rows)
 #pragma unroll
-            for (int k = 0; k < NP; ++k) { sv_kw[k] = rk[k]; sv_hw[k] = hk[k]; }
+            for (int k = 0; k < NP; ++k) { sv_kw[k] = rk[k]; sv_hw[k] = hk[k]; sv_gw[k] = gk[k]; }
           }
           ++grp_entries;
           grp_open = true;
@@ -3077,24 +3129,31 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           }
           if (pos + 64 < gend) {
             uint32_t hvn = any_row ? (hi_ok ? hi_pre : gload_u32(hi_blk, r0)) : 0u;   // the next step's rows are in r0
+            uint32_t gvn = any_cnt ? (hi_ok ? gi_pre : gload_u32(gi_blk, r0)) : 0u;
             do {
               uint32_t rkl[NP];
               take_rk(rkl);                           // (rk_ok: the ring moved on by a 64-row step)
-              const uint32_t hvl = hvn;
+              const uint32_t hvl = hvn, gvl = gvn;
               pos += 64;
               advance64();
               if (any_row) hvn = gload_u32(hi_blk, r0);
+              if (any_cnt) gvn = gload_u32(gi_blk, r0);
 #pragma unroll
               for (int k = 0; k < NP; ++k) {
                 const uint32_t c = tl_query(T[k], rkl[k] >> 16, IT, magic);
                 S[k].dis += c;
                 if (ntgB[k] < 0) S[k].tie2 -= tl_query(T[k], (comp[k] ? (hvl >> 16) : (hvl & 0xFFFFu)) + 1u, IT, magic) - c;
+                else if (cntB[k]) {
+                  const uint32_t g = comp[k] ? (gvl >> 16) : (gvl & 0xFFFFu);
+                  if (g < (uint32_t)cnt_cap) cnt_inc(cntT[k], g);
+                }
               }
               ++grp_entries;
               ICIKT_ST_MARK(3, 64)
             } while (pos + 64 < gend);
             hi_pre = hvn;
-            hi_ok = any_row;
+            gi_pre = gvn;
+            hi_ok = any_row || any_cnt;
             fw_word = -1;                             // the flag window is read again
           }
         }

@@ -691,6 +691,31 @@ def test_joint_tie_counting_modes(plan_ctx, plan):
         _check(hip_ctx, X, perspective=p)
 
 
+@pytest.mark.parametrize("n", [20000, 33000, 50000, 65535])
+@pytest.mark.parametrize("plan", [None, {"np": "1"}, {"tgmax": "1000000"}, {"tgmax": "300", "half": "0"}, {"tgmax": "-1"}])
+def test_whole_wave_count_mode(plan_ctx, n, plan):
+    """Count mode of the whole-wave kernels (columns too long for the half-wave ones, or `half=0`): a counter per tie group of
+    the gathered column -- the pre-pass writes girow for long columns of more than eight tie groups -- against list and row mode,
+    on streamed groups of one step, two (rows kept in registers), and many (counters read back by tie group), with gathered
+    columns of ~10, ~150 (list), ~300, ~900 (count) and thousands (row mode, or count mode when the table is forced) of groups."""
+    plan_ctx.debug_set_plan(plan)
+    rng = np.random.default_rng(n + 5)
+    base = rng.standard_normal((n, 8))
+    X = np.empty((n, 8))
+    X[:, 0] = np.round(base[:, 0] * 1.5)          # ~10 groups of thousands of rows
+    X[:, 1] = np.round(base[:, 1] * 25)           # ~150 groups
+    X[:, 2] = np.round(base[:, 2] * 50)           # ~300
+    X[:, 3] = np.round(base[:, 3] * 150)          # ~900
+    X[:, 4] = np.round(base[:, 4] * 1000)         # thousands of short groups
+    X[:, 5] = base[:, 5]                          # continuous
+    X[:, 6] = np.round(0.7 * base[:, 2] * 50 + 0.3 * base[:, 6] * 50)   # correlated with column 2: joint ties
+    X[:, 7] = np.repeat(np.arange((n + 99) // 100), 100)[:n]           # groups of 100 rows, contiguous in row order
+    X[rng.random(X.shape) < 0.04] = np.nan
+    _check(plan_ctx, X, perspective="global")
+    if n <= 33000:
+        _check(plan_ctx, X, perspective="local")
+
+
 @pytest.mark.parametrize("n", [900, 6887, 10000, 18000, 30000])
 @pytest.mark.parametrize("plan", [None, {"solo": "0"}, {"list": "0", "tgmax": "1000000"}, {"waves": "4"}])
 def test_tie_program_step_kinds(plan_ctx, n, plan):

@@ -3199,14 +3199,26 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
       }
       seg_tie += tl;
-      uint32_t row_next = r0;
-      for (int p = last_start; p < n; p += 64) {
-        const int kpos = p + (int)lane;
-        const uint2 rv = gload_rec2(rec_blk, row_next);
-        row_next = gload_u16(ord, (uint32_t)(kpos + 64));
-        if (kpos < n) {
+      // (four 64-row chunks per turn: four gathers in flight and the next turn's rows behind them -- one chunk per turn, each gather
+      //  waiting for its row, was a memory round trip per 64 rows: a fill group of 1 000 rows cost a task sixteen of them)
+      {
+        uint32_t rw[4];
+        rw[0] = r0;
 #pragma unroll
-          for (int k = 0; k < NP; ++k) S[k].dis += (comp[k] ? rv.y : rv.x) >> 16;
+        for (int i = 1; i < 4; ++i) rw[i] = gload_u16(ord, min((uint32_t)(last_start + 64 * i) + lane, (uint32_t)n));   // (order[n ..]: zero padding)
+        for (int p = last_start; p < n; p += 256) {
+          uint2 rv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rv[i] = gload_rec2(rec_blk, rw[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rw[i] = gload_u16(ord, min((uint32_t)(p + 256 + 64 * i) + lane, (uint32_t)n));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (p + 64 * i + (int)lane < n) {
+#pragma unroll
+              for (int k = 0; k < NP; ++k) S[k].dis += (comp[k] ? rv[i].y : rv[i].x) >> 16;
+            }
+          }
         }
       }
       const unsigned long long m = (unsigned long long)(n - last_start);
@@ -3232,21 +3244,33 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
         }
         S[k].tie += tl[k];
       }
-      uint32_t row_next = r0;
-      for (int p = last_start; p < n; p += 64) {
-        const int kpos = p + (int)lane;
-        uint32_t rkt[NP];
-        if (NP == 2) {
-          const uint2 rv = gload_rec2(rec_blk, row_next);
+      // (four 64-row chunks per turn, as in the half-wave kernels above)
+      {
+        uint32_t rw[4];
+        rw[0] = r0;
 #pragma unroll
-          for (int k = 0; k < NP; ++k) rkt[k] = comp[k] ? rv.y : rv.x;
-        } else {
-          rkt[0] = gload_u32(rec_blk, 2u * row_next + comp[0]);
-        }
-        row_next = gload_u16(ord, (uint32_t)(kpos + 64));
-        if (kpos < n) {
+        for (int i = 1; i < 4; ++i) rw[i] = gload_u16(ord, min((uint32_t)(last_start + 64 * i) + lane, (uint32_t)n));   // (order[n ..]: zero padding)
+        for (int p = last_start; p < n; p += 256) {
+          uint32_t rkt[4][NP];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) S[k].dis += rkt[k] >> 16;
+          for (int i = 0; i < 4; ++i) {
+            if (NP == 2) {
+              const uint2 rv = gload_rec2(rec_blk, rw[i]);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) rkt[i][k] = comp[k] ? rv.y : rv.x;
+            } else {
+              rkt[i][0] = gload_u32(rec_blk, 2u * rw[i] + comp[0]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rw[i] = gload_u16(ord, min((uint32_t)(p + 256 + 64 * i) + lane, (uint32_t)n));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (p + 64 * i + (int)lane < n) {
+#pragma unroll
+              for (int k = 0; k < NP; ++k) S[k].dis += rkt[i][k] >> 16;
+            }
+          }
         }
       }
       const unsigned long long m = (unsigned long long)(n - last_start);

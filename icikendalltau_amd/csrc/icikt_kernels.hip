@@ -2987,17 +2987,29 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
           wave_lds_fence();
           // phase B: the group's rows enter `seen`
           if (kept <= 1) {
+            // (the rows of both steps and both pairs first -- bits and the counts inside their owners -- then ONE collection of
+            //  the owners' histogram per pair: four incremental updates one after the other were a dozen LDS round trips per close)
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
               if (kept == 1) {
                 seen_insert(S[k].L.seen, sv_kw[k] & 0xFFFFu);
-                tl_update(T[k], true, sv_kw[k] & 0xFFFFu, IT, magic, lane);
-                wave_lds_fence();
+                tl_update_rows(T[k], sv_kw[k]);
               }
-              if (valid) seen_insert(S[k].L.seen, rk[k] & 0xFFFFu);
-              tl_update(T[k], valid, rk[k] & 0xFFFFu, IT, magic, lane);
-              wave_lds_fence();
+              if (valid) {
+                seen_insert(S[k].L.seen, rk[k] & 0xFFFFu);
+                tl_update_rows(T[k], rk[k]);
+              }
             }
+            wave_lds_fence();
+            uint32_t hcol[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) hcol[k] = atomicExch(&T[k].hist[lane], 0u);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              const uint32_t below = wave_incl_scan(hcol[k]) - hcol[k];
+              if (below != 0u) atomicAdd(&T[k].lb[lane], below);
+            }
+            wave_lds_fence();
           } else {
             uint32_t rw = gload_u16(ord, (uint32_t)grp_start + lane);
             uint32_t rw_n = gload_u16(ord, (uint32_t)grp_start + 64u + lane);

@@ -239,7 +239,10 @@ K1Plan plan_k1(const PrepView& pv, int64_t n_pairs, int n_cu, const icikt_ctx::P
       // the prepared columns hold more tie groups than that (matrix_tied's read-back): a table that covers them is worth one wave
       // of eight -- count-like data, 50 000 x 96, ~630 tie groups per column (at most 940): 2.76 ms with 512 counters at eight
       // waves per CU, 2.48 with 1 024 at seven
-      if (ntg_hint > cap && target >= 6) {
+      // (... when a tied pair of rows sits, on average, in a group of 256 rows or more: groups of one or two steps close from
+      //  registers in row mode, for less than the counters and the lost wave cost -- 50 000 x 128 columns of ~1 000 tie groups of
+      //  ~120 rows: 5.24 ms in row mode, 5.77 with the table)
+      if (ntg_hint > cap && group_hint >= 256 && target >= 6) {
         for (int i = (int)(sizeof(caps) / sizeof(caps[0])) - 1; i >= 0; --i) {
           if (caps[i] < ntg_hint) continue;
           if (waves_any(pair_bytes(caps[i])) >= target - 1) cap = caps[i];

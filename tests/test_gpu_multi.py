@@ -96,6 +96,30 @@ def test_multi_longer_columns_and_degenerate(single):
         m.close()
 
 
+def test_multi_long_tied_columns_count_mode(single):
+    """Columns too long for the half-wave kernels, tied: the rows' tie-group indices that the whole-wave kernels' count mode
+    reads are rebuilt on the receiving rank (the expand kernel) -- two ranks against one device, and the oracle on a few pairs."""
+    from icikendalltau_amd import _lib
+    from oracle import oracle as O
+    m = _lib.MultiContext([0, 0], exchange="copy")
+    try:
+        rng = np.random.default_rng(77)
+        n, S = 36000, 18                                 # 153 pairs: enough for the entry to use both ranks
+        X = np.round(rng.standard_normal((n, S)) * np.array([2, 30, 60, 150, 60, 30, 2, 500, 60, 60, 30, 150, 60, 30, 150, 60, 2, 30]))
+        X[rng.random(X.shape) < 0.05] = np.nan
+        X = np.asfortranarray(X)
+        got = m.pairs(X, perspective="global")
+        assert m.ranks_used == 2
+        _same(got, single.pairs(X, perspective="global"))
+        pi = np.array([0, 2, 3, 7, 12], dtype=np.int32)
+        pj = np.array([2, 4, 11, 8, 15], dtype=np.int32)
+        ref, rcnt, rrsn = O.ici_pairs(X, pi, pj, "global")
+        idx = [int(i * S - i * (i + 1) // 2 + (j - i - 1)) for i, j in zip(pi, pj)]
+        assert np.array_equal(got[1][idx], rcnt[:, :got[1].shape[1]]) and np.allclose(got[0][idx], ref, rtol=0, atol=1e-10, equal_nan=True)
+    finally:
+        m.close()
+
+
 def test_multi_error_contract():
     import ctypes
     from icikendalltau_amd import _lib

@@ -537,7 +537,7 @@ void icikt_ctx_destroy(icikt_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   c->order.release(); c->hirow.release(); c->girow.release(); c->rec.release(); c->meta.release();
-  c->tgroups.release(); c->tprog.release(); c->smask.release(); c->srow.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->k0_bits.release();
+  c->tgroups.release(); c->tprog.release(); c->smask.release(); c->srow.release(); c->sort_keys.release(); c->sort_idx.release(); c->wide32.release(); c->order_w.release(); c->k0_bits.release();
   c->d_pi.release(); c->d_pj.release(); c->d_unit_start.release(); c->d_raw.release();
   c->d_task_ctr.release();
   c->d_X.release(); c->d_Xp.release(); c->d_out4.release(); c->d_counts.release(); c->d_reasons.release(); c->d_self.release();
@@ -674,12 +674,14 @@ int prepare_alloc(icikt_ctx* c, int64_t n_feat, int64_t n_samp, int64_t alloc_co
     pv.sr_steps = pv.tp_stride ? pv.n_pad / 17 + 8 : 0;
     HIPCHK(c, c->srow.reserve(std::max<size_t>(1, S * (size_t)pv.sr_steps * 64)));
     HIPCHK(c, c->smask.reserve(std::max<size_t>(1, S * (size_t)pv.sr_steps * 32)));
+    if (pv.tp_stride == 0) HIPCHK(c, c->order_w.reserve(S * (size_t)pv.n_ord));   // (the whole-wave kernels' ring reload: PrepView::order_w)
   }
   HIPCHK(c, c->sort_keys.reserve(chunk * np2));
   HIPCHK(c, c->sort_idx.reserve(chunk * np2));
   c->sort_chunk = (int)chunk;
 
   pv.order = c->order.p; pv.hirow = c->hirow.p; pv.girow = c->girow.p; pv.rec = c->rec.p;
+  pv.order_w = (!pv.wide && pv.tp_stride == 0) ? c->order_w.p : nullptr;
   pv.meta = c->meta.p;
   pv.sort_keys = c->sort_keys.p; pv.sort_idx = c->sort_idx.p;
   pv.tgroups = c->tgroups.p;

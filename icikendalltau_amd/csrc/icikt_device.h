@@ -85,6 +85,8 @@ struct PrepView {
   int n_samp;
   // per column, stride n_pad
   uint16_t* order;   // [S][n_ord]  row at processing position k (descending value)
+  uint32_t* order_w; // [S][n_ord]  the same as 32-bit words, for columns too long for the half-wave kernels (else nullptr): the whole-wave
+                     //              kernels reload their ring of rows from it after a step of fewer than 64 rows (k1_pairs)
   int rec_rows;      // rows of a rec / hirow block: n_pad + 8.  Row n_pad is the GUARD ROW of every column: q = n_pad (a
                      // position in the guard word of a pair kernel's bitset), lo = 0, hi = 0 -- the empty lanes of a step
                      // of the tie program name it (srow below), so that they gather "a row that never counts, is never

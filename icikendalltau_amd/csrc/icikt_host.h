@@ -46,6 +46,7 @@ struct icikt_ctx {
   icikt::PrepView pv{};
   DevBuf<uint16_t> order, hirow, girow, srow;
   DevBuf<uint32_t> wide32;                 // wide columns: order32 | q32 | lo32 | hi32, S x n_pad each
+  DevBuf<uint32_t> order_w;                // columns of more than 30 656 rows: `order` as 32-bit words (PrepView::order_w)
   DevBuf<unsigned long long> k0_bits;      // wide columns: K0's phase-3 bitsets, per column of a sort chunk
   DevBuf<uint32_t> rec, tgroups, tprog;
   DevBuf<uint2> smask;

@@ -837,6 +837,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
     for (int k = n + tid; k < pv.n_pad; k += NT) order32[k] = 0u;
   } else {
     for (int k = n + tid; k < pv.n_ord; k += NT) order[k] = 0;  // zero padding: K1 prefetches one step ahead
+    if (pv.order_w) { for (int k = n + tid; k < pv.n_ord; k += NT) pv.order_w[(int64_t)c * pv.n_ord + k] = 0u; }
   }
   __syncthreads();
   auto is_start = [&](int k) -> bool { return (sh_st[k >> 6] >> (k & 63)) & 1ull; };   // 0 <= k <= n
@@ -918,6 +919,7 @@ __device__ __forceinline__ void k0_prepare_body(const PrepView& pv, const double
       if (stage_rec) rec_s[row] = (uint32_t)k | ((uint32_t)lo << 16);
       else rec[2 * row] = (uint32_t)k | ((uint32_t)lo << 16);
       order[n - 1 - k] = (uint16_t)row;  // processing order of K1: descending value
+      if (pv.order_w) pv.order_w[(int64_t)c * pv.n_ord + (n - 1 - k)] = row;
       }
       if (lo == 0 && nna > 0) atomicOr(&sh_bits[row >> 6], 1ull << (row & 63));
       if (lo == k) {
@@ -1113,6 +1115,10 @@ __global__ void __launch_bounds__(64 * KX_WAVES) k0_expand(PrepView pv, int col_
   uint32_t* tgl = pv.tgroups + (int64_t)c * pv.tg_stride;
   if (threadIdx.x == 0) {   // the guard row (PrepView::rec_rows)
     rec[2 * pv.n_pad] = (uint32_t)pv.n_pad; hirow[2 * pv.n_pad] = 0; girow[2 * pv.n_pad] = GIROW_NONE;
+  }
+  if (pv.order_w) {   // long columns: the received order (with its zero padding) as 32-bit words
+    uint32_t* ow = pv.order_w + (int64_t)c * pv.n_ord;
+    for (int k = (int)threadIdx.x; k < pv.n_ord; k += (int)blockDim.x) ow[k] = (uint32_t)ord[k];
   }
 
   // starts of groups of size >= 2: a start whose successor position exists and is not a start
@@ -1973,6 +1979,7 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
   // streamed column (shared by the task's pairs): rows in descending order, group-start flags
   const int scol = __builtin_amdgcn_readfirstlane(pj[pidx[0]]);
   const uint16_t* ord = pv.order + (int64_t)scol * pv.n_ord;
+  const uint32_t* ord_w = pv.order_w ? pv.order_w + (int64_t)scol * pv.n_ord : nullptr;   // (long columns: the same as 32-bit words)
   const unsigned long long* gf = pv.col_gflag(scol);
   const unsigned long long* ma = pv.col_mask(scol);
   const unsigned long long* fa = pv.col_fillmask(scol);
@@ -2674,7 +2681,10 @@ k1_pairs(PrepView pv, const int32_t* __restrict__ tasks, int n_tasks,
       r1 = wrap ? a2 : a1;
       if (NP == 2) rv_pre = gload_rec2(rec_blk, r0);
       else rk_pre[0] = gload_u32(rec_blk, 2u * r0 + comp[0]);
-      r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
+      // (long columns: from the 32-bit copy of `order` -- behind the two-byte load the compiler puts its zero extension into this
+      //  very block, and every tie step then began by waiting for a memory round trip; the word load lands in r2 and nothing waits)
+      if (ord_w) r2 = gload_u32(ord_w, (uint32_t)pos + 128u + lane);
+      else r2 = gload_u16(ord, (uint32_t)pos + 128u + lane);
       rk_ok = true;
     }
     if (!half_mode) {

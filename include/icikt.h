@@ -155,7 +155,7 @@ int icikt_prep_arrays(icikt_ctx *ctx, void **ptrs, int64_t *bytes_per_col);
  * group-start bitsets + the column's statistics) carry the information: 24 KB per column of 10 000 rows, two
  * collectives.  Everything else -- ICIKT_PREP_REC, ICIKT_PREP_HIROW, ICIKT_PREP_TGROUPS (exposed for inspection: 80 KB
  * per column; a rec / hirow block has n_pad + 8 rows, row n_pad the guard row of the step records) and the state that is
- * not exposed (per-row tie-group indices, the tie program and its step records) -- is a function of a column's order
+ * not exposed (per-row tie-group indices, the tie program and its step records, the 32-bit copy of the order that long columns keep) -- is a function of a column's order
  * and group starts: icikt_expand_cols_dev() rebuilds it for the received columns [col_begin, col_end). */
 #define ICIKT_PREP_ORDER 0
 #define ICIKT_PREP_REC 1

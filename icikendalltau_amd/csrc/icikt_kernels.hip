@@ -1775,12 +1775,14 @@ __device__ __forceinline__ uint32_t seg_query(unsigned long long* seen, uint16_t
   return (SEG == 64) ? tl_query(tl_view(seen, spre), lo, IT, magic) : prefix_query_half<(HI > 0 ? HI : 1)>(seen, spre, lo);
 }
 
+// (inlined since the end of round 4: as a function of its own it began, like every callee, by waiting for ALL outstanding loads
+//  -- the next step's gather and the ring reload the caller had just issued: a memory round trip per MIXED step)
 template <int SEG, int HI>
-__device__ __attribute__((noinline)) SegCounts seg_mixed_step(const SegState st, const unsigned long long F_in, const int nact_in,
+__device__ __forceinline__ SegCounts seg_mixed_step(const SegState st, const unsigned long long F_in, const int nact_in,
                                                               const uint32_t rk, const int IT_in, const uint32_t magic_in,
                                                               const uint32_t lane) {
-  // arguments of an out-of-line function arrive in vector registers: the wave-uniform ones go back to scalar
-  // registers, or everything derived from them (the flag arithmetic, loop counters) runs on the vector unit
+  // (when this was an out-of-line function its arguments arrived in vector registers; the wave-uniform ones go back to scalar
+  //  registers -- harmless now -- or everything derived from them would run on the vector unit)
   const unsigned long long F = uniform_u64(F_in);
   const int nact = __builtin_amdgcn_readfirstlane(nact_in);
   const int IT = __builtin_amdgcn_readfirstlane(IT_in);
